@@ -1,0 +1,78 @@
+// Shared device helpers for the TubeR gfx950 kernels (wave64, MFMA bf16, LDS-tiled).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define TUBER_OK 0
+#define TUBER_EINVAL (-1)
+
+// Every extern "C" launcher ends with this: report a launch failure as its hipError_t code.
+#define TUBER_RETURN_LAUNCH()                      \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        return e__ == hipSuccess ? TUBER_OK : (int)e__; \
+    } while (0)
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+// 16-byte vector <-> 8 bf16
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ uint4 as_uint4(bf16x8 v) { return __builtin_bit_cast(uint4, v); }
+__device__ __forceinline__ bf16x4 as_bf16x4(uint2 v) { return __builtin_bit_cast(bf16x4, v); }
+__device__ __forceinline__ uint2 as_uint2(bf16x4 v) { return __builtin_bit_cast(uint2, v); }
+
+// XCD-aware block remap (8 XCDs; block b runs on XCD b % 8): give each XCD a contiguous
+// range of logical tile ids so neighbouring tiles share an L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// wave64 butterfly sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float quad16_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// Counter-based RNG for dropout: one 32-bit hash per (seed, element index).  Deterministic and
+// stateless so the backward pass regenerates the forward mask instead of storing it.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    // keep iff hash >= thresh, thresh = p * 2^32
+    uint32_t h = hash_u32((uint32_t)idx ^ hash_u32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
+    return h >= thresh;
+}

@@ -1,0 +1,183 @@
+// Small HBM-bound helpers of the TubeR path (gfx950): dtype casts / weight repacks, row gathers
+// with broadcast or reduction, temporal pooling, sigmoid, dropout, adds.  16-byte accesses.
+#include "common.h"
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *(const float4*)(s + i), b = *(const float4*)(s + i + 4);
+        bf16x8 v = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w), f2bf(b.x), f2bf(b.y), f2bf(b.z), f2bf(b.w)};
+        *(uint4*)(d + i) = as_uint4(v);
+    } else {
+        for (long j = i; j < n; ++j) d[j] = f2bf(s[j]);
+    }
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ s, float* __restrict__ d, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = bf2f(s[i]);
+}
+
+// W[R][C] fp32 -> WT[C][ldt] bf16 (transposed repack for the data-gradient GEMM), 32x32 LDS tiles
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ W, bf16* __restrict__ WT, int R, int C, int ldt) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) t[j][tx] = (r0 + j < R && c0 + tx < C) ? W[(long)(r0 + j) * C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) WT[(long)(c0 + j) * ldt + r0 + tx] = f2bf(t[tx][j]);
+}
+
+// out[(a,b,c)][:] = sum_{d<D} in[a*sa + b*sb + c*sc + d*sd][:]  (rows of E bf16, E % 8 == 0)
+__global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int A, int B, int Cc,
+                                                              int D, long sa, long sb, long sc, long sd, int E, float mul) {
+    const int epr = E >> 3;
+    const long total = (long)A * B * Cc * epr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % epr); long r = i / epr;
+        const int c = (int)(r % Cc); long q = r / Cc;
+        const int b = (int)(q % B); const int a = (int)(q / B);
+        const long src = (long)a * sa + (long)b * sb + (long)c * sc;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const bf16x8 v = as_bf16x8(*(const uint4*)(in + (src + (long)d * sd) * E + ch * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * mul);
+        *(uint4*)(out + r * E + ch * 8) = as_uint4(o);
+    }
+}
+
+// out = alpha*a + beta*b   (bf16, n % 8 == 0)
+__global__ void axpby_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, long n8, float alpha, float beta) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 x = as_bf16x8(((const uint4*)a)[i]);
+        bf16x8 y = bf16x8{};
+        if (b) y = as_bf16x8(((const uint4*)b)[i]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(alpha * bf2f(x[e]) + (b ? beta * bf2f(y[e]) : 0.f));
+        ((uint4*)out)[i] = as_uint4(o);
+    }
+}
+
+// in-place (or out-of-place) dropout with the stateless hash RNG: y = keep ? x/(1-p) : 0
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long n8, uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 v = as_bf16x8(((const uint4*)x)[i]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = dropout_keep(seed, (uint64_t)i * 8 + e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : (bf16)0.f;
+        ((uint4*)y)[i] = as_uint4(o);
+    }
+}
+
+// y = sigmoid(x) (fp32);  bwd: dx = dy * y * (1 - y)
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.f / (1.f + __expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+
+// dx = dy * [h > 0]   (ReLU backward from the saved post-activation)
+__global__ void relu_mask_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h, bf16* __restrict__ dx, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 g = as_bf16x8(((const uint4*)dy)[i]);
+        const bf16x8 a = as_bf16x8(((const uint4*)h)[i]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(a[e]) > 0.f ? g[e] : (bf16)0.f;
+        ((uint4*)dx)[i] = as_uint4(o);
+    }
+}
+
+// PositionEmbeddingSine_3D (models/transformer/position_encoding.py:32-72) for a (B,T,H,W) bool mask,
+// written token-major: out[((b*T + t)*H + y)*W + x][hidden] bf16 (and fp32 NCDHW-free); normalize=True,
+// scale 2*pi, eps 1e-6, temperature 1e4; channels = [t: hidden/4 | y: 3*hidden/8 | x: 3*hidden/8].
+__global__ void posenc_kernel(const uint8_t* __restrict__ mask, bf16* __restrict__ out, int B, int T, int H, int W, int hidden) {
+    const long tok = blockIdx.x;
+    const int x = (int)(tok % W); long r = tok / W;
+    const int y = (int)(r % H); r /= H;
+    const int t = (int)(r % T); const int b = (int)(r / T);
+    __shared__ float emb[3];
+    if (threadIdx.x < 3) {
+        // cumulative count of non-masked positions up to (and including) this one, and the axis total
+        float cum = 0.f, tot = 0.f;
+        if (threadIdx.x == 0) { for (int i = 0; i < T; ++i) { const float v = mask[(((long)b * T + i) * H + y) * W + x] ? 0.f : 1.f; tot += v; if (i <= t) cum += v; } }
+        if (threadIdx.x == 1) { for (int i = 0; i < H; ++i) { const float v = mask[(((long)b * T + t) * H + i) * W + x] ? 0.f : 1.f; tot += v; if (i <= y) cum += v; } }
+        if (threadIdx.x == 2) { for (int i = 0; i < W; ++i) { const float v = mask[(((long)b * T + t) * H + y) * W + i] ? 0.f : 1.f; tot += v; if (i <= x) cum += v; } }
+        emb[threadIdx.x] = cum / (tot + 1e-6f) * 6.283185307179586f;
+    }
+    __syncthreads();
+    const int nt = hidden / 4, ns = hidden * 3 / 8;
+    for (int c = threadIdx.x; c < hidden; c += blockDim.x) {
+        int axis, i, nf;
+        if (c < nt) { axis = 0; i = c; nf = nt; } else if (c < nt + ns) { axis = 1; i = c - nt; nf = ns; } else { axis = 2; i = c - nt - ns; nf = ns; }
+        const float div = powf(10000.f, (float)(2 * (i / 2)) / (float)nf);
+        const float v = emb[axis] / div;
+        out[tok * hidden + c] = f2bf((i & 1) ? cosf(v) : sinf(v));
+    }
+}
+
+static inline int grid1(long n, int cap = 8192) { long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+
+extern "C" {
+
+int tuber_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ceil_div(ceil_div(n, 8), 256)), dim3(256), 0, stream, src, (bf16*)dst, n);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_cast_bf16_f32(const void* src, float* dst, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, (const bf16*)src, dst, n);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_cast_transpose(const float* W, void* WT, int R, int C, int ldt, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, stream, W, (bf16*)WT, R, C, ldt);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_rows_gather_sum(const void* in, void* out, int A, int B, int C, int D, long sa, long sb, long sc, long sd, int E, float mul,
+                          hipStream_t stream) {
+    if (E & 7) return TUBER_EINVAL;
+    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(grid1((long)A * B * C * (E / 8))), dim3(256), 0, stream, (const bf16*)in, (bf16*)out,
+                       A, B, C, D, sa, sb, sc, sd, E, mul);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, hipStream_t stream) {
+    if (n & 7) return TUBER_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)out, n / 8, alpha, beta);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_dropout(const void* x, void* y, long n, float p, unsigned long long seed, hipStream_t stream) {
+    if ((n & 7) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8,
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), (uint64_t)seed);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_sigmoid_fwd(const float* x, float* y, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, x, y, n);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, dy, y, dx, n);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_relu_mask(const void* dy, const void* h, void* dx, long n, hipStream_t stream) {
+    if (n & 7) return TUBER_EINVAL;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)h, (bf16*)dx, n / 8);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_posenc(const void* mask, void* out, int B, int T, int H, int W, int hidden, hipStream_t stream) {
+    if (hidden % 8) return TUBER_EINVAL;
+    hipLaunchKernelGGL(posenc_kernel, dim3(B * T * H * W), dim3(64), 0, stream, (const uint8_t*)mask, (bf16*)out, B, T, H, W, hidden);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,570 @@
+// MFMA bf16 GEMMs for the TubeR hot path (gfx950, wave64).
+//
+//   gemm_nt : C[M,N] = f(A)[M,K] . B[N,K]^T      forward of every 1x1x1 conv / nn.Linear,
+//                                                 and the data-gradient (with W^T as B)
+//   gemm_tn : C[N,K] = sum_m G[m,N]^T . f(A)[m,K] weight gradient (split over M, fp32 partials)
+//
+// Activations are NDHWC / token-major, i.e. row-major [M, C] bf16 with the channel dimension
+// contiguous, so a pointwise conv IS a row-major GEMM (reference: nn.Conv3d(k=1) in
+// models/backbones/ir_CSN_152.py:41,58,155-161 and nn.Linear throughout models/transformer/*).
+//
+// Tiling: 256 threads = 4 waves; BK = 64 (128-byte LDS rows, one full cache line per row per
+// k-tile); LDS rows XOR-swizzled in 16-byte chunks so every ds_read_b128 lane group is
+// conflict-free; double-buffered LDS with register prefetch of the next k-tile.
+// The MFMA is issued "swapped" (weights as the A operand, activations as the B operand) with a
+// permuted weight-row -> MFMA-row assignment, so each lane ends up holding 4*NT consecutive
+// output columns of one output row and stores them with 16-byte stores.
+//
+// Fused prologue (A operand): BatchNorm apply + ReLU of the producer's raw conv output
+// (a = relu(x*scale[k]+shift[k])), optional strided row gather (down_sample convs).
+// Fused epilogues: bias / ReLU / residual add; per-column partial statistics (sum, sum of
+// squares) for training-mode BatchNorm; ReLU-mask + BN-backward partial statistics.
+#include "common.h"
+
+enum { A_PLAIN = 0, A_BN_RELU = 1 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2 };
+
+struct GemmNT {
+    const bf16* A; long lda;
+    const bf16* B; long ldb;
+    void* C; long ldc;
+    int M, N, K;
+    const float* a_scale; const float* a_shift;   // A_BN_RELU
+    int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss; // row gather (strided 1x1x1 conv)
+    const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
+    float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
+    const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
+};
+
+__device__ __forceinline__ int swz_act(int row) { return (row >> 1) & 7; }
+template <int NT>
+__device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = L % tiles_n, tile_m = L / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K / 64;
+
+    // ---- staging assignment: chunk c = tid + 256*i -> (row = c>>3, q = c&7) ----
+    const int q = tid & 7;
+    const bf16* a_ptr[CA];
+    bool a_ok[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        long src = m;
+        if (p.gather && a_ok[i]) {
+            int w = m % p.Wo; int r = m / p.Wo;
+            int h = r % p.Ho; r /= p.Ho;
+            int t = r % p.To; int n = r / p.To;
+            src = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)h * p.ss) * p.Wi + (long)w * p.ss;
+        }
+        a_ptr[i] = p.A + src * p.lda + q * 8;
+    }
+    const bf16* b_ptr[CB];
+    bool b_ok[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        b_ok[i] = (n0 + row) < p.N;
+        b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + q * 8;
+    }
+
+    uint4 ra[CA], rb[CB];
+    float4 sc0, sc1, sh0, sh1;
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ra[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CB; ++i) rb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        if (AMODE == A_BN_RELU) {
+            const float4* s = (const float4*)(p.a_scale + k0 + q * 8);
+            const float4* h = (const float4*)(p.a_shift + k0 + q * 8);
+            sc0 = s[0]; sc1 = s[1]; sh0 = h[0]; sh1 = h[1];
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            uint4 v = ra[i];
+            if (AMODE == A_BN_RELU) {
+                bf16x8 x = as_bf16x8(v), y;
+                const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sc[e], sh[e]), 0.f));
+                v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
+            }
+            *(uint4*)(sa + row * 128 + ((q ^ swz_act(row)) << 4)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *(uint4*)(sb + row * 128 + ((q ^ swz_wgt<NT>(row)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15;
+    int a_row[MT], w_row[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_row[i] = wm * TM + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);
+
+    load_tile(0);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile(buf);
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* sa = smem + buf * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int qq = ks * 4 + g;
+            bf16x8 xa[MT], wb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                xa[i] = as_bf16x8(*(const uint4*)(sa + a_row[i] * 128 + ((qq ^ swz_act(a_row[i])) << 4)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wb[j] = as_bf16x8(*(const uint4*)(sb + w_row[j] * 128 + ((qq ^ swz_wgt<NT>(w_row[j])) << 4)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
+    constexpr int NC = 4 * NT;
+    const int nb = n0 + wn * TN + g * NC;
+    const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
+    float s0[NC], s1[NC];
+    if (EPI != EPI_PLAIN) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; }
+    }
+    float msc[NC], msh[NC];
+    if (EPI == EPI_BWD) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool ok = nb + c < p.N;
+            msc[c] = (p.m_scale && ok) ? p.m_scale[nb + c] : 1.f;
+            msh[c] = (p.m_shift && ok) ? p.m_shift[nb + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * TM + i * 16 + li;
+        const bool mok = m < p.M;
+        float v[NC];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+        if (EPI == EPI_PLAIN) {
+            if (p.bias) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += p.bias[nb + c];
+            }
+            if (p.R && mok) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+        } else if (EPI == EPI_STATS) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
+        } else {  // EPI_BWD: dz = acc * [relu'(bn(c))];  stats: sum dz, sum dz*c
+            if (mok) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (nb + c < p.N) {
+                        const float cv = bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
+                        const float z = fmaf(cv, msc[c], msh[c]);
+                        v[c] = z > 0.f ? v[c] : 0.f;
+                        s0[c] += v[c]; s1[c] += v[c] * cv;
+                    }
+                }
+            }
+        }
+        if (mok) {
+            if (EPI == EPI_PLAIN && p.out_f32) {
+                float* o = (float*)p.C + (long)m * p.ldc + nb;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (nb + c < p.N) o[c] = v[c];
+            } else {
+                bf16* o = (bf16*)p.C + (long)m * p.ldc + nb;
+                if (vec_ok) {
+#pragma unroll
+                    for (int c8 = 0; c8 < NC / 8; ++c8) {
+                        bf16x8 y;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = f2bf(v[c8 * 8 + e]);
+                        *(uint4*)(o + c8 * 8) = as_uint4(y);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) if (nb + c < p.N) o[c] = f2bf(v[c]);
+                }
+            }
+        }
+    }
+    if (EPI != EPI_PLAIN && p.stat0) {
+        // one partial row per workgroup tile: reduce the 16 lanes sharing g, then the WM waves via LDS
+        __syncthreads();
+        float* red = (float*)smem;                       // [WM][BN][2]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float a = quad16_sum(s0[c]);
+            const float b = quad16_sum(s1[c]);
+            if (li == 0) {
+                const int col = wn * TN + g * NC + c;
+                red[(wm * BN + col) * 2 + 0] = a;
+                red[(wm * BN + col) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+            p.stat0[(long)tile_m * p.N + n0 + tid] = a;
+            p.stat1[(long)tile_m * p.N + n0 + tid] = b;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    const size_t lds = 2 * (BM + BN) * 128;
+    dim3 grid(tiles), block(256);
+#define LNT(AM, EP) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AM, EP>), grid, block, lds, s, p)
+    if (amode == A_PLAIN) {
+        if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
+        else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
+        else LNT(A_PLAIN, EPI_BWD);
+    } else {
+        if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
+        else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
+        else LNT(A_BN_RELU, EPI_BWD);
+    }
+#undef LNT
+    TUBER_RETURN_LAUNCH();
+}
+
+// tile choice: (cfg 0) 128x128, (1) 128x64, (2) 64x64
+static int nt_pick_cfg(int M, int N) {
+    if (N <= 64) return (long)ceil_div(M, 128) >= 256 ? 1 : 2;
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    return t128 >= 192 ? 0 : 2;
+}
+static void nt_cfg_dims(int cfg, int* bm, int* wm) {
+    if (cfg == 0) { *bm = 128; *wm = 2; }
+    else if (cfg == 1) { *bm = 128; *wm = 4; }
+    else { *bm = 64; *wm = 2; }
+}
+
+extern "C" {
+
+// number of partial-statistics rows gemm_nt writes for (M, N): the caller sizes stat0/stat1 as
+// [rows][N] floats and hands the same row count to the finalize kernels.
+int tuber_gemm_nt_stat_rows(int M, int N) {
+    int bm, wm;
+    nt_cfg_dims(nt_pick_cfg(M, N), &bm, &wm);
+    return ceil_div(M, bm);
+}
+
+int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                  int amode, const float* a_scale, const float* a_shift,
+                  int gather, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
+                  int epi, const float* bias, const void* R, long ldr, int relu, int out_f32,
+                  float* stat0, float* stat1,
+                  const void* Cm, long ldcm, const float* m_scale, const float* m_shift,
+                  hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7)) return TUBER_EINVAL;
+    if (amode == A_BN_RELU && (!a_scale || !a_shift)) return TUBER_EINVAL;
+    if (epi == EPI_BWD && !Cm) return TUBER_EINVAL;
+    if (epi != EPI_PLAIN && out_f32) return TUBER_EINVAL;
+    GemmNT p;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.a_scale = a_scale; p.a_shift = a_shift;
+    p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
+    p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
+    p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
+    switch (nt_pick_cfg(M, N)) {
+        case 0: return launch_nt_cfg<128, 128, 2, 2>(p, amode, epi, stream);
+        case 1: return launch_nt_cfg<128, 64, 4, 1>(p, amode, epi, stream);
+        default: return launch_nt_cfg<64, 64, 2, 2>(p, amode, epi, stream);
+    }
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// gemm_tn: dW[N,K] = sum_m G[m,N]^T . f(A)[m,K]   (both operands are m-major in HBM)
+// =====================================================================================
+// Each workgroup owns one 128(N) x 128(K) output tile and one slab of M; per step it stages
+// 64 rows of G and A, transposing 4x4 bf16 blocks in registers so the LDS image is
+// [col][m] with m contiguous (the k-contiguous layout the MFMA fragments need), then runs the
+// same fragment reads / MFMA as gemm_nt.  Slab partials are fp32 [S][N][K]; a second kernel
+// sums the slabs (deterministic; no atomics).
+struct GemmTN {
+    const bf16* G; long ldg;     // [M, N]
+    const bf16* A; long lda;     // [M, K]
+    float* P;                    // partials [S][N][K]
+    int M, N, K, S, rows_per_slab;
+    const float* a_scale; const float* a_shift;   // A_BN_RELU on A (per k column)
+    int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
+};
+
+// transposed staging: the 64 x 128 tile (m x col) is cut in 4x4 blocks; thread -> block
+// (mi = 0..15 along m, ci = 0..31 along col).  Lane mapping keeps 128-byte global segments
+// (16 consecutive ci per row) and spreads the transposed 8-byte LDS writes over banks.
+template <int AMODE>
+__device__ __forceinline__ void tn_stage_store(char* dst, const uint2 (&r)[4], int mi, int ci, bool is_a, bool ok,
+                                               const float (&sc)[4], const float (&sh)[4]) {
+    // r[j] = row (mi*4 + j), cols ci*4 .. ci*4+3
+    bf16x4 x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x[j] = as_bf16x4(r[j]);
+        if (AMODE == A_BN_RELU && is_a) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[j][c] = f2bf(fmaxf(fmaf(bf2f(x[j][c]), sc[c], sh[c]), 0.f));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bf16x4 y = {x[0][c], x[1][c], x[2][c], x[3][c]};   // 4 consecutive m for column ci*4+c
+        if (!ok) y = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        const int col = ci * 4 + c;
+        const int chunk = mi >> 1;                      // 16-byte chunk along m (8 per 128-byte row)
+        // rows are 128 bytes (64 m); swizzle chunk with the same functions the fragment reads use
+        const int sw = is_a ? swz_act(col) : swz_wgt<4>(col);
+        *(uint2*)(dst + col * 128 + ((chunk ^ sw) << 4) + ((mi & 1) << 3)) = as_uint2(y);
+    }
+}
+
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+    constexpr int BN = 128, BKo = 128, TM = 64, TN = 64, MT = 4, NT = 4;
+    constexpr int STAGE = (BN + BKo) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_k = (p.K + BKo - 1) / BKo;
+    int b = blockIdx.x;
+    const int slab = b / (tiles_n * tiles_k);
+    b -= slab * tiles_n * tiles_k;
+    const int tile_n = b % tiles_n, tile_k = b / tiles_n;
+    const int n0 = tile_n * BN, k0 = tile_k * BKo;
+    const int m_begin = slab * p.rows_per_slab;
+    const int m_end = min(p.M, m_begin + p.rows_per_slab);
+
+    // staging: two 4x4 blocks per thread per operand per step: block id = tid + 256*i -> (mi, ci)
+    // wave covers 4 mi x 16 ci; lane: ci_lo = (l & 3) | ((l >> 4) << 2), mi_lo = (l >> 2) & 3
+    const int ci_lo = (lane & 3) | ((lane >> 4) << 2);      // 0..15
+    const int mi_lo = (lane >> 2) & 3;                       // 0..3
+    // 512 blocks per operand per step (16 mi x 32 ci): wave w, iteration i -> mi_hi = (w*2+i)>>1 ... lay out:
+    // block group id gidx = wave*2 + i in 0..7 -> mi_hi = gidx & 3 (x4 mi), ci_hi = gidx >> 2 (x16 ci)
+    int mi[2], ci[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gidx = wave * 2 + i;
+        mi[i] = (gidx & 3) * 4 + mi_lo;
+        ci[i] = (gidx >> 2) * 16 + ci_lo;
+    }
+    float asc[2][4], ash[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + ci[i] * 4 + c;
+            asc[i][c] = (AMODE == A_BN_RELU && k < p.K) ? p.a_scale[k] : 1.f;
+            ash[i][c] = (AMODE == A_BN_RELU && k < p.K) ? p.a_shift[k] : 0.f;
+        }
+    const bool g_col_ok[2] = {n0 + ci[0] * 4 < p.N, n0 + ci[1] * 4 < p.N};   // N, K multiples of 4
+    const bool a_col_ok[2] = {k0 + ci[0] * 4 < p.K, k0 + ci[1] * 4 < p.K};
+
+    uint2 rg[2][4], rav[2][4];
+    bool rok[2][4];
+    auto load_step = [&](int ms) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = ms + mi[i] * 4 + j;
+                const bool ok = m < m_end;
+                rok[i][j] = ok;
+                long arow = m;
+                if (p.gather && ok) {
+                    int w = m % p.Wo; int r = m / p.Wo;
+                    int h = r % p.Ho; r /= p.Ho;
+                    int t = r % p.To; int n = r / p.To;
+                    arow = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)h * p.ss) * p.Wi + (long)w * p.ss;
+                }
+                rg[i][j] = (ok && g_col_ok[i]) ? *(const uint2*)(p.G + (long)m * p.ldg + n0 + ci[i] * 4) : make_uint2(0, 0);
+                rav[i][j] = (ok && a_col_ok[i]) ? *(const uint2*)(p.A + arow * p.lda + k0 + ci[i] * 4) : make_uint2(0, 0);
+            }
+    };
+    auto store_step = [&](int buf) {
+        char* sg = smem + buf * STAGE;       // G^T tile: [n][m]  (MFMA A operand -> "weight" swizzle)
+        char* sa = sg + BN * 128;            // A^T tile: [k][m]  (MFMA B operand -> "act" swizzle)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // rows beyond m_end must contribute zero: zero both operands (prologue of zero != 0)
+            uint2 g4[4], a4[4];
+            bool any_bad = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g4[j] = rg[i][j]; a4[j] = rav[i][j]; any_bad |= !rok[i][j]; }
+            const float one[4] = {1.f, 1.f, 1.f, 1.f}, zero[4] = {0.f, 0.f, 0.f, 0.f};
+            tn_stage_store<A_PLAIN>(sg, g4, mi[i], ci[i], false, true, one, zero);
+            if (AMODE == A_BN_RELU && any_bad) {
+                // slow path at the slab tail: transform then zero the invalid rows individually
+                bf16x4 x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[j] = as_bf16x4(a4[j]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        x[j][c] = rok[i][j] ? f2bf(fmaxf(fmaf(bf2f(x[j][c]), asc[i][c], ash[i][c]), 0.f)) : (bf16)0.f;
+                    a4[j] = as_uint2(x[j]);
+                }
+                tn_stage_store<A_PLAIN>(sa, a4, mi[i], ci[i], true, true, one, zero);
+            } else {
+                tn_stage_store<AMODE>(sa, a4, mi[i], ci[i], true, true, asc[i], ash[i]);
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, li = lane & 15;
+    int a_row[MT], w_row[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_row[i] = wm * TM + i * 16 + li;                       // k index (A^T rows)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * 16 + j * 4 + (li & 3);  // n index (G^T rows)
+
+    int buf = 0;
+    if (m_begin < m_end) load_step(m_begin);
+    for (int ms = m_begin; ms < m_end; ms += 64) {
+        store_step(buf);
+        __syncthreads();
+        if (ms + 64 < m_end) load_step(ms + 64);
+        const char* sg = smem + buf * STAGE;
+        const char* sa = sg + BN * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int qq = ks * 4 + g;
+            bf16x8 xa[MT], wb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                xa[i] = as_bf16x8(*(const uint4*)(sa + a_row[i] * 128 + ((qq ^ swz_act(a_row[i])) << 4)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wb[j] = as_bf16x8(*(const uint4*)(sg + w_row[j] * 128 + ((qq ^ swz_wgt<4>(w_row[j])) << 4)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // D[i = n_local][j = k_local]: lane holds k = k0 + wm*64 + mt*16 + li, n = n0 + wn*64 + g*16 + (nt*4 + r)
+    float* P = p.P + (long)slab * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int k = k0 + wm * TM + i * 16 + li;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * TN + g * 16 + j * 4 + r;
+                if (n < p.N) P[(long)n * p.K + k] = acc[i][j][r];
+            }
+    }
+}
+
+// out[j] (+)= sum_s P[s][j]
+__global__ void reduce_slabs_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += P[(long)s * n + i];
+    out[i] = accumulate ? out[i] + a : a;
+}
+
+extern "C" {
+
+// slabs gemm_tn will use for (M, N, K): the caller sizes the partial buffer as [S][N][K] floats.
+int tuber_gemm_tn_slabs(int M, int N, int K) {
+    const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
+    int S = ceil_div(768, tiles);
+    const int maxS = ceil_div(M, 256);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S;
+}
+
+int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* partial, float* out, int accumulate,
+                  int M, int N, int K, int amode, const float* a_scale, const float* a_shift,
+                  int gather, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
+                  hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || (ldg & 3) || (lda & 3)) return TUBER_EINVAL;
+    GemmTN p;
+    p.G = (const bf16*)G; p.ldg = ldg; p.A = (const bf16*)A; p.lda = lda; p.P = partial;
+    p.M = M; p.N = N; p.K = K; p.S = tuber_gemm_tn_slabs(M, N, K);
+    int rps = ceil_div(M, p.S);
+    rps = ceil_div(rps, 64) * 64;
+    p.rows_per_slab = rps;
+    p.S = ceil_div(M, rps);
+    p.a_scale = a_scale; p.a_shift = a_shift;
+    p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
+    const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
+    dim3 grid(tiles * p.S), block(256);
+    const size_t lds = 2 * 256 * 128;
+    if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn_kernel<A_BN_RELU>, grid, block, lds, stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<A_PLAIN>, grid, block, lds, stream, p);
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""Regenerate include/tuber_hip.h from the extern "C" definitions in csrc/*.hip.
+
+The prototypes are extracted from the sources (so header and library cannot drift); the
+per-function documentation -- what reference op each entry point replaces (file:line under
+/root/reference) -- lives in DOC below.  Run:  python tubelet_transformer_amd/csrc/gen_header.py
+"""
+import glob
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+DOC = {
+    "tuber_gemm_nt": "C[M,N] = f(A)[M,K] . B[N,K]^T on MFMA bf16. Replaces every nn.Conv3d(k=1) of the CSN bottlenecks "
+                     "(models/backbones/ir_CSN_152.py:41,58,155-161), input_proj/class_proj (models/tuber_ava.py:57-58) and every "
+                     "nn.Linear / packed in-projection (models/transformer/transformer.py:159-165,227-245; transformer_layers.py:81-94; "
+                     "tuber_ava.py:65-71), plus their data gradients (B = W^T). amode 1 fuses relu(x*a_scale[k]+a_shift[k]) "
+                     "(BatchNorm apply, ir_CSN_152.py:72-79) into the A load; gather=1 reads A rows through the strided "
+                     "(n,t*st,h*ss,w*ss) map of the down_sample conv (:155-161). epi 0: +bias, +R, ReLU, bf16|fp32 out; "
+                     "epi 1: bf16 out + per-column partial (sum, sum^2) rows for training-mode BatchNorm; epi 2: out = acc*[Cm*m_scale+m_shift>0] "
+                     "+ partial (sum dz, sum dz*Cm) rows for BatchNorm backward. K % 64 == 0.",
+    "tuber_gemm_nt_stat_rows": "rows of partial statistics tuber_gemm_nt(epi 1|2) writes for (M,N).",
+    "tuber_gemm_tn": "dW[N,K] (+)= sum_m G[m,N]^T . f(A)[m,K]: weight gradient of the same convs / linears (autograd of the ops above); "
+                     "split over M into fp32 slabs `partial` [tuber_gemm_tn_slabs][N][K], then reduced deterministically.",
+    "tuber_gemm_tn_slabs": "number of slabs (size of `partial` / (N*K)) tuber_gemm_tn uses.",
+    "tuber_dwconv_fwd": "depthwise Conv3d(C,C,3,groups=C,stride=(st,ss,ss),padding=1) on NDHWC bf16, ResNeXtBottleneck.conv3 "
+                        "(ir_CSN_152.py:48-51) with relu(bn1(.)) fused on load (sc/sh may be NULL) and bn3 partial statistics on store.",
+    "tuber_dwconv_bwd_data": "input gradient of conv3 fused with the backward of relu(bn1(.)): dz = da*[x*sc+sh>0] + partial (sum dz, sum dz*x).",
+    "tuber_dwconv_bwd_weight": "weight gradient of conv3 ([C][27] fp32), activation relu(bn1(x)) recomputed on load.",
+    "tuber_dwconv_fwd_stat_rows": "partial-stat rows written by tuber_dwconv_fwd.",
+    "tuber_dwconv_bwd_data_stat_rows": "partial-stat rows written by tuber_dwconv_bwd_data.",
+    "tuber_dwconv_bwd_weight_blocks": "blocks (size of `partial` / (27*C)) used by tuber_dwconv_bwd_weight.",
+    "tuber_bn_finalize": "training-mode nn.BatchNorm3d(eps=1e-3, momentum=0.1) statistics (ir_CSN_152.py:15-16,46,56,64,119,154): partial rows -> "
+                         "mean/invstd, scale=gamma*invstd, shift=beta-mean*scale, running_mean/var (unbiased) and num_batches_tracked update.",
+    "tuber_bn_eval_affine": "eval-mode BatchNorm3d folded to scale/shift from the running statistics.",
+    "tuber_bn_bwd_finalize": "BatchNorm backward coefficients: dx = cA*dz + cB*x + cC, dgamma = sum dz*xhat, dbeta = sum dz.",
+    "tuber_bn_bwd_apply": "dx = cA*dz + cB*x + cC (BatchNorm backward apply), bf16 [M,C].",
+    "tuber_block_out_fwd": "bottleneck join y = relu(bn4(c4) + shortcut) (ir_CSN_152.py:81-90); shortcut = res or bn_ds(res) when rs/rh given.",
+    "tuber_block_out_bwd": "backward of the join: dz = dy*[y>0] and the partial statistics of bn4 (and of the down_sample BN).",
+    "tuber_relu_bn_bwd_reduce": "dz = g*[x*sc+sh>0] + partial (sum dz, sum dz*x): backward of relu(bn(x)) when not fused elsewhere.",
+    "tuber_rowblock_count": "partial-stat rows written by the row-blocked reduce kernels for M rows.",
+    "tuber_layernorm_fwd": "y = LayerNorm(x (+ res)) over E in {256, 2048}, eps 1e-5 (nn.LayerNorm, transformer.py:163-167,229-247,116-123; "
+                           "transformer_layers.py:84,91,96,437-445); saves xhat (bf16) and rstd for backward.",
+    "tuber_layernorm_bwd": "LayerNorm backward: dx (= gradient of both x and res) and dgamma/dbeta via block partials.",
+    "tuber_layernorm_bwd_blocks": "blocks used by tuber_layernorm_bwd (partial = 2*blocks*E floats).",
+    "tuber_reduce_rows": "out[c] (+)= sum_r P[r][c].",
+    "tuber_colsum": "bias gradient: out[c] (+)= sum_m g[m][c] for bf16 g.",
+    "tuber_stem_im2col": "patch matrix [N*T*Ho*Wo, 448] bf16 of the stem Conv3d(3,64,(3,7,7),s=(1,2,2),p=(1,3,3)) (ir_CSN_152.py:109-115) from the fp32 NCDHW clip.",
+    "tuber_stem_pool_fwd": "relu(bn1(.)) + MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1)) (ir_CSN_152.py:119-122) on NDHWC bf16, C=64; saves the argmax tap.",
+    "tuber_stem_pool_bwd": "backward of the pool + relu(bn1(.)): dz and the BN-backward partial statistics.",
+    "tuber_stem_pool_bwd_stat_rows": "partial-stat rows written by tuber_stem_pool_bwd.",
+    "tuber_attn_fwd": "softmax(scale*QK^T + key_padding_mask)[dropout] V for 32-wide heads, operands read in place through strided token maps "
+                      "{ld,sL,s1,s2,B2}: row(l,b) = l*sL + (b/B2)*s1 + (b%B2)*s2. Core of nn.MultiheadAttention "
+                      "(transformer.py:159,227,237; tuber_ava.py:138; transformer_layers.py:81,88) and of the hand-rolled MHA (:156-167,306-366).",
+    "tuber_attn_bwd": "gradients dQ, dK, dV of tuber_attn_fwd (P recomputed from the saved log-sum-exp).",
+    "tuber_cast_f32_bf16": "fp32 -> bf16 copy (bf16 shadow of the fp32 master weights).",
+    "tuber_cast_bf16_f32": "bf16 -> fp32 copy.",
+    "tuber_cast_transpose": "W[R][C] fp32 -> W^T[C][ldt] bf16 (B operand of the data-gradient GEMM).",
+    "tuber_rows_gather_sum": "out[(a,b,c)] = mul * sum_d in[a*sa+b*sb+c*sc+d*sd] over rows of E bf16: temporal AvgPool3d((4,1,1)) "
+                             "(backbone_builder.py:44,73), its backward (broadcast), the x6 replication of src_c (tuber_ava.py:133) and its backward (sum).",
+    "tuber_axpby": "out = alpha*a + beta*b (bf16): with_pos_embed adds (transformer.py:150-151), gradient accumulation.",
+    "tuber_dropout": "y = keep ? x/(1-p) : 0 with a stateless hash RNG keyed by (seed, index); applying it to a gradient with the same seed is the backward.",
+    "tuber_sigmoid_fwd": "boxes = sigmoid(bbox_embed(hs)) (tuber_ava.py:142).",
+    "tuber_sigmoid_bwd": "dx = dy*y*(1-y).",
+    "tuber_relu_mask": "dx = dy*[h>0] (ReLU backward from the saved activation; FFN and MLP hidden layers).",
+    "tuber_posenc": "PositionEmbeddingSine_3D (models/transformer/position_encoding.py:32-72) of a (B,T,H,W) padding mask, token-major bf16.",
+}
+
+HEADER = '''/* tuber_hip.h -- C ABI of libtuber_hip.so: the MI355X (gfx950) kernels behind the TubeR forward/backward path.
+ *
+ * GENERATED by tubelet_transformer_amd/csrc/gen_header.py from the extern "C" definitions in csrc/*.hip.
+ *
+ * The reference (amazon-science/tubelet-transformer) has no FFI or operator-plugin boundary: its hot path is stock
+ * torch.nn calls (SURVEY.md section 8b).  This ABI is therefore build-defined: one launcher per kernel family, each
+ * citing the reference call site(s) whose arithmetic it replaces.  Conventions:
+ *   - plain pointers to DEVICE memory + explicit sizes / leading dimensions (in elements); no torch types;
+ *   - activations are row-major [rows, channels] bf16 (NDHWC / token-major), master weights and statistics fp32;
+ *   - the callee never allocates: outputs, saved tensors and workspaces (`partial`, `st0`, ...) are caller-owned,
+ *     sized with the *_rows / *_slabs / *_blocks helper calls;
+ *   - every launcher enqueues on `stream` and returns 0, a negative argument-check code (TUBER_EINVAL = -1) or the
+ *     positive hipError_t of a failed launch; nothing throws across the ABI.
+ */
+#ifndef TUBER_HIP_H
+#define TUBER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+'''
+FOOTER = '''
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUBER_HIP_H */
+'''
+
+
+def prototypes():
+    out = []
+    for f in sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.cpp"))):
+        s = open(f).read()
+        for m in re.finditer(r'^(int|long) (tuber_\w+)\(([^)]*)\)\s*\{', s, re.M):
+            out.append((os.path.basename(f), m.group(1), m.group(2), " ".join(m.group(3).split())))
+    return out
+
+
+def wrap(text, width=116, indent=" * "):
+    words, lines, cur = text.split(), [], ""
+    for w in words:
+        if len(cur) + len(w) + 1 > width:
+            lines.append(cur)
+            cur = w
+        else:
+            cur = (cur + " " + w).strip()
+    lines.append(cur)
+    return "\n".join(indent + l for l in lines)
+
+
+def main():
+    parts = [HEADER]
+    last = None
+    for f, ret, name, args in prototypes():
+        if f != last:
+            parts.append("/* ---- %s ---- */\n" % f)
+            last = f
+        parts.append("/*\n%s\n */\n" % wrap(DOC.get(name, "(undocumented)")))
+        parts.append("%s %s(%s);\n\n" % (ret, name, args if args else "void"))
+    parts.append(FOOTER)
+    os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
+    open(os.path.join(ROOT, "include", "tuber_hip.h"), "w").write("".join(parts))
+    missing = [n for _, _, n, _ in prototypes() if n not in DOC]
+    if missing:
+        print("undocumented:", missing)
+
+
+if __name__ == "__main__":
+    main()

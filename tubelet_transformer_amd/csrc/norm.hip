@@ -1,0 +1,482 @@
+// BatchNorm3d (training + eval) split into the pieces that fuse into neighbouring kernels,
+// the bottleneck residual join, and LayerNorm -- gfx950, HBM-bound, 16-byte vector access.
+//
+// Training-mode BatchNorm (reference: nn.BatchNorm3d(eps=1e-3, momentum=0.1),
+// models/backbones/ir_CSN_152.py:15-16,46,56,64,119,154) is a two-phase scheme:
+//   producer conv epilogue  -> per-tile partial (sum, sum of squares) per channel
+//   bn_finalize             -> mean / var / running-stat update / scale = g*invstd, shift = b - mean*scale
+//   consumer prologue       -> relu(x*scale + shift)       (gemm.hip A_BN_RELU, dwconv.hip)
+// Backward mirrors it: partial (sum dz, sum dz*x) -> bn_bwd_finalize -> dx = A*dz + B*x + C.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// finalize kernels: one block per 32 channels, 1024 threads = 32 row-groups x 32 channels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+    float momentum, float eps,
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = rg; r < R; r += 32) { a += (double)st0[(long)r * C + c]; b += (double)st1[(long)r * C + c]; }
+    red[0][rg][cl] = a; red[1][rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < 32; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+        const double mean = a / (double)count;
+        double var = b / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (rmean) {
+            const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// dL/dx = A*dz + B*x + C per channel;  dgamma = sum dz*xhat, dbeta = sum dz
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+    const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = rg; r < R; r += 32) { a += (double)st0[(long)r * C + c]; b += (double)st1[(long)r * C + c]; }
+    red[0][rg][cl] = a; red[1][rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < 32; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+        const double mu = mean[c], r = invstd[c], g = gamma[c];
+        const double sum_dz = a, sum_dz_xhat = (b - mu * a) * r;
+        const double m1 = sum_dz / count, m2 = sum_dz_xhat / count;
+        cA[c] = (float)(g * r);
+        cB[c] = (float)(-g * r * r * m2);
+        cC[c] = (float)(g * r * r * m2 * mu - g * r * m1);
+        if (dgamma) {
+            dgamma[c] = accumulate ? dgamma[c] + (float)sum_dz_xhat : (float)sum_dz_xhat;
+            dbeta[c] = accumulate ? dbeta[c] + (float)sum_dz : (float)sum_dz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-major [M, C] elementwise kernels: thread = 8 channels (16 B); TPR = C/8 threads per row
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// y = relu( c4*s4+h4 + (rs ? res*rs+rh : res) )     [block output; ir_CSN_152.py:84-90]
+__global__ __launch_bounds__(256) void block_out_fwd_kernel(
+    const bf16* __restrict__ c4, const float* __restrict__ s4, const float* __restrict__ h4,
+    const bf16* __restrict__ res, const float* __restrict__ rs, const float* __restrict__ rh,
+    bf16* __restrict__ y, long M, int C) {
+    const int tpr = C >> 3;
+    const int cg = threadIdx.x % tpr;
+    const long rpp = 256 / tpr;
+    float a4[8], b4[8], ar[8], br[8];
+    load8f(s4 + cg * 8, a4); load8f(h4 + cg * 8, b4);
+    if (rs) { load8f(rs + cg * 8, ar); load8f(rh + cg * 8, br); }
+    for (long row = (long)blockIdx.x * rpp + threadIdx.x / tpr; row < M; row += (long)gridDim.x * rpp) {
+        const long off = row * C + cg * 8;
+        const bf16x8 c = as_bf16x8(*(const uint4*)(c4 + off));
+        const bf16x8 r = as_bf16x8(*(const uint4*)(res + off));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float rv = bf2f(r[e]);
+            if (rs) rv = fmaf(rv, ar[e], br[e]);
+            o[e] = f2bf(fmaxf(fmaf(bf2f(c[e]), a4[e], b4[e]) + rv, 0.f));
+        }
+        *(uint4*)(y + off) = as_uint4(o);
+    }
+}
+
+// dz = dy * [y > 0]  (bf16 out) ; partial stats per block: sum dz, sum dz*c4, (sum dz*cds)
+__global__ __launch_bounds__(256) void block_out_bwd_kernel(
+    const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ c4, const bf16* __restrict__ cds,
+    bf16* __restrict__ dz, float* __restrict__ st_dz, float* __restrict__ st_c4, float* __restrict__ st_ds,
+    long M, int C, long rows_per_block) {
+    __shared__ float red[3][256][8 + 1];
+    const int tpr = C >> 3;
+    const int cg = threadIdx.x % tpr, rs = threadIdx.x / tpr;
+    const int rpp = 256 / tpr;
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (long row = r0 + rs; row < r1; row += rpp) {
+        const long off = row * C + cg * 8;
+        const bf16x8 g = as_bf16x8(*(const uint4*)(dy + off));
+        const bf16x8 yy = as_bf16x8(*(const uint4*)(y + off));
+        const bf16x8 c = as_bf16x8(*(const uint4*)(c4 + off));
+        bf16x8 d = bf16x8{};
+        if (cds) d = as_bf16x8(*(const uint4*)(cds + off));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = bf2f(yy[e]) > 0.f ? bf2f(g[e]) : 0.f;
+            o[e] = f2bf(v);
+            s0[e] += v; s1[e] += v * bf2f(c[e]);
+            if (cds) s2[e] += v * bf2f(d[e]);
+        }
+        *(uint4*)(dz + off) = as_uint4(o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; red[2][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    // thread t < C reduces channel t over the rpp row slots
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int g8 = ch >> 3, e = ch & 7;
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int s = 0; s < rpp; ++s) { const int t = s * tpr + g8; a += red[0][t][e]; b += red[1][t][e]; c += red[2][t][e]; }
+        st_dz[(long)blockIdx.x * C + ch] = a;
+        st_c4[(long)blockIdx.x * C + ch] = b;
+        if (st_ds) st_ds[(long)blockIdx.x * C + ch] = c;
+    }
+}
+
+// generic "relu(bn(x))-masked gradient + stats":  dz = g * [x*sc+sh > 0]; partial sum dz, sum dz*x
+// (used for the stem BN; the bottleneck BNs get this fused into gemm / dwconv epilogues)
+__global__ __launch_bounds__(256) void relu_bn_bwd_reduce_kernel(
+    const bf16* __restrict__ g, const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+    bf16* __restrict__ dz, float* __restrict__ st0, float* __restrict__ st1, long M, int C, long rows_per_block) {
+    __shared__ float red[2][256][8 + 1];
+    const int tpr = C >> 3;
+    const int cg = threadIdx.x % tpr, rs = threadIdx.x / tpr;
+    const int rpp = 256 / tpr;
+    float a8[8], b8[8], s0[8], s1[8];
+    load8f(sc + cg * 8, a8); load8f(sh + cg * 8, b8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (long row = r0 + rs; row < r1; row += rpp) {
+        const long off = row * C + cg * 8;
+        const bf16x8 gg = as_bf16x8(*(const uint4*)(g + off));
+        const bf16x8 xx = as_bf16x8(*(const uint4*)(x + off));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = bf2f(xx[e]);
+            const float v = fmaf(xv, a8[e], b8[e]) > 0.f ? bf2f(gg[e]) : 0.f;
+            o[e] = f2bf(v);
+            s0[e] += v; s1[e] += v * xv;
+        }
+        *(uint4*)(dz + off) = as_uint4(o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int g8 = ch >> 3, e = ch & 7;
+        float a = 0.f, b = 0.f;
+        for (int s = 0; s < rpp; ++s) { const int t = s * tpr + g8; a += red[0][t][e]; b += red[1][t][e]; }
+        st0[(long)blockIdx.x * C + ch] = a;
+        st1[(long)blockIdx.x * C + ch] = b;
+    }
+}
+
+// dx = A*dz + B*x + C   (BatchNorm backward apply)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16* __restrict__ dz, const bf16* __restrict__ x, const float* __restrict__ cA, const float* __restrict__ cB,
+    const float* __restrict__ cC, bf16* __restrict__ dx, long M, int C) {
+    const int tpr = C >> 3;
+    const int cg = threadIdx.x % tpr;
+    const long rpp = 256 / tpr;
+    float a[8], b[8], c[8];
+    load8f(cA + cg * 8, a); load8f(cB + cg * 8, b); load8f(cC + cg * 8, c);
+    for (long row = (long)blockIdx.x * rpp + threadIdx.x / tpr; row < M; row += (long)gridDim.x * rpp) {
+        const long off = row * C + cg * 8;
+        const bf16x8 d = as_bf16x8(*(const uint4*)(dz + off));
+        const bf16x8 xx = as_bf16x8(*(const uint4*)(x + off));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(a[e], bf2f(d[e]), fmaf(b[e], bf2f(xx[e]), c[e])));
+        *(uint4*)(dx + off) = as_uint4(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(x + res) over the last dim E (256 or 2048), eps 1e-5, one wave per row.
+// reference: nn.LayerNorm in models/transformer/transformer.py:163-167,229-247 (post-norm).
+// ---------------------------------------------------------------------------------------------
+template <int EPL>   // elements per lane = E / 64 (4 for E=256, 32 for E=2048)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const bf16* __restrict__ x, const bf16* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16* __restrict__ y, bf16* __restrict__ xhat_out, float* __restrict__ rstd_out, int M, float eps) {
+    constexpr int E = EPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[EPL];
+    const long base = (long)row * E;
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const bf16x4 a = as_bf16x4(*(const uint2*)(x + base + col));
+        bf16x4 r = bf16x4{};
+        if (res) r = as_bf16x4(*(const uint2*)(res + base + col));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i * 4 + e] = bf2f(a[e]) + (res ? bf2f(r[e]) : 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.f / E);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / E) + eps);
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const float4 g = *(const float4*)(gamma + col), b = *(const float4*)(beta + col);
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+        bf16x4 o, xh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = (v[i * 4 + e] - mean) * rstd;
+            xh[e] = f2bf(h);
+            o[e] = f2bf(fmaf(h, gg[e], bb[e]));
+        }
+        *(uint2*)(y + base + col) = as_uint2(o);
+        if (xhat_out) *(uint2*)(xhat_out + base + col) = as_uint2(xh);
+    }
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); partial dgamma = sum dy*xhat, dbeta = sum dy
+// over the rows of each block (blocks write [gridDim.x][E] partials).
+template <int EPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const bf16* __restrict__ dy, const bf16* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    bf16* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb, int M, int rows_per_block) {
+    constexpr int E = EPL * 64;
+    __shared__ float red[2][4][E];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[EPL], ab[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    float gm[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const float4 g = *(const float4*)(gamma + (i * 64 + lane) * 4);
+        gm[i * 4] = g.x; gm[i * 4 + 1] = g.y; gm[i * 4 + 2] = g.z; gm[i * 4 + 3] = g.w;
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int row = r0 + w; row < r1; row += 4) {
+        const long base = (long)row * E;
+        float d[EPL], h[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            const bf16x4 a = as_bf16x4(*(const uint2*)(dy + base + col));
+            const bf16x4 b = as_bf16x4(*(const uint2*)(xhat + base + col));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[i * 4 + e] = bf2f(a[e]); h[i * 4 + e] = bf2f(b[e]); }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            ag[i] += d[i] * h[i]; ab[i] += d[i];
+            const float gd = d[i] * gm[i];
+            s1 += gd; s2 += gd * h[i];
+        }
+        s1 = wave_sum(s1) * (1.f / E);
+        s2 = wave_sum(s2) * (1.f / E);
+        const float rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(rs * (d[i * 4 + e] * gm[i * 4 + e] - s1 - h[i * 4 + e] * s2));
+            *(uint2*)(dx + base + col) = as_uint2(o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = (i * 64 + lane) * 4 + e;
+            red[0][w][col] = ag[i * 4 + e];
+            red[1][w][col] = ab[i * 4 + e];
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < E; col += 256) {
+        pg[(long)blockIdx.x * E + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+        pb[(long)blockIdx.x * E + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+    }
+}
+
+// out[c] (+)= sum_r P[r][c]   (column reduce of partial rows; also used for bias gradients)
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ P, float* __restrict__ out, int R, int C, int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float a = 0.f;
+    if (c < C) for (int r = rg; r < R; r += 32) a += P[(long)r * C + c];
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        a = 0.f;
+        for (int i = 0; i < 32; ++i) a += red[i][cl];
+        out[c] = accumulate ? out[c] + a : a;
+    }
+}
+
+// partial column sums of a bf16 [M, C] matrix (bias gradient): blocks write [gridDim.x][C]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ P, long M, int C, long rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (long r = r0; r < r1; ++r) a += bf2f(g[r * C + c]);
+        P[(long)blockIdx.x * C + c] = a;
+    }
+}
+
+static inline int ew_grid(long M, int C) {
+    const long rpp = 256 / (C >> 3);
+    long nb = (M + rpp - 1) / rpp;
+    if (nb > 4096) nb = 4096;
+    return (int)nb;
+}
+
+extern "C" {
+
+int tuber_bn_finalize(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                      float* scale, float* shift, float* mean, float* invstd, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                         float* scale, float* shift, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, gamma, beta, running_mean, running_var,
+                       eps, scale, shift, C);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_bn_bwd_finalize(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* mean,
+                          const float* invstd, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
+                          hipStream_t stream) {
+    if (R <= 0 || C <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, mean,
+                       invstd, cA, cB, cC, dgamma, dbeta, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+static inline bool chan_ok(int C) { return C >= 8 && C <= 2048 && (256 % (C >> 3)) == 0 && (C & 7) == 0; }
+
+int tuber_block_out_fwd(const void* c4, const float* s4, const float* h4, const void* res, const float* rs, const float* rh,
+                        void* y, long M, int C, hipStream_t stream) {
+    if (!chan_ok(C)) return TUBER_EINVAL;
+    hipLaunchKernelGGL(block_out_fwd_kernel, dim3(ew_grid(M, C)), dim3(256), 0, stream, (const bf16*)c4, s4, h4, (const bf16*)res,
+                       rs, rh, (bf16*)y, M, C);
+    TUBER_RETURN_LAUNCH();
+}
+
+// rows of partial stats written by the *_bwd / reduce kernels for M rows
+int tuber_rowblock_count(long M) { return ceil_div(M, 512) > 1024 ? 1024 : ceil_div(M, 512); }
+static inline long rows_per_block(long M) { const int nb = tuber_rowblock_count(M); return (M + nb - 1) / nb; }
+
+int tuber_block_out_bwd(const void* dy, const void* y, const void* c4, const void* cds, void* dz, float* st_dz, float* st_c4,
+                        float* st_ds, long M, int C, hipStream_t stream) {
+    if (!chan_ok(C)) return TUBER_EINVAL;
+    hipLaunchKernelGGL(block_out_bwd_kernel, dim3(tuber_rowblock_count(M)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y,
+                       (const bf16*)c4, (const bf16*)cds, (bf16*)dz, st_dz, st_c4, st_ds, M, C, rows_per_block(M));
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_relu_bn_bwd_reduce(const void* g, const void* x, const float* sc, const float* sh, void* dz, float* st0, float* st1,
+                             long M, int C, hipStream_t stream) {
+    if (!chan_ok(C)) return TUBER_EINVAL;
+    hipLaunchKernelGGL(relu_bn_bwd_reduce_kernel, dim3(tuber_rowblock_count(M)), dim3(256), 0, stream, (const bf16*)g,
+                       (const bf16*)x, sc, sh, (bf16*)dz, st0, st1, M, C, rows_per_block(M));
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_bn_bwd_apply(const void* dz, const void* x, const float* cA, const float* cB, const float* cC, void* dx, long M, int C,
+                       hipStream_t stream) {
+    if (!chan_ok(C)) return TUBER_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M, C)), dim3(256), 0, stream, (const bf16*)dz, (const bf16*)x, cA, cB, cC,
+                       (bf16*)dx, M, C);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* xhat, float* rstd,
+                        int M, int E, float eps, hipStream_t stream) {
+    dim3 grid(ceil_div(M, 4)), block(256);
+    if (E == 256) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, (bf16*)y, (bf16*)xhat, rstd, M, eps);
+    else if (E == 2048) hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, (bf16*)y, (bf16*)xhat, rstd, M, eps);
+    else return TUBER_EINVAL;
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_layernorm_bwd_blocks(int M) { const int nb = ceil_div(M, 64); return nb > 512 ? 512 : nb; }
+
+// partial must hold 2 * blocks * E floats; dgamma/dbeta are (accumulated into or) written
+int tuber_layernorm_bwd(const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, float* partial,
+                        float* dgamma, float* dbeta, int accumulate, int M, int E, hipStream_t stream) {
+    const int nb = tuber_layernorm_bwd_blocks(M);
+    int rpb = ceil_div(M, nb);
+    rpb = ceil_div(rpb, 4) * 4;
+    float* pg = partial;
+    float* pb = partial + (long)nb * E;
+    dim3 grid(nb), block(256);
+    if (E == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, (const bf16*)dy, (const bf16*)xhat, rstd, gamma, (bf16*)dx, pg, pb, M, rpb);
+    else if (E == 2048) hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, stream, (const bf16*)dy, (const bf16*)xhat, rstd, gamma, (bf16*)dx, pg, pb, M, rpb);
+    else return TUBER_EINVAL;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, pg, dgamma, nb, E, accumulate);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, pb, dbeta, nb, E, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_reduce_rows(const float* P, float* out, int R, int C, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, P, out, R, C, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+// dbias[c] (+)= sum_m g[m][c];  partial must hold tuber_rowblock_count(M) * C floats
+int tuber_colsum(const void* g, float* partial, float* out, int accumulate, long M, int C, hipStream_t stream) {
+    const int nb = tuber_rowblock_count(M);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)g, partial, M, C, rows_per_block(M));
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, partial, out, nb, C, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// CSN stem: Conv3d(3,64,k=(3,7,7),s=(1,2,2),p=(1,3,3)) -> BN -> ReLU -> MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1))
+// reference: models/backbones/ir_CSN_152.py:109-122,172-179.
+// Round-1 formulation: the 3->64 conv runs on the MFMA GEMM over an explicit bf16 patch matrix
+// [M, 448] (441 taps padded to a multiple of 64) built here from the fp32 NCDHW clip; its weight
+// gradient is the TN GEMM over the same matrix.  BN-apply + ReLU are fused into the max-pool read;
+// the pool backward fuses the ReLU mask and the BN-backward partial statistics.
+#include "common.h"
+
+#define STEM_K 441
+#define STEM_KP 448
+
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ clip, bf16* __restrict__ col, int N, int T,
+                                                          int H, int W, int Ho, int Wo, long total_chunks) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (STEM_KP / 8));
+        long m = i / (STEM_KP / 8);
+        const int wo = (int)(m % Wo); long r = m / Wo;
+        const int ho = (int)(r % Ho); r /= Ho;
+        const int t = (int)(r % T); const int n = (int)(r / T);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float f = 0.f;
+            if (k < STEM_K) {
+                const int kw = k % 7; int q = k / 7;
+                const int kh = q % 7; q /= 7;
+                const int kt = q % 3; const int c = q / 3;
+                const int ti = t + kt - 1, hi = ho * 2 + kh - 3, wi = wo * 2 + kw - 3;
+                if (ti >= 0 && ti < T && hi >= 0 && hi < H && wi >= 0 && wi < W)
+                    f = clip[((((long)n * 3 + c) * T + ti) * H + hi) * W + wi];
+            }
+            v[e] = f2bf(f);
+        }
+        *(uint4*)(col + m * STEM_KP + ch * 8) = as_uint4(v);
+    }
+}
+
+// out = max over the 3x3 window of relu(x*sc+sh); arg = window tap index (first maximum, like ATen)
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, bf16* __restrict__ out,
+                                                            uint8_t* __restrict__ arg, int NT, int Hs, int Ws, int Hp, int Wp) {
+    const int cg = threadIdx.x & 7;     // 8 channels each, C = 64
+    float a[8], b[8];
+    {
+        const float4 s0 = *(const float4*)(sc + cg * 8), s1 = *(const float4*)(sc + cg * 8 + 4);
+        const float4 h0 = *(const float4*)(sh + cg * 8), h1 = *(const float4*)(sh + cg * 8 + 4);
+        a[0] = s0.x; a[1] = s0.y; a[2] = s0.z; a[3] = s0.w; a[4] = s1.x; a[5] = s1.y; a[6] = s1.z; a[7] = s1.w;
+        b[0] = h0.x; b[1] = h0.y; b[2] = h0.z; b[3] = h0.w; b[4] = h1.x; b[5] = h1.y; b[6] = h1.z; b[7] = h1.w;
+    }
+    const long total = (long)NT * Hp * Wp;
+    for (long p = (long)blockIdx.x * 32 + (threadIdx.x >> 3); p < total; p += (long)gridDim.x * 32) {
+        const int wp = (int)(p % Wp); long r = p / Wp;
+        const int hp = (int)(r % Hp); const long nt = r / Hp;
+        float best[8]; int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = hp * 2 + dh - 1;
+            if (hi < 0 || hi >= Hs) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = wp * 2 + dw - 1;
+                if (wi < 0 || wi >= Ws) continue;
+                const bf16x8 v = as_bf16x8(*(const uint4*)(x + ((nt * Hs + hi) * Ws + wi) * 64 + cg * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = fmaxf(fmaf(bf2f(v[e]), a[e], b[e]), 0.f);
+                    if (f > best[e]) { best[e] = f; bi[e] = dh * 3 + dw; }
+                }
+            }
+        }
+        bf16x8 o;
+        uint32_t lo = 0, hi4 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = f2bf(best[e]);
+            if (e < 4) lo |= (uint32_t)bi[e] << (8 * e); else hi4 |= (uint32_t)bi[e] << (8 * (e - 4));
+        }
+        *(uint4*)(out + p * 64 + cg * 8) = as_uint4(o);
+        if (arg) *(uint2*)(arg + p * 64 + cg * 8) = make_uint2(lo, hi4);
+    }
+}
+
+// gradient back through pool + relu(bn): for every stem position gather the pooled gradients whose
+// argmax points at it, mask by relu, write dz and the BN-backward partial statistics.
+__global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restrict__ gpool, const uint8_t* __restrict__ arg,
+                                                            const bf16* __restrict__ x, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, bf16* __restrict__ dz,
+                                                            float* __restrict__ st0, float* __restrict__ st1, int NT, int Hs,
+                                                            int Ws, int Hp, int Wp, long rows_per_block) {
+    __shared__ float red[2][32][64];
+    const int cg = threadIdx.x & 7, rs = threadIdx.x >> 3;
+    float a[8], b[8], s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = sc[cg * 8 + e]; b[e] = sh[cg * 8 + e]; s0[e] = 0.f; s1[e] = 0.f; }
+    const long total = (long)NT * Hs * Ws;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(total, r0 + rows_per_block);
+    for (long p = r0 + rs; p < r1; p += 32) {
+        const int wi = (int)(p % Ws); long r = p / Ws;
+        const int hi = (int)(r % Hs); const long nt = r / Hs;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hn = hi + 1 - dh;
+            if (hn < 0 || (hn & 1)) continue;
+            const int hp = hn >> 1;
+            if (hp >= Hp) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wn = wi + 1 - dw;
+                if (wn < 0 || (wn & 1)) continue;
+                const int wp = wn >> 1;
+                if (wp >= Wp) continue;
+                const long q = ((nt * Hp + hp) * Wp + wp) * 64 + cg * 8;
+                const bf16x8 g = as_bf16x8(*(const uint4*)(gpool + q));
+                const uint2 ai = *(const uint2*)(arg + q);
+                const int tap = dh * 3 + dw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = (int)(((e < 4 ? ai.x : ai.y) >> (8 * (e & 3))) & 0xff);
+                    if (idx == tap) acc[e] += bf2f(g[e]);
+                }
+            }
+        }
+        const bf16x8 xv = as_bf16x8(*(const uint4*)(x + p * 64 + cg * 8));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = bf2f(xv[e]);
+            const float v = fmaf(xf, a[e], b[e]) > 0.f ? acc[e] : 0.f;
+            o[e] = f2bf(v);
+            s0[e] += v; s1[e] += v * xf;
+        }
+        *(uint4*)(dz + p * 64 + cg * 8) = as_uint4(o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][rs][cg * 8 + e] = s0[e]; red[1][rs][cg * 8 + e] = s1[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) { u += red[0][s][threadIdx.x]; v += red[1][s][threadIdx.x]; }
+        st0[(long)blockIdx.x * 64 + threadIdx.x] = u;
+        st1[(long)blockIdx.x * 64 + threadIdx.x] = v;
+    }
+}
+
+extern "C" {
+
+int tuber_stem_im2col(const float* clip, void* col, int N, int T, int H, int W, int Ho, int Wo, hipStream_t stream) {
+    const long chunks = (long)N * T * Ho * Wo * (STEM_KP / 8);
+    long nb = (chunks + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((int)nb), dim3(256), 0, stream, clip, (bf16*)col, N, T, H, W, Ho, Wo, chunks);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_stem_pool_fwd(const void* x, const float* sc, const float* sh, void* out, void* arg, int NT, int Hs, int Ws, int Hp, int Wp,
+                        hipStream_t stream) {
+    const long total = (long)NT * Hp * Wp;
+    long nb = (total + 31) / 32;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((int)nb), dim3(256), 0, stream, (const bf16*)x, sc, sh, (bf16*)out, (uint8_t*)arg,
+                       NT, Hs, Ws, Hp, Wp);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_stem_pool_bwd_stat_rows(long positions) { long nb = (positions + 1023) / 1024; return (int)(nb > 1024 ? 1024 : nb); }
+
+int tuber_stem_pool_bwd(const void* gpool, const void* arg, const void* x, const float* sc, const float* sh, void* dz, float* st0,
+                        float* st1, int NT, int Hs, int Ws, int Hp, int Wp, hipStream_t stream) {
+    const long total = (long)NT * Hs * Ws;
+    const int nb = tuber_stem_pool_bwd_stat_rows(total);
+    const long rpb = (total + nb - 1) / nb;
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)x,
+                       sc, sh, (bf16*)dz, st0, st1, NT, Hs, Ws, Hp, Wp, rpb);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // extern "C"
