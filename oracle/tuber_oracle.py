@@ -26,7 +26,8 @@ from scipy.optimize import linear_sum_assignment
 
 BN_EPS = 1e-3       # models/backbones/ir_CSN_152.py:15
 BN_MOMENTUM = 0.1   # models/backbones/ir_CSN_152.py:16
-CSN_BLOCKS = {"CSN-152": [3, 8, 36, 3], "CSN-50": [3, 4, 6, 3]}  # ir_CSN_152.py:204 / ir_CSN_50.py:204
+CSN_BLOCKS = {"CSN-152": [3, 8, 36, 3], "CSN-50": [3, 4, 6, 3],   # ir_CSN_152.py:204 / ir_CSN_50.py:204
+              "CSN-TEST": [2, 2, 2, 2]}   # shallow test-only body (same block code; keeps bf16 parity tests well-conditioned)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,333 @@
+"""ir-CSN-50/152 backbone on the HIP kernels (forward + hand-scheduled backward).
+
+API mirror of the reference: ``build_CSN`` / ``ResNeXt`` / ``ResNeXtBottleneck``
+(models/backbones/ir_CSN_152.py:33-210, ir_CSN_50.py) -- same module tree and state_dict keys
+(``conv1, bn1, layer{1-4}.{i}.{conv1,bn1,conv3,bn3,conv4,bn4,down_sample.{0,1}}``, CSN-50 ``out_fc``).
+The nn.Conv3d / nn.BatchNorm3d children are PARAMETER CONTAINERS only: arithmetic runs through
+libtuber_hip.so on NDHWC bf16 activations; there is no eager fallback.
+
+Forward schedule per bottleneck (ir_CSN_152.py:70-90), all BN statistics fused into the producers:
+    c1 = gemm_nt(x, W1)            [+stats]   -> bn_finalize(bn1)
+    c3 = dwconv(relu(bn1(c1)), w3) [+stats]   -> bn_finalize(bn3)
+    c4 = gemm_nt(relu(bn3(c3)), W4)[+stats]   -> bn_finalize(bn4)
+    cd = gemm_nt(gather(x), Wd)    [+stats]   -> bn_finalize(down_sample.1)      (first block of a stage)
+    y  = relu(bn4(c4) + (bn_d(cd) | x))
+"""
+import torch
+from torch import nn
+
+from . import lib
+
+BN_EPS = 1e-3       # ir_CSN_152.py:15
+BN_MOM = 0.1        # ir_CSN_152.py:16
+BF = torch.bfloat16
+CMAX = 2048
+
+
+class ResNeXtBottleneck(nn.Module):
+    """Parameter container with the reference's attribute names (ir_CSN_152.py:33-68)."""
+
+    def __init__(self, in_planes, planes, stride=1, temporal_stride=1, down_sample=None, expansion=2):
+        super().__init__()
+        self.expansion = expansion
+        self.conv1 = nn.Conv3d(in_planes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm3d(planes, eps=BN_EPS, momentum=BN_MOM)
+        self.conv3 = nn.Conv3d(planes, planes, kernel_size=3, bias=False, stride=(temporal_stride, stride, stride),
+                               padding=1, groups=planes)
+        self.bn3 = nn.BatchNorm3d(planes, eps=BN_EPS, momentum=BN_MOM)
+        self.conv4 = nn.Conv3d(planes, planes * expansion, kernel_size=1, bias=False)
+        self.bn4 = nn.BatchNorm3d(planes * expansion, eps=BN_EPS, momentum=BN_MOM)
+        self.relu = nn.ReLU(inplace=True)
+        self.down_sample = down_sample
+        self.stride = stride
+        self.temporal_stride = temporal_stride
+
+    def forward(self, x):
+        raise RuntimeError("ResNeXtBottleneck is executed by the fused HIP schedule of ResNeXt.forward")
+
+
+class ResNeXt(nn.Module):
+    """CSN body (ir_CSN_152.py:93-186).  ``forward`` takes an fp32 NCDHW clip batch on the GPU and returns
+    ``(features, None)`` where features is the NDHWC bf16 tensor [B, T/8, H/16, W/16, 2048]."""
+
+    def __init__(self, block_nums, num_classes=400, last_stride=True, with_out_fc=False):
+        super().__init__()
+        self.conv1 = nn.Conv3d(3, 64, kernel_size=(3, 7, 7), stride=(1, 2, 2), padding=(1, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(64, eps=BN_EPS, momentum=BN_MOM)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.layer1 = self._make_layer(64, 64, block_nums[0], 1, 1)
+        self.layer2 = self._make_layer(256, 128, block_nums[1], 2, 2)
+        self.layer3 = self._make_layer(512, 256, block_nums[2], 2, 2)
+        self.layer4 = self._make_layer(1024, 512, block_nums[3], 2 if last_stride else 1, 2)
+        self.avgpool = nn.AdaptiveAvgPool3d(output_size=(1, 1, 1))
+        if with_out_fc:  # CSN-50 only (ir_CSN_50.py:137-138); never used in forward
+            self.out_fc = nn.Linear(2048, num_classes)
+            self.sigmoid = nn.Sigmoid()
+        self._runner = None
+
+    @staticmethod
+    def _make_layer(in_planes, planes, blocks, stride, temporal_stride, expansion=4):
+        ds = nn.Sequential(
+            nn.Conv3d(in_planes, planes * expansion, kernel_size=1, stride=(temporal_stride, stride, stride), bias=False),
+            nn.BatchNorm3d(planes * expansion, eps=BN_EPS, momentum=BN_MOM))
+        layers = [ResNeXtBottleneck(in_planes, planes, stride, temporal_stride, ds, expansion)]
+        for _ in range(1, blocks):
+            layers.append(ResNeXtBottleneck(planes * expansion, planes, expansion=expansion))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        raise RuntimeError("ResNeXt runs through tubelet_transformer_amd.tuber.DETR (needs the model's ParamStore)")
+
+
+def build_CSN(cfg):
+    """models/backbones/ir_CSN_{50,152}.py:build_CSN: block counts [3,4,6,3] / [3,8,36,3]."""
+    name = cfg.CONFIG.MODEL.BACKBONE_NAME
+    if name == "CSN-152":
+        m = ResNeXt([3, 8, 36, 3], cfg.CONFIG.DATA.NUM_CLASSES, cfg.CONFIG.MODEL.LAST_STRIDE, with_out_fc=False)
+    elif name == "CSN-50":
+        m = ResNeXt([3, 4, 6, 3], cfg.CONFIG.DATA.NUM_CLASSES, cfg.CONFIG.MODEL.LAST_STRIDE, with_out_fc=True)
+    elif name == "CSN-TEST":   # shallow test-only body (2 blocks per stage) used by the well-conditioned bf16 parity tests
+        m = ResNeXt([2, 2, 2, 2], cfg.CONFIG.DATA.NUM_CLASSES, cfg.CONFIG.MODEL.LAST_STRIDE, with_out_fc=False)
+    else:
+        raise ValueError("unsupported BACKBONE_NAME %r (CSN-50 / CSN-152)" % name)
+    if cfg.CONFIG.MODEL.PRETRAINED:
+        from .checkpoint import load_csn_mat
+        load_csn_mat(m, cfg.CONFIG.MODEL.PRETRAIN_BACKBONE_DIR, name)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+# fused schedule
+# ------------------------------------------------------------------------------------------------
+class _BN:
+    """Raw device pointers of one BatchNorm layer (params in the flat store + per-layer scratch)."""
+    __slots__ = ("C", "gamma", "beta", "rmean", "rvar", "nbt", "dgamma", "dbeta", "scale", "shift", "mean", "invstd",
+                 "cA", "cB", "cC")
+
+
+class CSNRunner:
+    """Executes ResNeXt forward/backward for one ParamStore.  Pointers are cached as ints; every launch
+    goes through the C ABI on torch's current stream."""
+
+    def __init__(self, body: ResNeXt, prefix: str, store):
+        self.body, self.store = body, store
+        dev = store.device
+        self.dev = dev
+        bns = [m for m in body.modules() if isinstance(m, nn.BatchNorm3d)]
+        self.scratch = torch.zeros(len(bns), 7, CMAX, dtype=torch.float32, device=dev)
+        self._bn_index = {}
+        self.blocks = []
+        sp = self.scratch.data_ptr()
+
+        def mk_bn(mod_prefix, mod):
+            b = _BN()
+            i = len(self._bn_index)
+            self._bn_index[mod_prefix] = i
+            f, g = store.flat.data_ptr(), store.gflat.data_ptr()
+            ow, ob = store.offsets[mod_prefix + ".weight"], store.offsets[mod_prefix + ".bias"]
+            b.C = mod.num_features
+            b.gamma, b.beta = f + 4 * ow, f + 4 * ob
+            b.dgamma, b.dbeta = g + 4 * ow, g + 4 * ob
+            b.rmean, b.rvar, b.nbt = mod.running_mean.data_ptr(), mod.running_var.data_ptr(), mod.num_batches_tracked.data_ptr()
+            base = sp + 4 * i * 7 * CMAX
+            b.scale, b.shift, b.mean, b.invstd, b.cA, b.cB, b.cC = (base + 4 * k * CMAX for k in range(7))
+            return b
+
+        def wptr(name):
+            o = store.offsets[name]
+            return store.shadow.data_ptr() + 2 * o, store.flat.data_ptr() + 4 * o, store.gflat.data_ptr() + 4 * o
+
+        def tptr(name):
+            toff, N, K, ldt = store.tinfo[name]
+            return store.tshadow.data_ptr() + 2 * toff, ldt
+
+        self.stem_w32 = store.flat.data_ptr() + 4 * store.offsets[prefix + "conv1.weight"]
+        self.stem_g = store.gflat.data_ptr() + 4 * store.offsets[prefix + "conv1.weight"]
+        self.stem_wpad = torch.zeros(64, 448, dtype=BF, device=dev)
+        self.stem_bn = mk_bn(prefix + "bn1", body.bn1)
+        for li in range(1, 5):
+            layer = getattr(body, "layer%d" % li)
+            for bi, blk in enumerate(layer):
+                p = "%slayer%d.%d." % (prefix, li, bi)
+                d = {"cin": blk.conv1.in_channels, "p": blk.conv1.out_channels, "st": blk.temporal_stride, "ss": blk.stride,
+                     "ds": blk.down_sample is not None}
+                d["w1"], _, d["g1"] = wptr(p + "conv1.weight")
+                d["w1t"], d["ld1t"] = tptr(p + "conv1.weight")
+                _, d["w3"], d["g3"] = wptr(p + "conv3.weight")
+                d["w4"], _, d["g4"] = wptr(p + "conv4.weight")
+                d["w4t"], d["ld4t"] = tptr(p + "conv4.weight")
+                d["bn1"], d["bn3"], d["bn4"] = mk_bn(p + "bn1", blk.bn1), mk_bn(p + "bn3", blk.bn3), mk_bn(p + "bn4", blk.bn4)
+                if d["ds"]:
+                    d["wd"], _, d["gd"] = wptr(p + "down_sample.0.weight")
+                    d["wdt"], d["lddt"] = tptr(p + "down_sample.0.weight")
+                    d["bnd"] = mk_bn(p + "down_sample.1", blk.down_sample[1])
+                self.blocks.append(d)
+        self._ws = {}
+
+    # -- workspaces (serialised on the stream, so one of each kind suffices) ---------------------
+    def ws(self, key, numel, dtype=torch.float32):
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel:
+            t = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t.data_ptr()
+
+    def _bn_train(self, bn, st0, st1, R, count):
+        lib.call("tuber_bn_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, BN_MOM, BN_EPS,
+                 bn.scale, bn.shift, bn.mean, bn.invstd)
+
+    def _bn_eval(self, bn):
+        lib.call("tuber_bn_eval_affine", bn.gamma, bn.beta, bn.rmean, bn.rvar, BN_EPS, bn.scale, bn.shift, bn.C)
+
+    def _gemm_stats(self, A, lda, Wb, ldb, C, M, N, K, amode, sc, sh, gather, bn, train):
+        """conv as GEMM; in training mode also the following BatchNorm's statistics."""
+        g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
+        if train:
+            R = lib.query("tuber_gemm_nt_stat_rows", M, N)
+            st0, st1 = self.ws("st0", R * N), self.ws("st1", R * N)
+            lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 1, None, None, 0, 0, 0,
+                     st0, st1, None, 0, None, None)
+            self._bn_train(bn, st0, st1, R, M)
+        else:
+            lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 0, None, None, 0, 0, 0,
+                     None, None, None, 0, None, None)
+            self._bn_eval(bn)
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward(self, clips, train):
+        """clips fp32 [B,3,T,H,W] (contiguous, on device).  Returns (features [B,T',h,w,2048] bf16, saved)."""
+        B, _, T, H, W = clips.shape
+        dev = self.dev
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        M0 = B * T * Ho * Wo
+        lib.call("tuber_cast_pad_rows", self.stem_w32, self.stem_wpad, 64, 441, 448)
+        col = torch.empty(M0, 448, dtype=BF, device=dev)
+        lib.call("tuber_stem_im2col", clips, col, B, T, H, W, Ho, Wo)
+        c0 = torch.empty(M0, 64, dtype=BF, device=dev)
+        self._gemm_stats(col, 448, self.stem_wpad, 448, c0, M0, 64, 448, 0, None, None, None, self.stem_bn, train)
+        Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        x = torch.empty(B * T * Hp * Wp, 64, dtype=BF, device=dev)
+        arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
+        lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
+        saved = {"stem": (clips.shape, col if train else None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": []}
+        Ti, Hi, Wi = T, Hp, Wp
+        for d in self.blocks:
+            cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
+            To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
+            Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
+            c1 = torch.empty(Min, P, dtype=BF, device=dev)
+            self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
+            c3 = torch.empty(Mout, P, dtype=BF, device=dev)
+            b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
+            if train:
+                R = lib.query("tuber_dwconv_fwd_stat_rows", B, To, Hq, Wq)
+                st0, st1 = self.ws("st0", R * P), self.ws("st1", R * P)
+                lib.call("tuber_dwconv_fwd", c1, b1.scale, b1.shift, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+                self._bn_train(b3, st0, st1, R, Mout)
+            else:
+                lib.call("tuber_dwconv_fwd", c1, b1.scale, b1.shift, d["w3"], c3, None, None, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+                self._bn_eval(b3)
+            c4 = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
+            self._gemm_stats(c3, P, d["w4"], P, c4, Mout, 4 * P, P, 1, b3.scale, b3.shift, None, b4, train)
+            y = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
+            cd = None
+            if d["ds"]:
+                cd = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
+                strided = st != 1 or ss != 1
+                gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
+                self._gemm_stats(x, cin, d["wd"], cin, cd, Mout, 4 * P, cin, 0, None, None, gather, d["bnd"], train)
+                lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, cd, d["bnd"].scale, d["bnd"].shift, y, Mout, 4 * P)
+            else:
+                lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, x, None, None, y, Mout, 4 * P)
+            if train:
+                saved["blocks"].append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq)))
+            x = y
+            Ti, Hi, Wi = To, Hq, Wq
+        feat = x.view(B, Ti, Hi, Wi, 2048)
+        return feat, saved
+
+    # -- backward -------------------------------------------------------------------------------------
+    def _bn_bwd(self, bn, st0, st1, R, count, dz, x, M):
+        """finalize coefficients (+ dgamma/dbeta into the flat grads) and apply: returns dx tensor [M, C]."""
+        lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
+                 bn.dgamma, bn.dbeta, 1)
+        dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
+        lib.call("tuber_bn_bwd_apply", dz, x, bn.cA, bn.cB, bn.cC, dx, M, bn.C)
+        return dx
+
+    def _wgrad(self, G, ldg, A, lda, out, M, N, K, amode=0, sc=None, sh=None, gather=None):
+        S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+        part = self.ws("tn", S * N * K)
+        g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
+        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g)
+
+    def backward(self, saved, dfeat):
+        """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients are
+        accumulated into the ParamStore's flat gradient buffer."""
+        dev = self.dev
+        dy = dfeat
+        B = saved["stem"][4][0]
+        for d, sv in zip(reversed(self.blocks), reversed(saved["blocks"])):
+            x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
+            cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
+            C4 = 4 * P
+            Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
+            b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
+            # join backward: dz + stats of bn4 (and the shortcut BN)
+            R = lib.query("tuber_rowblock_count", Mout)
+            sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
+            dz = torch.empty(Mout, C4, dtype=BF, device=dev)
+            lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
+            dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout)
+            dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout) if d["ds"] else None
+            # conv4: weight grad (A = relu(bn3(c3)) recomputed on load) and data grad fused with relu/bn3 backward
+            self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
+            R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
+            s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
+            dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
+            lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift)
+            dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
+            # depthwise conv: weight grad, data grad fused with relu/bn1 backward
+            nb = lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
+            lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
+                     To, Hq, Wq, P, st, ss)
+            R1 = lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
+            s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
+            dz1 = torch.empty(Min, P, dtype=BF, device=dev)
+            lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+            dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min)
+            # conv1: weight grad and data grad (+ identity shortcut gradient as residual)
+            self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
+            dx = torch.empty(Min, cin, dtype=BF, device=dev)
+            strided = st != 1 or ss != 1
+            if not d["ds"]:
+                res = dz
+            elif not strided:
+                res = None  # filled below: stride-1 projection shortcut adds its dense data gradient
+            else:
+                res = None
+            if d["ds"]:
+                gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
+                self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
+                dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
+                lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
+                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None)
+                if not strided:
+                    res = dxd
+            lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     0, None, res, cin, 0, 0, None, None, None, 0, None, None)
+            if d["ds"] and strided:
+                lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
+            dy = dx
+        # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
+        _, col, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
+        M0 = B * T * Ho * Wo
+        R = lib.query("tuber_stem_pool_bwd_stat_rows", M0)
+        s0, s1 = self.ws("st0", R * 64), self.ws("st1", R * 64)
+        dz0 = torch.empty(M0, 64, dtype=BF, device=dev)
+        bn = self.stem_bn
+        lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
+        dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0)
+        self._wgrad(dc0, 64, col, 448, self.stem_g, M0, 64, 441)

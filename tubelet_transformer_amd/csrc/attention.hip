@@ -256,6 +256,106 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wide-head, single-query attention of the LSTR pooling decoder (TEMPORAL_DS_STRATEGY 'decode',
+// backbone_builder.py:74-78; transformer_layers.py:156-167,306-366): d_model 2048, 8 heads of 256,
+// ONE query per pixel attending over the T <= 8 temporal slots of that pixel.
+//   q  [NQ, 2048]               rows (b, hw)
+//   kv [rows, 4096] = [k | v]   row(pixel, t) = (b*T + t)*HW + hw   (T == 1: row = pixel, self-attention)
+// One 256-thread block per pixel: thread = (head, 8-dim slice); the 256-dim dot products are reduced
+// over the 32 lanes of a head with shuffles; softmax over T in registers.
+// ---------------------------------------------------------------------------------------------
+#define WT_MAX 8
+__device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes sharing a head
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+    return v;
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+    const bf16x8 t = as_bf16x8(*(const uint4*)p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+    *(uint4*)p = as_uint4(t);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv, bf16* __restrict__ o,
+                                                        const bf16* __restrict__ dO, bf16* __restrict__ dq, bf16* __restrict__ dkv,
+                                                        int HW, int T, float scale, float pdrop, uint32_t thresh, uint64_t seed) {
+    const int pix = blockIdx.x, head = threadIdx.x >> 5, d0 = threadIdx.x * 8;   // d0 = head*256 + lane32*8
+    const int b = pix / HW, hwi = pix % HW;
+    float qv[8];
+    load8(q + (long)pix * 2048 + d0, qv);
+    float s[WT_MAX], kk[WT_MAX][8], vv[WT_MAX][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < WT_MAX; ++t) {
+        if (t < T) {
+            const long row = T == 1 ? pix : ((long)b * T + t) * HW + hwi;
+            load8(kv + row * 4096 + d0, kk[t]);
+            load8(kv + row * 4096 + 2048 + d0, vv[t]);
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(qv[e], kk[t][e], a);
+            s[t] = half_wave_sum(a) * scale;
+            mx = fmaxf(mx, s[t]);
+        }
+    }
+    float l = 0.f, p[WT_MAX], keep[WT_MAX];
+    const float inv_keep = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+#pragma unroll
+    for (int t = 0; t < WT_MAX; ++t)
+        if (t < T) { p[t] = __expf(s[t] - mx); l += p[t]; }
+#pragma unroll
+    for (int t = 0; t < WT_MAX; ++t)
+        if (t < T) {
+            p[t] /= l;
+            keep[t] = 1.f;
+            if (pdrop > 0.f) keep[t] = dropout_keep(seed, ((uint64_t)pix * 8 + head) * WT_MAX + t, thresh) ? inv_keep : 0.f;
+        }
+    if (!BWD) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < WT_MAX; ++t)
+            if (t < T) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(p[t] * keep[t], vv[t][e], acc[e]);
+            }
+        store8(o + (long)pix * 2048 + d0, acc);
+    } else {
+        float g[8];
+        load8(dO + (long)pix * 2048 + d0, g);
+        float dp[WT_MAX], dsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < WT_MAX; ++t)
+            if (t < T) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fmaf(g[e], vv[t][e], a);
+                dp[t] = half_wave_sum(a) * keep[t];
+                dsum += p[t] * dp[t];
+            }
+        float dqv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < WT_MAX; ++t)
+            if (t < T) {
+                const float ds = p[t] * (dp[t] - dsum) * scale;
+                float dk[8], dv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dqv[e] = fmaf(ds, kk[t][e], dqv[e]); dk[e] = ds * qv[e]; dv[e] = p[t] * keep[t] * g[e]; }
+                const long row = T == 1 ? pix : ((long)b * T + t) * HW + hwi;
+                store8(dkv + row * 4096 + d0, dk);
+                store8(dkv + row * 4096 + 2048 + d0, dv);
+            }
+        store8(dq + (long)pix * 2048 + d0, dqv);
+    }
+}
+
 extern "C" {
 
 // maps: 5 longs each = {ld, sL, s1, s2, B2}
@@ -288,6 +388,21 @@ int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.dV = (bf16*)dV; a.mdv = mk_map(mdv); a.delta = delta;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(128), 0, stream, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(128), 0, stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_attn_wide_fwd(const void* q, const void* kv, void* o, int NQ, int HW, int T, float pdrop, unsigned long long seed,
+                        hipStream_t stream) {
+    if (T < 1 || T > WT_MAX || NQ <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
+    hipLaunchKernelGGL(attn_wide_kernel<false>, dim3(NQ), dim3(256), 0, stream, (const bf16*)q, (const bf16*)kv, (bf16*)o, nullptr,
+                       nullptr, nullptr, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (uint64_t)seed);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_attn_wide_bwd(const void* q, const void* kv, const void* dO, void* dq, void* dkv, int NQ, int HW, int T, float pdrop,
+                        unsigned long long seed, hipStream_t stream) {
+    if (T < 1 || T > WT_MAX || NQ <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
+    hipLaunchKernelGGL(attn_wide_kernel<true>, dim3(NQ), dim3(256), 0, stream, (const bf16*)q, (const bf16*)kv, nullptr, (const bf16*)dO,
+                       (bf16*)dq, (bf16*)dkv, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (uint64_t)seed);
     TUBER_RETURN_LAUNCH();
 }
 

@@ -127,6 +127,55 @@ __global__ void posenc_kernel(const uint8_t* __restrict__ mask, bf16* __restrict
     }
 }
 
+
+// batched W[R][C] fp32 -> W^T[C][ldt] bf16 over a device table of matrices (one launch for every
+// GEMM weight of the model).  table[i] = {src_off, dst_off, R, C, ldt, tile_begin, tiles_x}
+struct TrEntry { long src_off, dst_off; int R, C, ldt, tile_begin, tiles_x, pad; };
+__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                                   const TrEntry* __restrict__ table, int nmat) {
+    __shared__ float t[32][33];
+    int lo = 0, hi = nmat - 1;
+    const int tile = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile_begin <= tile) lo = mid; else hi = mid - 1; }
+    const TrEntry e = table[lo];
+    const int lt = tile - e.tile_begin;
+    const int c0 = (lt % e.tiles_x) * 32, r0 = (lt / e.tiles_x) * 32;
+    const float* W = src + e.src_off;
+    bf16* WT = dst + e.dst_off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) t[j][tx] = (r0 + j < e.R && c0 + tx < e.C) ? W[(long)(r0 + j) * e.C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < e.C && r0 + tx < e.R) WT[(long)(c0 + j) * e.ldt + r0 + tx] = f2bf(t[tx][j]);
+}
+
+// src[R][C] fp32 -> dst[R][ldd] bf16, columns C..ldd-1 zero filled
+__global__ void cast_pad_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C, int ldd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * ldd) return;
+    const int r = (int)(i / ldd), c = (int)(i % ldd);
+    dst[i] = c < C ? f2bf(src[(long)r * C + c]) : (bf16)0.f;
+}
+
+// dst[map(m)][:] += src[m][:] for the strided row map of a down_sample conv (rows unique: no atomics)
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(bf16* __restrict__ dst, const bf16* __restrict__ src, long Mo, int To,
+                                                               int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss, int E) {
+    const int epr = E >> 3;
+    const long total = Mo * epr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % epr); const long m = i / epr;
+        int w = (int)(m % Wo); long r = m / Wo;
+        int h = (int)(r % Ho); r /= Ho;
+        int t = (int)(r % To); const long n = r / To;
+        const long d = ((n * Ti + (long)t * st) * Hi + (long)h * ss) * Wi + (long)w * ss;
+        const bf16x8 a = as_bf16x8(*(const uint4*)(src + m * E + ch * 8));
+        bf16x8 b = as_bf16x8(*(const uint4*)(dst + d * E + ch * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = f2bf(bf2f(a[e]) + bf2f(b[e]));
+        *(uint4*)(dst + d * E + ch * 8) = as_uint4(b);
+    }
+}
+
 static inline int grid1(long n, int cap = 8192) { long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
 
 extern "C" {
@@ -177,6 +226,24 @@ int tuber_relu_mask(const void* dy, const void* h, void* dx, long n, hipStream_t
 int tuber_posenc(const void* mask, void* out, int B, int T, int H, int W, int hidden, hipStream_t stream) {
     if (hidden % 8) return TUBER_EINVAL;
     hipLaunchKernelGGL(posenc_kernel, dim3(B * T * H * W), dim3(64), 0, stream, (const uint8_t*)mask, (bf16*)out, B, T, H, W, hidden);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_multi_cast_transpose(const float* src, void* dst, const void* table, int nmat, int total_tiles, hipStream_t stream) {
+    if (nmat <= 0 || total_tiles <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(multi_cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, stream, src, (bf16*)dst, (const TrEntry*)table, nmat);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_cast_pad_rows(const float* src, void* dst, int R, int C, int ldd, hipStream_t stream) {
+    if (ldd < C) return TUBER_EINVAL;
+    hipLaunchKernelGGL(cast_pad_rows_kernel, dim3(ceil_div((long)R * ldd, 256)), dim3(256), 0, stream, src, (bf16*)dst, R, C, ldd);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_rows_scatter_add(void* dst, const void* src, long Mo, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss, int E,
+                           hipStream_t stream) {
+    if (E & 7) return TUBER_EINVAL;
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(grid1(Mo * (E / 8))), dim3(256), 0, stream, (bf16*)dst, (const bf16*)src, Mo, To, Ho,
+                       Wo, Ti, Hi, Wi, st, ss, E);
     TUBER_RETURN_LAUNCH();
 }
 

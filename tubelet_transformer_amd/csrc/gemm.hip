@@ -547,7 +547,8 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
                   int M, int N, int K, int amode, const float* a_scale, const float* a_shift,
                   int gather, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
                   hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || (ldg & 3) || (lda & 3)) return TUBER_EINVAL;
+    // N / K need not be multiples of 4, but G / A must be readable up to ceil4(N) / ceil4(K) columns (padded ld)
+    if (M <= 0 || N <= 0 || K <= 0 || (ldg & 3) || (lda & 3) || ldg < ((N + 3) & ~3) || lda < ((K + 3) & ~3)) return TUBER_EINVAL;
     GemmTN p;
     p.G = (const bf16*)G; p.ldg = ldg; p.A = (const bf16*)A; p.lda = lda; p.P = partial;
     p.M = M; p.N = N; p.K = K; p.S = tuber_gemm_tn_slabs(M, N, K);

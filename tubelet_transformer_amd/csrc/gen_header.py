@@ -54,6 +54,11 @@ DOC = {
                       "{ld,sL,s1,s2,B2}: row(l,b) = l*sL + (b/B2)*s1 + (b%B2)*s2. Core of nn.MultiheadAttention "
                       "(transformer.py:159,227,237; tuber_ava.py:138; transformer_layers.py:81,88) and of the hand-rolled MHA (:156-167,306-366).",
     "tuber_attn_bwd": "gradients dQ, dK, dV of tuber_attn_fwd (P recomputed from the saved log-sum-exp).",
+    "tuber_attn_wide_fwd": "single-query, 256-wide-head attention of the LSTR pooling decoder (TEMPORAL_DS_STRATEGY decode; "
+                           "backbone_builder.py:74-78, transformer_layers.py:156-167,306-366): q [NQ,2048], kv [rows,4096]=[k|v], T<=8 slots per pixel.",
+    "tuber_attn_wide_bwd": "gradients dq [NQ,2048] and dkv [rows,4096] of tuber_attn_wide_fwd.",
+    "tuber_lsap": "rectangular linear sum assignment on HOST doubles; restates scipy.optimize.linear_sum_assignment (call sites "
+                  "models/detr/matcher.py:80, matcher_ucf.py:82) incl. its tie-breaking.",
     "tuber_cast_f32_bf16": "fp32 -> bf16 copy (bf16 shadow of the fp32 master weights).",
     "tuber_cast_bf16_f32": "bf16 -> fp32 copy.",
     "tuber_cast_transpose": "W[R][C] fp32 -> W^T[C][ldt] bf16 (B operand of the data-gradient GEMM).",
@@ -64,6 +69,9 @@ DOC = {
     "tuber_sigmoid_fwd": "boxes = sigmoid(bbox_embed(hs)) (tuber_ava.py:142).",
     "tuber_sigmoid_bwd": "dx = dy*y*(1-y).",
     "tuber_relu_mask": "dx = dy*[h>0] (ReLU backward from the saved activation; FFN and MLP hidden layers).",
+    "tuber_multi_cast_transpose": "every GEMM weight W[R][C] fp32 -> W^T[C][ldt] bf16 in one launch over a device table {src_off,dst_off,R,C,ldt,tile_begin,tiles_x,pad}.",
+    "tuber_cast_pad_rows": "src[R][C] fp32 -> dst[R][ldd] bf16 with zero-filled pad columns (stem 441->448 taps, head gradients).",
+    "tuber_rows_scatter_add": "dst[map(m)] += src[m] over the strided (n,t*st,h*ss,w*ss) row map: input gradient of a strided down_sample conv (ir_CSN_152.py:155-161).",
     "tuber_posenc": "PositionEmbeddingSine_3D (models/transformer/position_encoding.py:32-72) of a (B,T,H,W) padding mask, token-major bf16.",
 }
 

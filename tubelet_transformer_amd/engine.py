@@ -1,0 +1,128 @@
+"""Device-side parameter store of the TubeR MI355X path.
+
+Layout in HBM (per model, per GPU):
+  * ``flat``   fp32 master parameters, one contiguous buffer; every ``nn.Parameter`` of the model is a
+               view into it, so ``state_dict()`` keeps the reference's names/shapes;
+  * ``gflat``  fp32 gradients, same offsets; ``p.grad`` are views.  The backward kernels accumulate
+               straight into these slices, the optimizer / gradient all-reduce work on the flat buffer;
+  * ``shadow`` bf16 copy of ``flat`` (one cast launch per step) -- the B operands of the forward GEMMs;
+  * ``tshadow`` bf16 TRANSPOSED copies of every GEMM weight (one batched launch per step) -- the B
+               operands of the data-gradient GEMMs; leading dimension padded to a multiple of 64.
+Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
+"""
+import numpy as np
+import torch
+
+from . import lib
+
+ALIGN = 64
+
+
+def _ceil(x, m):
+    return (x + m - 1) // m * m
+
+
+class ParamStore:
+    def __init__(self, module, device):
+        self.module = module
+        self.device = torch.device(device)
+        names, params = [], []
+        seen = set()
+        for n, p in module.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            names.append(n)
+            params.append(p)
+        self.names, self.params = names, params
+        self.offsets = {}
+        off = 0
+        for n, p in zip(names, params):
+            self.offsets[n] = off
+            off += _ceil(p.numel(), ALIGN)
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.gflat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        with torch.no_grad():
+            for n, p in zip(names, params):
+                o = self.offsets[n]
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.gflat[o:o + p.numel()].view(p.shape)
+        self._ptrs = [p.data_ptr() for p in params]
+        # transposed GEMM weights: 2-D view [N, K] of 1x1x1 convs, linears and packed in-projections
+        self.tinfo = {}
+        toff, entries, tiles = 0, [], 0
+        for n, p in zip(names, params):
+            if p.dim() >= 2 and self._is_gemm_weight(n, p):
+                N = p.shape[0]
+                K = p.numel() // N
+                ldt = _ceil(N, 64)
+                self.tinfo[n] = (toff, N, K, ldt)
+                tx, ty = (K + 31) // 32, (N + 31) // 32
+                entries.append((self.offsets[n], toff, N, K, ldt, tiles, tx, 0))
+                tiles += tx * ty
+                toff += _ceil(K * ldt, ALIGN)
+        self.tshadow = torch.zeros(max(toff, ALIGN), dtype=torch.bfloat16, device=self.device)
+        self.ttiles = tiles
+        tab = np.zeros(len(entries), dtype=[("src", "<i8"), ("dst", "<i8"), ("R", "<i4"), ("C", "<i4"), ("ldt", "<i4"),
+                                             ("tb", "<i4"), ("tx", "<i4"), ("pad", "<i4")])
+        for i, e in enumerate(entries):
+            tab[i] = e
+        self.ttable = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+        self.nmat = len(entries)
+        self.step_seed = 0
+
+    @staticmethod
+    def _is_gemm_weight(name, p):
+        if name.endswith("conv3.weight") or name.endswith("query_embed.weight") or name.endswith("query_pool.weight"):
+            return False
+        if name == "backbone.body.conv1.weight":
+            return False
+        return name.endswith("weight")
+
+    # -- consistency -------------------------------------------------------------------------
+    def valid(self):
+        """False if someone re-allocated the parameters (``model.to()``, ``.half()`` ...)."""
+        return all(p.data_ptr() == q for p, q in zip(self.params, self._ptrs))
+
+    def ensure_grad_views(self):
+        for n, p in zip(self.names, self.params):
+            o = self.offsets[n]
+            want = self.gflat[o:o + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != want.data_ptr():
+                if p.grad is not None:
+                    want.copy_(p.grad)
+                p.grad = want
+
+    def zero_grad(self):
+        self.gflat.zero_()
+        self.ensure_grad_views()
+
+    # -- per-step refresh --------------------------------------------------------------------
+    def refresh(self):
+        lib.call("tuber_cast_f32_bf16", self.flat, self.shadow, self.total)
+        if self.nmat:
+            lib.call("tuber_multi_cast_transpose", self.flat, self.tshadow, self.ttable, self.nmat, self.ttiles)
+
+    # -- accessors ---------------------------------------------------------------------------
+    def w(self, name):
+        """fp32 master view (flat 1-D)."""
+        o = self.offsets[name]
+        return self.flat[o:]
+
+    def g(self, name):
+        o = self.offsets[name]
+        return self.gflat[o:]
+
+    def wb(self, name):
+        """bf16 shadow (flat 1-D view starting at the parameter)."""
+        o = self.offsets[name]
+        return self.shadow[o:]
+
+    def wt(self, name):
+        """(bf16 transposed weight flat view, ldt)."""
+        toff, N, K, ldt = self.tinfo[name]
+        return self.tshadow[toff:], ldt

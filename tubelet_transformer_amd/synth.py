@@ -112,3 +112,13 @@ def synthetic_targets(batch, dataset="ava", num_classes=80, seed=4321, device="c
             t["key_pos"] = torch.tensor(16, dtype=torch.int64, device=device)
         out.append(t)
     return out
+
+
+def zero_dropout(model):
+    """Deterministic train mode for parity runs: nn.Dropout.p and nn.MultiheadAttention.dropout -> 0."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(getattr(m, "dropout", None), float):
+            m.dropout = 0.0
+    return model

@@ -1,0 +1,399 @@
+"""TubeR model API on the MI355X HIP path.
+
+Mirrors ``models/tuber_ava.py`` (``DETR`` :22-157, ``build_model`` :160-221), ``models/backbone_builder.py``
+(``Backbone`` :26-90), ``models/transformer/transformer.py`` and ``transformer_layers.py``: same module tree,
+attribute names and ``state_dict`` keys, so released checkpoints load and ``train_tuber_*.py`` / ``eval_tuber_*.py``
+style drivers work unchanged.  The torch.nn children hold parameters only; ``DETR.forward`` runs the whole
+network through libtuber_hip.so (NDHWC / token-major bf16 activations, fp32 master weights) and raises if the
+library or a GPU is missing -- there is no eager fallback.
+
+Row orders used internally (all row-wise ops are order-agnostic; attention gets explicit strides):
+    backbone features   (b, t, hw)      encoder memory   (b, hw)        decoder / hs   (layer, b, query)
+    class branch        (layer*B + b, t, hw)   -- the reference's permute/contiguous copies
+    (tuber_ava.py:133-139, transformer_layers.py:77-91) are never materialised.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import lib, ops
+from .backbone import build_CSN, CSNRunner
+from .engine import ParamStore
+from .misc import NestedTensor, nested_tensor_from_tensor_list
+
+BF = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's names
+# ------------------------------------------------------------------------------------------------
+def _clones(m, n):
+    return nn.ModuleList([copy.deepcopy(m) for _ in range(n)])
+
+
+class TransformerEncoderLayer(nn.Module):      # transformer.py:131-189
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+
+class TransformerDecoderLayer(nn.Module):      # transformer.py:192-285
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+
+
+class _Stack(nn.Module):
+    def __init__(self, layer, n, norm=None):
+        super().__init__()
+        self.layers = _clones(layer, n)
+        self.num_layers = n
+        self.norm = norm
+
+
+class Transformer(nn.Module):                  # transformer.py:15-64
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, normalize_before=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("NORMALIZE_BEFORE: True is broken in the reference (transformer.py:81,170-182); "
+                                      "only the post-norm path is implemented")
+        self.encoder = _Stack(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout), num_encoder_layers)
+        self.decoder = _Stack(TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout), num_decoder_layers,
+                              nn.LayerNorm(d_model))
+        for p in self.parameters():            # transformer.py:44-47
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model, self.nhead = d_model, nhead
+
+
+def build_transformer(cfg):                    # transformer.py:302-314
+    M = cfg.CONFIG.MODEL
+    return Transformer(M.D_MODEL, M.NHEAD, M.ENC_LAYERS, M.DEC_LAYERS, M.DIM_FEEDFORWARD, M.DROPOUT, M.NORMALIZE_BEFORE)
+
+
+class ClassEncoderLayer(nn.Module):            # transformer_layers.py:46-69 (factorised t/s layer)
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn_t = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.self_attn_s = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model * 2, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1_t = nn.LayerNorm(d_model)
+        self.norm1_s = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+
+class LSTRDecoderLayer(nn.Module):             # transformer_layers.py:403-448 (d=2048 pool decoder)
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+
+
+class MLP(nn.Module):                          # criterion.py:485-497
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+
+class Backbone(nn.Module):                     # backbone_builder.py:26-57
+    def __init__(self, train_backbone, num_channels, cfg):
+        super().__init__()
+        self.body = build_CSN(cfg)
+        if not train_backbone:
+            for p in self.body.parameters():
+                p.requires_grad_(False)
+        M = cfg.CONFIG.MODEL
+        self.ds = M.SINGLE_FRAME
+        self.pool_len = M.TEMP_LEN // M.DS_RATE
+        if M.SINGLE_FRAME and M.TEMPORAL_DS_STRATEGY == "decode":
+            self.query_pool = nn.Embedding(1, 2048)
+            self.pool_decoder = _Stack(LSTRDecoderLayer(2048, 8, 2048, 0.1), 1, nn.LayerNorm(2048))
+        self.num_channels = num_channels
+        self.backbone_name = M.BACKBONE_NAME
+        self.temporal_ds_strategy = M.TEMPORAL_DS_STRATEGY
+
+
+def build_backbone(cfg):                       # backbone_builder.py:109-113
+    return Backbone(cfg.CONFIG.TRAIN.LR_BACKBONE > 0, cfg.CONFIG.MODEL.DIM_FEEDFORWARD, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+class DETR(nn.Module):
+    """TubeR detector (tuber_ava.py:22-157).  ``forward(samples)`` -> dict with ``pred_logits`` [B,Q,C],
+    ``pred_boxes`` [B,Q,4] (cxcywh in (0,1)), ``pred_logits_b`` and ``aux_outputs`` -- fp32 tensors on the GPU."""
+
+    def __init__(self, backbone, transformer, num_classes, num_queries, hidden_dim, temporal_length, aux_loss=False,
+                 generate_lfb=False, backbone_name="CSN-152", ds_rate=1, last_stride=True, dataset_mode="ava"):
+        super().__init__()
+        self.temporal_length = temporal_length
+        self.num_queries = num_queries
+        self.transformer = transformer
+        self.avg = nn.AvgPool3d(kernel_size=(temporal_length, 1, 1))
+        self.dataset_mode = dataset_mode
+        if dataset_mode != "ava":
+            self.avg_s = nn.AdaptiveAvgPool3d((1, 1, 1))
+            self.query_embed = nn.Embedding(num_queries * temporal_length, hidden_dim)
+        else:
+            self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.input_proj = nn.Conv3d(backbone.num_channels, hidden_dim, kernel_size=1)
+        self.class_proj = nn.Conv3d(backbone.num_channels, hidden_dim, kernel_size=1)
+        self.encoder = _Stack(ClassEncoderLayer(hidden_dim, 8, 2048, 0.1), 1)
+        self.cross_attn = nn.MultiheadAttention(256, num_heads=8, dropout=0.1)
+        self.class_embed_b = nn.Linear(hidden_dim, 3) if dataset_mode == "ava" else nn.Linear(2048, 2)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.class_fc = nn.Linear(hidden_dim, num_classes if dataset_mode == "ava" else num_classes + 1)
+        self.dropout = nn.Dropout(0.5)
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.hidden_dim = hidden_dim
+        self.generate_lfb = generate_lfb
+        self.last_stride = last_stride
+        self._store = None
+        self._runner = None
+        self._anchor = None
+
+    # -- engine ----------------------------------------------------------------------------------
+    def engine(self):
+        """(ParamStore, CSNRunner) for the device the parameters live on; (re)built when parameters moved."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("TubeR MI355X path: parameters are on %s; move the model to a ROCm GPU (model.cuda()). "
+                               "There is no CPU fallback." % dev)
+        if self._store is None or not self._store.valid() or self._store.device != dev:
+            lib.load()
+            self._store = ParamStore(self, dev)
+            self._runner = CSNRunner(self.backbone.body, "backbone.body.", self._store)
+            self._anchor = torch.zeros((), device=dev, requires_grad=True)
+            self._store.anchor = self._anchor
+        return self._store, self._runner
+
+    def freeze_params(self):                   # tuber_ava.py:83-95
+        for mod in (self.backbone, self.transformer, self.query_embed, self.bbox_embed, self.input_proj, self.class_embed_b):
+            for p in mod.parameters():
+                p.requires_grad = False
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def _mha_self(self, st, x, qk_in, prefix, B, L, kpm, p, train):  # p = attention-weight dropout
+        """self-attention with q = k = qk_in, v = x (rows (b, l)); returns out_proj(attn)."""
+        E = self.hidden_dim
+        qk = ops.linear(qk_in, st, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(0, 2 * E))
+        v = ops.linear(x, st, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(2 * E, 3 * E))
+        geom = (B, 8, L, L, (1, L, 0, 1), (1, L, 0, 1))
+        st.step_seed += 1
+        a = ops.attention(st, ((0, 0), (0, E), (1, 0)), geom, kpm, p if train else 0.0, st.step_seed, qk, v)
+        return ops.linear(a, st, prefix + ".out_proj.weight", prefix + ".out_proj.bias")
+
+    def _ffn(self, st, x, prefix, p, train):
+        h = ops.linear(x, st, prefix + ".linear1.weight", prefix + ".linear1.bias", relu=True)
+        h = ops.dropout(h, p, train, st)
+        h = ops.linear(h, st, prefix + ".linear2.weight", prefix + ".linear2.bias")
+        return ops.dropout(h, p, train, st)
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward(self, samples):
+        if not isinstance(samples, NestedTensor):
+            samples = nested_tensor_from_tensor_list(samples)
+        st, runner = self.engine()
+        dev = st.device
+        train = self.training
+        clips = samples.tensors.to(dev, torch.float32).contiguous()
+        mask = samples.mask.to(dev)
+        st.refresh()
+        anchor = self._anchor
+        E, H = self.hidden_dim, 8
+        enc0 = self.transformer.encoder.layers[0]
+        pdrop, pattn = enc0.dropout.p, enc0.self_attn.dropout
+
+        # ---- backbone (Backbone.forward, backbone_builder.py:59-90) ----
+        feat = ops.BackboneFn.apply(clips, anchor, runner, train)          # [B*T'*hw, 2048] rows (b,t,hw)
+        B, Tp, h, w, C = runner.last_shape
+        hw = h * w
+        strat = self.backbone.temporal_ds_strategy
+        if not self.backbone.ds:
+            raise NotImplementedError("SINGLE_FRAME: False is not used by any published config")
+        if strat == "avg":
+            if Tp != self.backbone.pool_len:
+                raise ValueError("TEMPORAL_DS_STRATEGY 'avg' needs T/8 == TEMP_LEN/DS_RATE (got %d vs %d)" % (Tp, self.backbone.pool_len))
+            xs = ops.gather_sum(feat, (B, 1, hw, Tp, Tp * hw, 0, 1, hw, 1.0 / Tp), (B, Tp, hw, 1, hw, 0, 1, 0, 1.0 / Tp))
+        elif strat == "decode":
+            xs = self._lstr_pool(st, feat, B, Tp, hw, train)
+        elif strat == "max":
+            raise NotImplementedError("TEMPORAL_DS_STRATEGY 'max' is not used by any published config")
+        else:                                   # mid-frame slice (backbone_builder.py:79-80)
+            xs = feat.view(B, Tp, hw, C)[:, Tp // 2].reshape(B * hw, C)
+        m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]          # [B,h,w] (backbone_builder.py:85)
+        kpm = m.reshape(B, hw).to(torch.uint8).contiguous()
+        pos = torch.empty(B * hw, E, dtype=BF, device=dev)
+        lib.call("tuber_posenc", kpm, pos, B, 1, h, w, E)
+
+        # ---- DETR encoder / decoder (transformer.py:49-64) ----
+        src = ops.linear(xs, st, "input_proj.weight", "input_proj.bias")           # rows (b, hw)
+        for i in range(self.transformer.encoder.num_layers):
+            L = "transformer.encoder.layers.%d" % i
+            a = self._mha_self(st, src, ops.add(src, pos), L + ".self_attn", B, hw, kpm, pattn, train)
+            src = ops.layer_norm(ops.dropout(a, pdrop, train, st), src, st, L + ".norm1")
+            src = ops.layer_norm(self._ffn(st, src, L, pdrop, train), src, st, L + ".norm2")
+        memory = src
+        mem_pos = ops.add(memory, pos)
+        Q = self.query_embed.num_embeddings
+        qpos = ops.param_rows(st, "query_embed.weight", B, anchor)                 # rows (b, q)
+        tgt = torch.zeros(B * Q, E, dtype=BF, device=dev)
+        hs_list = []
+        for i in range(self.transformer.decoder.num_layers):
+            L = "transformer.decoder.layers.%d" % i
+            a = self._mha_self(st, tgt, ops.add(tgt, qpos), L + ".self_attn", B, Q, None, pattn, train)
+            tgt = ops.layer_norm(ops.dropout(a, pdrop, train, st), tgt, st, L + ".norm1")
+            P = L + ".multihead_attn"
+            q = ops.linear(ops.add(tgt, qpos), st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(0, E))
+            k = ops.linear(mem_pos, st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(E, 2 * E))
+            v = ops.linear(memory, st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(2 * E, 3 * E))
+            st.step_seed += 1
+            a = ops.attention(st, ((0, 0), (1, 0), (2, 0)), (B, H, Q, hw, (1, Q, 0, 1), (1, hw, 0, 1)), kpm,
+                              pattn if train else 0.0, st.step_seed, q, k, v)
+            a = ops.linear(a, st, P + ".out_proj.weight", P + ".out_proj.bias")
+            tgt = ops.layer_norm(ops.dropout(a, pdrop, train, st), tgt, st, L + ".norm2")
+            tgt = ops.layer_norm(self._ffn(st, tgt, L, pdrop, train), tgt, st, L + ".norm3")
+            hs_list.append(ops.layer_norm(tgt, None, st, "transformer.decoder.norm"))
+        lay_n = len(hs_list)
+        hs = torch.cat(hs_list, dim=0)                                              # rows (layer, b, q)
+
+        # ---- heads (tuber_ava.py:121-125,142) ----
+        if self.dataset_mode == "ava":
+            logits_b = ops.linear(hs, st, "class_embed_b.weight", "class_embed_b.bias", out_f32=True).view(lay_n, B, Q, 3)
+        else:
+            pooled = ops.gather_sum(feat, (B, 1, 1, Tp * hw, Tp * hw, 0, 0, 1, 1.0 / (Tp * hw)),
+                                    (B, 1, Tp * hw, 1, 1, 0, 0, 0, 1.0 / (Tp * hw)))
+            lb = ops.linear(pooled, st, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
+            logits_b = lb.unsqueeze(0).repeat(6, 1, 1)
+        x = ops.linear(hs, st, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
+        x = ops.linear(x, st, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
+        boxes = ops.sigmoid(ops.linear(x, st, "bbox_embed.layers.2.weight", "bbox_embed.layers.2.bias", out_f32=True))
+        boxes = boxes.view(lay_n, B, Q, 4)
+
+        # ---- class branch (tuber_ava.py:127-141; transformer_layers.py:71-97) ----
+        src_c = ops.linear(feat, st, "class_proj.weight", "class_proj.bias")       # rows (b, t, hw)
+        R0 = B * Tp * hw
+        rep = ops.gather_sum(src_c, (lay_n, 1, R0, 1, 0, 0, 1, 0, 1.0), (1, 1, R0, lay_n, 0, 0, 1, R0, 1.0))  # rows (l,b,t,hw)
+        LB = lay_n * B
+        cl = self.encoder.layers[0]
+        pa_c, p1_c, pf_c = cl.self_attn_t.dropout, cl.dropout1.p, cl.dropout.p
+        P = "encoder.layers.0"
+        qkv = ops.linear(rep, st, P + ".self_attn_t.in_proj_weight", P + ".self_attn_t.in_proj_bias")
+        st.step_seed += 1
+        mp = (1, hw, 0, 1)                       # sequence over hw, batch (lb, t)
+        a = ops.attention(st, ((0, 0), (0, E), (0, 2 * E)), (LB * Tp, H, hw, hw, mp, mp), None, pa_c if train else 0.0, st.step_seed, qkv)
+        a = ops.linear(a, st, P + ".self_attn_t.out_proj.weight", P + ".self_attn_t.out_proj.bias")
+        src_t = ops.layer_norm(ops.dropout(a, p1_c, train, st), rep, st, P + ".norm1_t")
+        qkv = ops.linear(rep, st, P + ".self_attn_s.in_proj_weight", P + ".self_attn_s.in_proj_bias")
+        st.step_seed += 1
+        mp = (hw, Tp * hw, 1, hw)                # sequence over t, batch (lb, hw)
+        a = ops.attention(st, ((0, 0), (0, E), (0, 2 * E)), (LB * hw, H, Tp, Tp, mp, mp), None, cl.self_attn_s.dropout if train else 0.0, st.step_seed, qkv)
+        a = ops.linear(a, st, P + ".self_attn_s.out_proj.weight", P + ".self_attn_s.out_proj.bias")
+        src_s = ops.layer_norm(ops.dropout(a, p1_c, train, st), rep, st, P + ".norm1_s")
+        cat = torch.cat((src_t, src_s), dim=1)
+        enc = ops.layer_norm(self._ffn(st, cat, P, pf_c, train), rep, st, P + ".norm2")
+        q = ops.linear(hs, st, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(0, E))
+        kv = ops.linear(enc, st, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(E, 3 * E))
+        st.step_seed += 1
+        a = ops.attention(st, ((0, 0), (1, 0), (1, E)), (LB, H, Q, Tp * hw, (1, Q, 0, 1), (1, Tp * hw, 0, 1)), None,
+                          self.cross_attn.dropout if train else 0.0, st.step_seed, q, kv)
+        q_class = ops.linear(a, st, "cross_attn.out_proj.weight", "cross_attn.out_proj.bias")
+        q_class = ops.dropout(q_class, self.dropout.p, train, st)
+        logits = ops.linear(q_class, st, "class_fc.weight", "class_fc.bias", out_f32=True).view(lay_n, B, Q, -1)
+
+        out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_logits_b": logits_b[-1]}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a_, "pred_boxes": b_, "pred_logits_b": c_}
+                                  for a_, b_, c_ in zip(logits[:-1], boxes[:-1], logits_b[:-1])]
+        return out
+
+    def _lstr_pool(self, st, feat, B, Tp, hw, train):
+        """TEMPORAL_DS_STRATEGY 'decode' (backbone_builder.py:74-78; transformer_layers.py:380-448): per-pixel one-query
+        decoder (d=2048, 8 heads of 256) over the T' temporal slots.  Rows: queries (b, hw); memory (b, t, hw)."""
+        E = 2048
+        P = "backbone.pool_decoder.layers.0"
+        NQ = B * hw
+        lay = self.backbone.pool_decoder.layers[0]
+        p = lay.self_attn.dropout if train else 0.0
+        pr = lay.dropout1.p
+        tgt = ops.param_rows(st, "backbone.query_pool.weight", NQ, self._anchor)     # the same learned query for every pixel
+        S = P + ".self_attn"
+        q = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(0, E))
+        kv = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(E, 3 * E))
+        st.step_seed += 1
+        a = ops.attention_wide(q, kv, hw, 1, p, st.step_seed)                       # one key: softmax = 1 (dropout still applies)
+        a = ops.linear(a, st, S + ".out_proj.weight", S + ".out_proj.bias")
+        tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm1")
+        Cx = P + ".multihead_attn"
+        q = ops.linear(tgt, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(0, E))
+        kv = ops.linear(feat, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(E, 3 * E))
+        st.step_seed += 1
+        a = ops.attention_wide(q, kv, hw, Tp, p, st.step_seed)
+        a = ops.linear(a, st, Cx + ".out_proj.weight", Cx + ".out_proj.bias")
+        tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm2")
+        tgt = ops.layer_norm(self._ffn(st, tgt, P, pr, train), tgt, st, P + ".norm3")
+        return ops.layer_norm(tgt, None, st, "backbone.pool_decoder.norm")
+
+
+def build_model(cfg):
+    """models/tuber_ava.py:160-221 -> (model, criterion, postprocessors)."""
+    from .criterion import SetCriterion, SetCriterionAVA, PostProcess, PostProcessAVA, build_matcher
+    C = cfg.CONFIG
+    num_classes = C.DATA.NUM_CLASSES
+    backbone = build_backbone(cfg)
+    transformer = build_transformer(cfg)
+    model = DETR(backbone, transformer, num_classes=num_classes, num_queries=C.MODEL.QUERY_NUM, aux_loss=C.TRAIN.AUX_LOSS,
+                 hidden_dim=C.MODEL.D_MODEL, temporal_length=C.MODEL.TEMP_LEN, generate_lfb=C.MODEL.GENERATE_LFB,
+                 backbone_name=C.MODEL.BACKBONE_NAME, ds_rate=C.MODEL.DS_RATE, last_stride=C.MODEL.LAST_STRIDE,
+                 dataset_mode=C.DATA.DATASET_NAME)
+    matcher = build_matcher(cfg)
+    weight_dict = {"loss_ce": C.LOSS_COFS.DICE_COF, "loss_bbox": C.LOSS_COFS.BBOX_COF, "loss_giou": C.LOSS_COFS.GIOU_COF,
+                   "loss_ce_b": 1}
+    if C.TRAIN.AUX_LOSS:
+        aux = {}
+        for i in range(C.MODEL.DEC_LAYERS - 1):
+            aux.update({k + "_%d" % i: v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    losses = ["labels", "boxes"]
+    crit_cls = SetCriterionAVA if C.DATA.DATASET_NAME == "ava" else SetCriterion
+    criterion = crit_cls(C.LOSS_COFS.WEIGHT, num_classes, num_queries=C.MODEL.QUERY_NUM, matcher=matcher, weight_dict=weight_dict,
+                         eos_coef=C.LOSS_COFS.EOS_COF, losses=losses, data_file=C.DATA.DATASET_NAME, evaluation=C.EVAL_ONLY)
+    postprocessors = {"bbox": PostProcessAVA() if C.DATA.DATASET_NAME == "ava" else PostProcess()}
+    return model, criterion, postprocessors
