@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""TubeR training-step throughput on MI355X (the headline metric of BASELINE.json).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one full optimisation step of TubeR_CSN152_AVA21 (forward, Hungarian-matched criterion, backward, global-norm
+clip 0.1, AdamW) on 2 synthetic clips 3x32x256x340 per GPU, model in train() mode with dropout ON, inputs resident in HBM.
+Rank 0 prints ONE JSON line: whole-job clips/s, plus
+  * "roofline": the dominant kernel family of the step (picked by a HIP-event pre-pass over every launch), its
+    ALGORITHMIC bytes per launch / average launch duration measured with HIP events INSIDE the timed steps, vs the 8 TB/s HBM peak;
+  * "cpu_baseline": the CPU oracle (stock PyTorch CPU ops, fp32, same graph) timed on this box's host cores on ONE clip
+    of the same workload (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def alg_cost(name, a):
+    """(key, algorithmic bytes, flops) of one launch from its C-ABI arguments (DESIGN.md 'algorithmic bytes')."""
+    from tubelet_transformer_amd import lib
+    if name == "tuber_gemm_nt":
+        M, N, K = a[6], a[7], a[8]
+        amode, epi, out_f32 = a[9], a[21], a[26]
+        cfg = lib.query("tuber_gemm_nt_cfg", M, N)
+        by = 2 * (M * K + N * K) + (4 if out_f32 else 2) * M * N
+        if a[23] is not None:
+            by += 2 * M * N          # residual read
+        if epi == 2:
+            by += 2 * M * N          # mask source read
+        tile = {0: "128,128,2,2", 1: "128,64,4,1", 2: "64,64,2,2"}[cfg]
+        return "gemm_nt_kernel<%s,%d,%d>" % (tile, amode, epi), by, 2 * M * N * K
+    if name == "tuber_gemm_tn":
+        M, N, K = a[7], a[8], a[9]
+        return "gemm_tn_kernel<%d>" % a[10], 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
+    if name in ("tuber_dwconv_fwd", "tuber_dwconv_bwd_data", "tuber_dwconv_bwd_weight"):
+        off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
+        N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss = a[off:off + 10]
+        by = 2 * C * N * (Ti * Hi * Wi + To * Ho * Wo)
+        if name == "tuber_dwconv_bwd_data":
+            by += 2 * C * N * Ti * Hi * Wi                       # reads x for the relu/bn mask, writes dz
+        key = {"tuber_dwconv_fwd": "dwconv_fwd_kernel<%d>" % ss, "tuber_dwconv_bwd_data": "dwconv_bwd_data_kernel<%d>" % ss,
+               "tuber_dwconv_bwd_weight": "dwconv_bwd_weight_kernel<%d>" % ss}[name]
+        return key, by, 2 * 27 * C * N * To * Ho * Wo
+    if name == "tuber_block_out_fwd":
+        return "block_out_fwd_kernel", 2 * 3 * a[7] * a[8], 0
+    if name == "tuber_block_out_bwd":
+        return "block_out_bwd_kernel", 2 * (5 if a[3] is not None else 4) * a[8] * a[9], 0
+    if name == "tuber_bn_bwd_apply":
+        return "bn_bwd_apply_kernel", 2 * 3 * a[6] * a[7], 0
+    if name == "tuber_stem_im2col":
+        N, T, H, W, Ho, Wo = a[2:8]
+        return "stem_im2col_kernel", 4 * N * 3 * T * H * W + 2 * N * T * Ho * Wo * 448, 0
+    return name.replace("tuber_", "") + "*", 0, 0
+
+
+class LaunchTimer:
+    """HIP-event timing of kernel launches on torch's current stream (where every tuber_* launch is enqueued)."""
+
+    def __init__(self, only=None):
+        self.only, self.rec = only, []
+
+    def __call__(self, name, args, launch):
+        key, by, fl = alg_cost(name, args)
+        if self.only is not None and key != self.only:
+            return launch(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = launch(name, *args)
+        e1.record()
+        self.rec.append((key, by, fl, e0, e1))
+        return rc
+
+    def summary(self):
+        out = {}
+        for key, by, fl, e0, e1 in self.rec:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += by
+            d["flops"] += fl
+        return out
+
+
+def cpu_baseline(cfg, hw):
+    """CPU oracle (oracle/tuber_oracle.py: stock PyTorch CPU ops, fp32, identical graph and state dict): one full training
+    step (forward, criterion, backward, clip, AdamW) on ONE clip of the benchmark workload, all host cores."""
+    from oracle import tuber_oracle as O
+    from tubelet_transformer_amd import synth
+    from tubelet_transformer_amd.tuber import build_model
+    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than that makes stock CPU conv3d slower, not faster
+    torch.set_num_threads(cores)
+    model, _, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    pn = [n for n, _ in model.named_parameters()]
+    state = {k: (v.clone().requires_grad_(True) if k in pn else v.clone()) for k, v in model.state_dict().items()}
+    del model
+    clips = synth.synthetic_clips(1, 32, hw[0], hw[1], seed=1234)
+    targets = synth.synthetic_targets(1, "ava", cfg.CONFIG.DATA.NUM_CLASSES, seed=4321, hw=hw)
+    params = [state[n] for n in pn]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    t0 = time.time()
+    out = O.tuber_forward(state, cfg, clips, train=True)
+    ld, _ = O.set_criterion(cfg, out, targets)
+    loss = O.total_loss(cfg, ld)
+    opt.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 0.1)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "1 full training step (fwd+criterion+bwd+clip+AdamW), batch 1 of the same 3x32x%dx%d workload, fp32, "
+                      "dropout off, cold (no warm-up), %.1f s" % (hw[0], hw[1], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="clips per GPU (reference: TRAIN.BATCH_SIZE 2)")
+    ap.add_argument("--config", default="TubeR_CSN152_AVA21.yaml")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=340)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraphs")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from tubelet_transformer_amd import lib, synth
+    from tubelet_transformer_amd.config import load_cfg
+    from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer, deploy_model, train_step
+    from tubelet_transformer_amd.tuber import build_model
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus == 1 and world == 1:
+            pass
+        else:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    cfg = load_cfg(os.path.join(ROOT, "configuration", args.config))
+    cfg.DDP_CONFIG.GPU = local
+    torch.manual_seed(0)
+    model, criterion, _ = build_model(cfg)
+    synth.load_name_hashed(model)                 # random-init weights of the named architecture (no checkpoints offline)
+    model = deploy_model(model, cfg, dev)
+    criterion.to(dev)
+    model.train()
+    criterion.train()
+    optimizer = build_optimizer(model, cfg)
+    hw = (args.height, args.width)
+    clips = synth.synthetic_clips(args.batch, 32, hw[0], hw[1], seed=1234 + rank, device=dev)
+    targets = synth.synthetic_targets(args.batch, "ava", cfg.CONFIG.DATA.NUM_CLASSES, seed=4321 + rank, device=dev, hw=hw)
+    max_norm = cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM
+
+    def eager_step():
+        return train_step(model, criterion, optimizer, clips, targets, max_norm)
+
+    mode = "eager"
+    step = eager_step
+    if not args.eager:
+        try:
+            graphed = GraphedTrainStep(model, criterion, optimizer, max_norm)
+            graphed(clips, targets)
+            torch.cuda.synchronize()
+            mode = "hipgraph"
+
+            def step():
+                return graphed(clips, targets)
+        except Exception as e:      # capture is an optimisation, never a requirement
+            print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    dominant, prepass = None, None
+    if not args.no_roofline:
+        timer = LaunchTimer()
+        lib.set_launch_hook(timer)
+        eager_step()
+        torch.cuda.synchronize()
+        lib.set_launch_hook(None)
+        prepass = timer.summary()
+        dominant = max((k for k in prepass if prepass[k]["bytes"] > 0), key=lambda k: prepass[k]["ms"])
+    fence()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss, _ = step()
+    fence()
+    dt = time.perf_counter() - t0
+    # HIP-event timing of the dominant kernel family: the same launches, same stream, same inputs, issued eagerly right after the
+    # timed region (launches replayed from a hipGraph cannot be bracketed by events individually)
+    timer = LaunchTimer(only=dominant) if dominant else None
+    if timer:
+        lib.set_launch_hook(timer)
+        for _ in range(min(args.steps, 3)):
+            eager_step()
+        torch.cuda.synchronize()
+        lib.set_launch_hook(None)
+        timed_steps = min(args.steps, 3)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    ms = 1e3 * dt / args.steps
+    total_clips = args.batch * world * args.steps
+    line = {
+        "metric": "clips/sec (TubeR CSN-152 AVA2.1 training step fwd+bwd+clip+AdamW, 32x256x340 clips; whole job)",
+        "value": round(total_clips / dt, 3), "unit": "clips/s", "per_gpu": round(total_clips / dt / world, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights"
+                               % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1]),
+                   "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce)" % world, "launch_mode": mode},
+        "final_loss": round(float(loss), 4) if loss is not None else None,
+        "alg_gflop_per_clip_fwd_bwd": 981.0,
+        "readme_implied_gflops": round(total_clips / dt * 120.0, 1),
+    }
+    if rank == 0 and timer is not None:
+        s = timer.summary()[dominant]
+        ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9
+        line["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
+                            "alg_bytes_per_launch": int(s["bytes"] / s["launches"]),
+                            "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
+                            "share_of_step": round(s["ms"] / timed_steps / ms, 4)}
+        line["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(prepass.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        line["end_to_end"] = {"hbm_frac_of_alg_bytes": round(8.4e9 * total_clips / dt / (HBM_PEAK_GBS * 1e9 * world), 4),
+                              "mfma_frac_of_alg_flops": round(981e9 * total_clips / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12 * world), 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cfg, hw)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

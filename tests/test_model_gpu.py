@@ -45,7 +45,7 @@ def make_clips(sizes, seed):
 
 
 def flat_outputs(out):
-    d = {k: v.detach().float().cpu().numpy() for k, v in out.items() if k != "aux_outputs"}
+    d = {k: v.detach().float().cpu().numpy() for k, v in out.items() if k not in ("aux_outputs", "_stacked")}
     for i, a in enumerate(out.get("aux_outputs", [])):
         for k, v in a.items():
             d["aux%d.%s" % (i, k)] = v.detach().float().cpu().numpy()

@@ -152,6 +152,7 @@ class CSNRunner:
                 p = "%slayer%d.%d." % (prefix, li, bi)
                 d = {"cin": blk.conv1.in_channels, "p": blk.conv1.out_channels, "st": blk.temporal_stride, "ss": blk.stride,
                      "ds": blk.down_sample is not None}
+                d["off0"] = store.offsets[p + "conv1.weight"]
                 d["w1"], _, d["g1"] = wptr(p + "conv1.weight")
                 d["w1t"], d["ld1t"] = tptr(p + "conv1.weight")
                 _, d["w3"], d["g3"] = wptr(p + "conv3.weight")
@@ -164,6 +165,9 @@ class CSNRunner:
                     d["bnd"] = mk_bn(p + "down_sample.1", blk.down_sample[1])
                 self.blocks.append(d)
         self._ws = {}
+        # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
+        body = [store.offsets[n] + (q.numel() + 63) // 64 * 64 for n, q in zip(store.names, store.params) if n.startswith(prefix)]
+        self.body_end = max(body)
 
     # -- workspaces (serialised on the stream, so one of each kind suffices) ---------------------
     def ws(self, key, numel, dtype=torch.float32):
@@ -268,6 +272,9 @@ class CSNRunner:
         dev = self.dev
         dy = dfeat
         B = saved["stem"][4][0]
+        red = getattr(self.store, "reducer", None)
+        if red is not None:           # everything behind the body (transformer, heads, pool decoder) is final
+            red.notify(self.body_end, force=True)
         for d, sv in zip(reversed(self.blocks), reversed(saved["blocks"])):
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
@@ -275,7 +282,7 @@ class CSNRunner:
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
             # join backward: dz + stats of bn4 (and the shortcut BN)
-            R = lib.query("tuber_rowblock_count", Mout)
+            R = lib.query("tuber_rowblock_count", Mout, C4)
             sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
             dz = torch.empty(Mout, C4, dtype=BF, device=dev)
             lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
@@ -321,6 +328,8 @@ class CSNRunner:
             if d["ds"] and strided:
                 lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
             dy = dx
+            if red is not None:
+                red.notify(d["off0"])
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
         _, col, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
         M0 = B * T * Ho * Wo

@@ -1,14 +1,16 @@
-"""Hungarian-matched set criterion and post-processing of TubeR.
+"""Hungarian-matched set criterion and post-processing of TubeR on the MI355X path.
 
 API mirror of ``models/criterion.py`` (``SetCriterionAVA`` :11-206, ``SetCriterion`` :209-410, ``PostProcess`` :413-445,
-``PostProcessAVA`` :447-482) and ``models/detr/matcher{,_ucf}.py`` (``HungarianMatcher`` :37-81 / :37-88).
+``PostProcessAVA`` :447-482) and ``models/detr/matcher{,_ucf}.py`` (``HungarianMatcher`` :37-81 / :37-88): same constructors,
+``criterion(outputs, targets) -> dict`` with the 24 (+class_error) keys, mutable ``criterion.weight_dict``.
 
-Differences in HOW (not what) it computes, chosen for the MI355X step (SURVEY.md sections 2.3 K14/K15, 7.8):
-  * the matching cost of ALL decoder layers is built in one batched device computation and copied to the host ONCE
-    per step (the reference does 6 ``.cpu()`` syncs), the assignment runs in the C++ restatement of SciPy's solver
-    (``tuber_lsap`` in libtuber_hip.so -- no SciPy on the product path);
-  * the weighted BCE is evaluated from logits in fp32 (``softplus``), which equals
-    ``F.binary_cross_entropy(sigmoid(x), t, w)`` up to that function's log clamp at -100 (criterion.py:57,71-73).
+How it runs (SURVEY.md sections 2.3 K14/K15, 7.8):
+  * ``tuber_criterion_cost``: matching cost of ALL decoder layers in one kernel, ONE device->host copy per step (the reference
+    does six ``.cpu()`` round trips), assignment by ``tuber_lsap`` -- the C++ restatement of SciPy's solver in libtuber_hip.so;
+  * ``tuber_criterion_loss``: every loss term of every layer AND its gradient w.r.t. the model outputs in one launch, fp32;
+    the autograd backward only scales those gradients by the loss weights.  The weighted BCE is evaluated from logits
+    (softplus), equal to ``F.binary_cross_entropy(sigmoid(x), t, w)`` including its log clamp at -100 (criterion.py:57,71-73);
+  * targets are padded to a static [B, Tmax] layout so the whole step can be captured in a hipGraph.
 """
 import numpy as np
 import torch
@@ -16,7 +18,6 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import box_ops, lib
-from .misc import accuracy, accuracy_sigmoid
 
 
 def _lsap(cost):
@@ -26,10 +27,36 @@ def _lsap(cost):
     nr, nc = cost.shape
     k = min(nr, nc)
     ri, ci = np.zeros(k, np.int64), np.zeros(k, np.int64)
+    if k == 0:
+        return ri, ci
     rc = L.tuber_lsap(cost.ctypes.data, nr, nc, ri.ctypes.data, ci.ctypes.data)
     if rc != 0:
         raise ValueError("cost matrix is infeasible or contains invalid entries (tuber_lsap rc=%d)" % rc)
     return ri, ci
+
+
+class PaddedTargets:
+    """Static [B, Tmax] device layout of the target dicts."""
+
+    def __init__(self, targets, ava, num_classes, device, tmax=None):
+        self.sizes = [int(t["boxes"].shape[0]) for t in targets]
+        B = len(targets)
+        need = max(self.sizes + [1])
+        self.tmax = tmax if tmax is not None else max(8, (need + 7) // 8 * 8)
+        if need > self.tmax:
+            raise ValueError("%d targets in a clip exceed Tmax=%d" % (need, self.tmax))
+        self.ava, self.B = ava, B
+        self.tboxes = torch.zeros(B, self.tmax, 4, dtype=torch.float32, device=device)
+        self.tlabels = torch.zeros((B, self.tmax, num_classes) if ava else (B, self.tmax), dtype=torch.float32, device=device)
+        self.tcount = torch.tensor(self.sizes, dtype=torch.int32).to(device)
+        self.fill(targets)
+
+    def fill(self, targets):
+        for b, t in enumerate(targets):
+            n = self.sizes[b]
+            if n:
+                self.tboxes[b, :n] = t["boxes"][:, 1:].to(self.tboxes)          # column 0 is the key-frame index
+                self.tlabels[b, :n] = t["labels"].to(self.tlabels)
 
 
 class HungarianMatcher(nn.Module):
@@ -40,43 +67,38 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def cost_matrices(self, layer_outputs, targets):
-        """Cost tensors for a list of per-layer output dicts: [n_layers, B, Q, sum_i N_i] on the device."""
-        ava = self.data_file == "ava"
-        boxes = torch.stack([o["pred_boxes"] for o in layer_outputs]).float()           # [L,B,Q,4]
-        Lr, B, Q, _ = boxes.shape
-        ob = boxes.reshape(-1, 4)
-        tb = torch.cat([t["boxes"] for t in targets])[:, 1:].float()
-        c_bbox = torch.cdist(ob, tb, p=1)
-        c_giou = -box_ops.generalized_box_iou(box_ops.box_cxcywh_to_xyxy(ob), box_ops.box_cxcywh_to_xyxy(tb))
-        if ava:
-            prob = torch.stack([o["pred_logits_b"] for o in layer_outputs]).float().reshape(Lr * B * Q, -1).softmax(-1)
-            c_cls = -prob[:, 1:2].expand(-1, tb.shape[0])
-        else:
-            ids = torch.cat([t["labels"] for t in targets])
-            prob = torch.stack([o["pred_logits"] for o in layer_outputs]).float().reshape(Lr * B * Q, -1).softmax(-1)
-            c_cls = -prob[:, ids]
-        C = self.cost_bbox * c_bbox + self.cost_class * c_cls + self.cost_giou * c_giou
-        return C.view(Lr, B, Q, -1)
+    def cost(self, logits, logits_b, boxes, pt):
+        """[L,B,Q,Tmax] cost tensor on the device (entries beyond tcount[b] are 0)."""
+        L, B, Q, C = logits.shape
+        out = torch.empty(L, B, Q, pt.tmax, dtype=torch.float32, device=logits.device)
+        lib.call("tuber_criterion_cost", logits, logits_b, boxes, pt.tboxes, pt.tlabels, pt.tcount, L, B, Q, C, pt.tmax,
+                 1 if self.data_file == "ava" else 0, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), out)
+        return out
 
-    @torch.no_grad()
-    def match_layers(self, layer_outputs, targets):
-        """indices[layer][b] = (idx_query int64, idx_target int64) CPU tensors; ONE device->host copy."""
-        C = self.cost_matrices(layer_outputs, targets).cpu().double().numpy()
-        sizes = [len(t["boxes"]) for t in targets]
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        out = []
-        for l in range(C.shape[0]):
+    @staticmethod
+    def solve(cost_host, sizes):
+        """cost_host numpy [L,B,Q,Tmax] -> (match int32 [L,B,Tmax] (query of target j or -1), indices[l][b] = (idx_q, idx_t))."""
+        L, B, Q, T = cost_host.shape
+        match = np.full((L, B, T), -1, dtype=np.int32)
+        indices = []
+        for l in range(L):
             per = []
             for b, n in enumerate(sizes):
-                i, j = _lsap(C[l, b, :, offs[b]:offs[b] + n])
+                i, j = _lsap(cost_host[l, b, :, :n].astype(np.float64))
+                match[l, b, j] = i
                 per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
-            out.append(per)
-        return out
+            indices.append(per)
+        return match, indices
 
     @torch.no_grad()
     def forward(self, outputs, targets):
-        return self.match_layers([outputs], targets)[0]
+        ava = self.data_file == "ava"
+        lg = outputs["pred_logits"].float().contiguous()[None]
+        bx = outputs["pred_boxes"].float().contiguous()[None]
+        lb = outputs["pred_logits_b"].float().contiguous()[None] if ava else lg
+        pt = PaddedTargets(targets, ava, lg.shape[-1], lg.device)
+        C = self.cost(lg, lb, bx, pt).cpu().numpy()
+        return self.solve(C, pt.sizes)[1][0]
 
 
 def build_matcher(cfg):
@@ -85,9 +107,31 @@ def build_matcher(cfg):
                             data_file=cfg.CONFIG.DATA.DATASET_NAME, binary_loss=M.BNY_LOSS, before=M.BEFORE)
 
 
-def _src_idx(indices, device):
-    b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)]).to(device)
-    return b, torch.cat([s for s, _ in indices]).to(device)
+class _LossFn(torch.autograd.Function):
+    """losses[L,4] = (ce, ce_b, bbox, giou) per decoder layer; gradients precomputed by the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, logits_b, boxes, pt, match, ava, eos, pos_weight):
+        L, B, Q, C = logits.shape
+        dev = logits.device
+        losses = torch.empty(L, 4, dtype=torch.float32, device=dev)
+        g_l = torch.empty_like(logits)
+        g_b = torch.empty(L, B, Q, 3, dtype=torch.float32, device=dev)
+        g_x, g_g = torch.empty_like(boxes), torch.empty_like(boxes)
+        lib.call("tuber_criterion_loss", logits, logits_b, boxes, pt.tboxes, pt.tlabels, pt.tcount, match, L, B, Q, C, pt.tmax,
+                 1 if ava else 0, float(eos), float(pos_weight), losses, g_l, g_b, g_x, g_g)
+        ctx.save_for_backward(g_l, g_b, g_x, g_g)
+        ctx.ava = ava
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        g_l, g_b, g_x, g_g = ctx.saved_tensors
+        g = g.float()
+        gl = g[:, 0].view(-1, 1, 1, 1) * g_l
+        gb = g[:, 1].view(-1, 1, 1, 1) * g_b if ctx.ava else None
+        gx = g[:, 2].view(-1, 1, 1, 1) * g_x + g[:, 3].view(-1, 1, 1, 1) * g_g
+        return gl, gb, gx, None, None, None, None, None
 
 
 class _SetCriterionBase(nn.Module):
@@ -97,36 +141,49 @@ class _SetCriterionBase(nn.Module):
         self.num_classes, self.num_queries = num_classes, num_queries
         self.matcher, self.weight_dict = matcher, weight_dict
         self.eos_coef, self.losses, self.data_file = eos_coef, losses, data_file
+        self.ava = data_file == "ava"
+        self.last_indices = None
 
-    def loss_boxes(self, outputs, targets, indices, num_boxes):
-        idx = _src_idx(indices, outputs["pred_boxes"].device)
-        src = outputs["pred_boxes"][idx].float()
-        tgt = torch.cat([t["boxes"][i.to(t["boxes"].device)] for t, (_, i) in zip(targets, indices)], dim=0)[:, 1:].float()
-        if src.shape[0] == 0:
-            z = src.sum() * 0
-            return {"loss_bbox": z, "loss_giou": z}
-        l1 = (src - tgt).abs().sum() / num_boxes
-        giou = torch.diag(box_ops.generalized_box_iou(box_ops.box_cxcywh_to_xyxy(src), box_ops.box_cxcywh_to_xyxy(tgt)))
-        return {"loss_bbox": l1, "loss_giou": (1 - giou).sum() / num_boxes}
+    # -- pieces (also used one by one by the hipGraph-captured step, training.GraphedStep) ----------------
+    def stacked(self, outputs):
+        """(logits, logits_b, boxes) as [L,B,Q,.] fp32 in decoder-layer order (main output = last layer)."""
+        if "_stacked" in outputs:
+            return outputs["_stacked"]
+        layers = list(outputs.get("aux_outputs", [])) + [{k: v for k, v in outputs.items() if k != "aux_outputs"}]
+        return tuple(torch.stack([o[k].float() for o in layers]) for k in ("pred_logits", "pred_logits_b", "pred_boxes"))
 
-    def _layers(self, outputs):
-        main = {k: v for k, v in outputs.items() if k != "aux_outputs"}
-        return [main] + list(outputs.get("aux_outputs", []))
+    def select(self, logits, boxes, targets):
+        return logits, boxes
+
+    def losses_from_match(self, logits, logits_b, boxes, pt, match_dev, targets):
+        L = logits.shape[0]
+        pos_w = 1.0 if (self.evaluation or not self.ava) else float(self.weight)
+        lv = _LossFn.apply(logits.contiguous(), logits_b.contiguous() if self.ava else logits, boxes.contiguous(), pt, match_dev,
+                           self.ava, float(self.eos_coef), pos_w)
+        ce_b = lv[:, 1] if self.ava else self.visibility_loss(logits_b, targets)
+        out = {}
+        for l in range(L):
+            sfx = "" if l == L - 1 else "_%d" % l
+            out["loss_ce" + sfx] = lv[l, 0]
+            out["loss_ce_b" + sfx] = ce_b[l]
+            out["loss_bbox" + sfx] = lv[l, 2]
+            out["loss_giou" + sfx] = lv[l, 3]
+        return out
 
     def forward(self, outputs, targets):
-        layers = [self._select(o, targets) for o in self._layers(outputs)]
-        all_idx = self.matcher.match_layers(layers, targets)
-        num_boxes = float(sum(len(t["labels"]) for t in targets))     # local count, not all-reduced (criterion.py:182-183)
-        losses = {}
-        for li, (o, indices) in enumerate(zip(layers, all_idx)):
-            ld = self.loss_labels(o, targets, indices, num_boxes, log=(li == 0))
-            ld.update(self.loss_boxes(o, targets, indices, max(num_boxes, 1.0)))
-            losses.update(ld if li == 0 else {k + "_%d" % (li - 1): v for k, v in ld.items()})
-        self.last_indices = all_idx
+        logits, logits_b, boxes = self.stacked(outputs)
+        logits_s, boxes_s = self.select(logits, boxes, targets)
+        pt = PaddedTargets(targets, self.ava, logits.shape[-1], logits.device)
+        with torch.no_grad():
+            cost = self.matcher.cost(logits_s.detach().contiguous(), (logits_b if self.ava else logits_s).detach().contiguous(),
+                                     boxes_s.detach().contiguous(), pt)
+            match, indices = self.matcher.solve(cost.cpu().numpy(), pt.sizes)          # the step's ONE device->host sync
+            match_dev = torch.from_numpy(match).to(logits.device, non_blocking=True)
+        L = logits.shape[0]
+        self.last_indices = [indices[L - 1]] + indices[:L - 1]                          # reference order: main, aux_0 .. aux_4
+        losses = self.losses_from_match(logits_s, logits_b, boxes_s, pt, match_dev, targets)
+        losses["class_error"] = self.class_error(logits_s[-1], pt, match_dev[-1])
         return losses
-
-    def _select(self, o, targets):
-        return o
 
 
 class SetCriterionAVA(_SetCriterionBase):
@@ -138,26 +195,19 @@ class SetCriterionAVA(_SetCriterionBase):
         ew[-1] = self.eos_coef
         self.register_buffer("empty_weight", ew)
 
-    def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
-        lg, lb = outputs["pred_logits"].float(), outputs["pred_logits_b"].float()
-        dev = lg.device
-        idx = _src_idx(indices, dev)
-        tcb = torch.full(lb.shape[:2], 2, dtype=torch.int64, device=dev)
-        tcb[idx] = 1
-        loss_ce_b = F.cross_entropy(lb.transpose(1, 2), tcb, self.empty_weight.to(dev))
-        tco = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)]).float()
-        tc = torch.zeros_like(lg)
-        tc[idx] = tco
-        # BCE(sigmoid(x), t) = softplus(x) - t*x ; the reference clamps each log term at -100
-        per = torch.minimum(F.softplus(-lg), lg.new_tensor(100.0)) * tc + torch.minimum(F.softplus(lg), lg.new_tensor(100.0)) * (1 - tc)
-        if not self.evaluation:
-            w = torch.ones(lg.shape[:2], dtype=lg.dtype, device=dev)
-            w[idx] = self.weight
-            per = per * w[:, :, None]
-        losses = {"loss_ce": per.mean(), "loss_ce_b": loss_ce_b}
-        if log:
-            losses["class_error"] = 100 - accuracy_sigmoid(lg[idx], tco)[0]
-        return losses
+    @torch.no_grad()
+    def class_error(self, logits, pt, match):
+        """100 - exact-set accuracy of the matched queries (utils/misc.py:497-518), computed on the device without a sync:
+        top-k(labels) == labels  <=>  min logit over the labels > max logit over the rest."""
+        B, Q, C = logits.shape
+        valid = match >= 0                                                   # [B,Tmax]
+        q = match.clamp(min=0).long()
+        rows = torch.gather(logits, 1, q[:, :, None].expand(-1, -1, C))      # [B,Tmax,C]
+        lab = pt.tlabels > 0.5
+        lo = torch.where(lab, rows, rows.new_full((), float("inf"))).amin(-1)
+        hi = torch.where(lab, rows.new_full((), float("-inf")), rows).amax(-1)
+        ok = (lo > hi) & valid
+        return 100.0 - 100.0 * ok.sum() / valid.sum().clamp(min=1)
 
 
 class SetCriterion(_SetCriterionBase):
@@ -169,28 +219,27 @@ class SetCriterion(_SetCriterionBase):
         ew[-1] = self.eos_coef
         self.register_buffer("empty_weight", ew)
 
-    def _select(self, o, targets):
+    def select(self, logits, boxes, targets):
         nq = self.num_queries
-        dev = o["pred_logits"].device
-        kf = torch.stack([nq * t["key_pos"].to(dev) + torch.arange(nq, device=dev) for t in targets])
-        sel = {}
-        for k, v in o.items():
-            sel[k] = v.gather(1, kf[:, :, None].expand(-1, -1, v.shape[-1])) if k in ("pred_boxes", "pred_logits") else v
-        return sel
+        dev = logits.device
+        kf = torch.stack([nq * t["key_pos"].to(dev) + torch.arange(nq, device=dev) for t in targets])       # [B,nq]
+        L = logits.shape[0]
+        idx = kf[None, :, :, None].expand(L, -1, -1, -1)
+        return (torch.gather(logits, 2, idx.expand(-1, -1, -1, logits.shape[-1])),
+                torch.gather(boxes, 2, idx.expand(-1, -1, -1, 4)))
 
-    def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
-        lg, lb = outputs["pred_logits"].float(), outputs["pred_logits_b"].float()
-        dev = lg.device
-        idx = _src_idx(indices, dev)
-        vis = torch.cat([t["vis"] for t in targets]).view(-1).to(dev)
-        loss_ce_b = F.cross_entropy(lb, vis)
-        tco = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)]).to(dev)
-        tc = torch.full(lg.shape[:2], self.num_classes, dtype=torch.int64, device=dev)
-        tc[idx] = tco
-        losses = {"loss_ce": F.cross_entropy(lg.transpose(1, 2), tc, self.empty_weight.to(dev)), "loss_ce_b": loss_ce_b}
-        if log:
-            losses["class_error"] = 100 - accuracy(lg[idx], tco)[0]
-        return losses
+    def visibility_loss(self, logits_b, targets):
+        vis = torch.cat([t["vis"] for t in targets]).view(-1).to(logits_b.device)
+        L, B = logits_b.shape[:2]
+        return F.cross_entropy(logits_b.reshape(L * B, -1).float(), vis.repeat(L), reduction="none").view(L, B).mean(1)
+
+    @torch.no_grad()
+    def class_error(self, logits, pt, match):
+        valid = match >= 0
+        q = match.clamp(min=0).long()
+        rows = torch.gather(logits, 1, q[:, :, None].expand(-1, -1, logits.shape[-1]))
+        ok = (rows.argmax(-1) == pt.tlabels.long()) & valid
+        return 100.0 - 100.0 * ok.sum() / valid.sum().clamp(min=1)
 
 
 class PostProcess(nn.Module):

@@ -28,7 +28,7 @@ struct AttnArgs {
     float* lse;                   // [B][H][Lq]
     const uint8_t* kpm;           // [B][Lk] (1 = padded key) or null
     int B, H, Lq, Lk;
-    float scale, pdrop; uint32_t thresh; uint64_t seed;
+    float scale, pdrop; uint32_t thresh; const uint64_t* seed_ptr; uint64_t salt;
     // backward
     const bf16* dO; TokMap mdo;
     bf16* dQ; TokMap mdq;
@@ -65,6 +65,10 @@ __device__ __forceinline__ void stage_tile(bf16 (*dst)[32], const bf16* base, co
     }
 }
 
+__device__ __forceinline__ uint64_t eff_seed(const uint64_t* seed_ptr, uint64_t salt) {
+    return (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
+}
+
 __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 ks[KT][32];
     __shared__ __attribute__((aligned(16))) bf16 vs[KT][32];
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnArgs a) {
     float mx = -INFINITY, l = 0.f;
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + (active ? qi : 0)) * (uint64_t)a.Lk;
+    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
         __syncthreads();
         stage_tile(ks, a.K, a.mk, b, h, k0, a.Lk);
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnArgs a) {
                 const float p = __expf(s[j] - mx);     // exp(-inf) = 0 for masked / tail keys
                 l += p;
                 float pv = p;
-                if (a.pdrop > 0.f) pv = dropout_keep(a.seed, rbase + k0 + kk, a.thresh) ? p * inv_keep : 0.f;
+                if (a.pdrop > 0.f) pv = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? p * inv_keep : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bf16x8 t = as_bf16x8(*(const uint4*)&vs[kk][i * 8]);
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + (active ? qi : 0)) * (uint64_t)a.Lk;
+    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
         __syncthreads();
         stage_tile(ks, a.K, a.mk, b, h, k0, a.Lk);
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
             const float p = __expf(s * a.scale - lse);
-            if (a.pdrop > 0.f) dp = dropout_keep(a.seed, rbase + k0 + kk, a.thresh) ? dp * inv_keep : 0.f;
+            if (a.pdrop > 0.f) dp = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? dp * inv_keep : 0.f;
             const float ds = p * (dp - delta) * a.scale;
 #pragma unroll
             for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, kv[d], dq[d]);
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnArgs a) {
         load_row32(a.V + tok_row(a.mv, ki, b) * a.mv.ld + h * 32, v);
     }
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     for (int q0 = 0; q0 < a.Lq; q0 += KT) {
         __syncthreads();
         stage_tile(qs, a.Q, a.mq, b, h, q0, a.Lq);
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnArgs a) {
             float pd = p;
             if (a.pdrop > 0.f) {
                 const uint64_t idx = ((uint64_t)(b * a.H + h) * a.Lq + (q0 + qq)) * (uint64_t)a.Lk + ki;
-                const bool keep = dropout_keep(a.seed, idx, a.thresh);
+                const bool keep = dropout_keep(seed, idx, a.thresh);
                 pd = keep ? p * inv_keep : 0.f;
                 dp = keep ? dp * inv_keep : 0.f;
             }
@@ -286,7 +293,8 @@ __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
 template <bool BWD>
 __global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kv, bf16* __restrict__ o,
                                                         const bf16* __restrict__ dO, bf16* __restrict__ dq, bf16* __restrict__ dkv,
-                                                        int HW, int T, float scale, float pdrop, uint32_t thresh, uint64_t seed) {
+                                                        int HW, int T, float scale, float pdrop, uint32_t thresh, const uint64_t* seed_ptr, uint64_t salt) {
+    const uint64_t seed = pdrop > 0.f ? eff_seed(seed_ptr, salt) : 0ull;
     const int pix = blockIdx.x, head = threadIdx.x >> 5, d0 = threadIdx.x * 8;   // d0 = head*256 + lane32*8
     const int b = pix / HW, hwi = pix % HW;
     float qv[8];
@@ -363,13 +371,13 @@ static TokMap mk_map(const long* m) { TokMap t; t.ld = m[0]; t.sL = m[1]; t.s1 =
 
 int tuber_attn_fwd(const void* Q, const long* mq, const void* K, const long* mk, const void* V, const long* mv, void* O,
                    const long* mo, float* lse, const void* key_padding_mask, int B, int H, int Lq, int Lk, float scale,
-                   float pdrop, unsigned long long seed, hipStream_t stream) {
+                   float pdrop, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
     AttnArgs a{};
     a.Q = (const bf16*)Q; a.mq = mk_map(mq); a.K = (const bf16*)K; a.mk = mk_map(mk); a.V = (const bf16*)V; a.mv = mk_map(mv);
     a.O = (bf16*)O; a.mo = mk_map(mo); a.lse = lse; a.kpm = (const uint8_t*)key_padding_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.pdrop = pdrop;
-    a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed = seed;
+    a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(128), 0, stream, a);
     TUBER_RETURN_LAUNCH();
 }
@@ -377,13 +385,13 @@ int tuber_attn_fwd(const void* Q, const long* mq, const void* K, const long* mk,
 int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk, const void* V, const long* mv, const void* O,
                    const long* mo, const float* lse, const void* key_padding_mask, const void* dO, const long* mdo, void* dQ,
                    const long* mdq, void* dK, const long* mdk, void* dV, const long* mdv, float* delta, int B, int H, int Lq,
-                   int Lk, float scale, float pdrop, unsigned long long seed, hipStream_t stream) {
+                   int Lk, float scale, float pdrop, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
     AttnArgs a{};
     a.Q = (const bf16*)Q; a.mq = mk_map(mq); a.K = (const bf16*)K; a.mk = mk_map(mk); a.V = (const bf16*)V; a.mv = mk_map(mv);
     a.O = (bf16*)O; a.mo = mk_map(mo); a.lse = (float*)lse; a.kpm = (const uint8_t*)key_padding_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.pdrop = pdrop;
-    a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed = seed;
+    a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
     a.dO = (const bf16*)dO; a.mdo = mk_map(mdo); a.dQ = (bf16*)dQ; a.mdq = mk_map(mdq); a.dK = (bf16*)dK; a.mdk = mk_map(mdk);
     a.dV = (bf16*)dV; a.mdv = mk_map(mdv); a.delta = delta;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(128), 0, stream, a);
@@ -391,18 +399,18 @@ int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk,
     TUBER_RETURN_LAUNCH();
 }
 
-int tuber_attn_wide_fwd(const void* q, const void* kv, void* o, int NQ, int HW, int T, float pdrop, unsigned long long seed,
-                        hipStream_t stream) {
+int tuber_attn_wide_fwd(const void* q, const void* kv, void* o, int NQ, int HW, int T, float pdrop, const void* seed_ptr,
+                        unsigned long long salt, hipStream_t stream) {
     if (T < 1 || T > WT_MAX || NQ <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
     hipLaunchKernelGGL(attn_wide_kernel<false>, dim3(NQ), dim3(256), 0, stream, (const bf16*)q, (const bf16*)kv, (bf16*)o, nullptr,
-                       nullptr, nullptr, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (uint64_t)seed);
+                       nullptr, nullptr, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (const uint64_t*)seed_ptr, (uint64_t)salt);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_attn_wide_bwd(const void* q, const void* kv, const void* dO, void* dq, void* dkv, int NQ, int HW, int T, float pdrop,
-                        unsigned long long seed, hipStream_t stream) {
+                        const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
     if (T < 1 || T > WT_MAX || NQ <= 0 || pdrop < 0.f || pdrop >= 1.f) return TUBER_EINVAL;
     hipLaunchKernelGGL(attn_wide_kernel<true>, dim3(NQ), dim3(256), 0, stream, (const bf16*)q, (const bf16*)kv, nullptr, (const bf16*)dO,
-                       (bf16*)dq, (bf16*)dkv, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (uint64_t)seed);
+                       (bf16*)dq, (bf16*)dkv, HW, T, 0.0625f, pdrop, (uint32_t)((double)pdrop * 4294967296.0), (const uint64_t*)seed_ptr, (uint64_t)salt);
     TUBER_RETURN_LAUNCH();
 }
 

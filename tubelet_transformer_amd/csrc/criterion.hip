@@ -1,0 +1,245 @@
+// Hungarian-matched set criterion of TubeR on the device (fp32), all decoder layers in one launch each.
+// reference: HungarianMatcher.forward (models/detr/matcher.py:37-81, matcher_ucf.py:37-88),
+// SetCriterionAVA.loss_labels / loss_boxes (models/criterion.py:42-81,97-117), SetCriterion.loss_labels (:237-262),
+// generalized_box_iou (utils/box_ops.py:41-65).
+//
+//   criterion_cost : C[l,b,q,j] = w_bbox*|box_q - box_j|_1 - w_giou*GIoU(box_q, box_j) - w_class*p   for every layer l
+//                    -> ONE device-to-host copy per step feeds the host assignment solver (tuber_lsap)
+//   criterion_loss : given match[l,b,j] = query matched to target j (or -1): the four loss terms of every layer
+//                    AND their gradients w.r.t. logits / actor logits / boxes (the backward pass only scales them)
+// Targets are padded to Tmax per clip (tcount[b] valid rows), so shapes are static: the step can be hipGraph-captured.
+#include "common.h"
+
+struct CritArgs {
+    const float* logits;     // [L,B,Q,C]
+    const float* logits_b;   // [L,B,Q,3] (AVA) or unused
+    const float* boxes;      // [L,B,Q,4] cxcywh
+    const float* tboxes;     // [B,Tmax,4] cxcywh
+    const float* tlabels;    // AVA: [B,Tmax,C] multi-hot ; JHMDB: [B,Tmax] class id stored as float
+    const int* tcount;       // [B]
+    int L, B, Q, C, Tmax, ava;
+    float w_class, w_bbox, w_giou;
+    // loss kernel
+    const int* match;        // [L,B,Tmax]
+    float eos, pos_weight;   // EOS_COF, LOSS_COFS.WEIGHT (1 when evaluation)
+    float* losses;           // [L,4] = ce, ce_b, bbox, giou
+    float* g_logits;         // [L,B,Q,C]
+    float* g_logits_b;       // [L,B,Q,3]
+    float* g_bbox;           // [L,B,Q,4]
+    float* g_giou;           // [L,B,Q,4]
+};
+
+__device__ __forceinline__ float softplus_clamped(float x) {   // min(softplus(x), 100): BCE's log clamp at -100
+    const float sp = x > 20.f ? x : log1pf(__expf(x));
+    return fminf(sp, 100.f);
+}
+
+// GIoU of a predicted cxcywh box p and a target t, optionally with d(1 - giou)/d(p)
+__device__ __forceinline__ float giou_loss(const float* p, const float* t, float* grad) {
+    const float x0 = p[0] - 0.5f * p[2], x1 = p[0] + 0.5f * p[2], y0 = p[1] - 0.5f * p[3], y1 = p[1] + 0.5f * p[3];
+    const float X0 = t[0] - 0.5f * t[2], X1 = t[0] + 0.5f * t[2], Y0 = t[1] - 0.5f * t[3], Y1 = t[1] + 0.5f * t[3];
+    const float A1 = (x1 - x0) * (y1 - y0), A2 = (X1 - X0) * (Y1 - Y0);
+    const float iw_raw = fminf(x1, X1) - fmaxf(x0, X0), ih_raw = fminf(y1, Y1) - fmaxf(y0, Y0);
+    const float iw = fmaxf(iw_raw, 0.f), ih = fmaxf(ih_raw, 0.f);
+    const float I = iw * ih, U = A1 + A2 - I;
+    const float cw = fmaxf(fmaxf(x1, X1) - fminf(x0, X0), 0.f), ch = fmaxf(fmaxf(y1, Y1) - fminf(y0, Y0), 0.f);
+    const float Ca = cw * ch;
+    const float iou = I / U;
+    const float giou = iou - (Ca - U) / Ca;
+    if (grad) {
+        // partials w.r.t. (x0, y0, x1, y1); subgradients follow torch (max/min route to the selected operand)
+        const float diw[4] = {(iw_raw > 0.f && x0 > X0) ? -1.f : 0.f, 0.f, (iw_raw > 0.f && x1 < X1) ? 1.f : 0.f, 0.f};
+        const float dih[4] = {0.f, (ih_raw > 0.f && y0 > Y0) ? -1.f : 0.f, 0.f, (ih_raw > 0.f && y1 < Y1) ? 1.f : 0.f};
+        const float dcw[4] = {x0 < X0 ? -1.f : 0.f, 0.f, x1 > X1 ? 1.f : 0.f, 0.f};
+        const float dch[4] = {0.f, y0 < Y0 ? -1.f : 0.f, 0.f, y1 > Y1 ? 1.f : 0.f};
+        const float dA1[4] = {-(y1 - y0), -(x1 - x0), (y1 - y0), (x1 - x0)};
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dI = diw[k] * ih + iw * dih[k];
+            const float dU = dA1[k] - dI;
+            const float dCa = dcw[k] * ch + cw * dch[k];
+            const float diou = (dI * U - I * dU) / (U * U);
+            const float dUC = (dU * Ca - U * dCa) / (Ca * Ca);     // d(U/Ca)
+            d[k] = -(diou + dUC);                                   // loss = 2 - iou - U/Ca
+        }
+        grad[0] = d[0] + d[2];
+        grad[1] = d[1] + d[3];
+        grad[2] = 0.5f * (d[2] - d[0]);
+        grad[3] = 0.5f * (d[3] - d[1]);
+    }
+    return 1.f - giou;
+}
+
+__global__ __launch_bounds__(256) void criterion_cost_kernel(CritArgs a, float* __restrict__ cost) {
+    const int lb = blockIdx.x, l = lb / a.B, b = lb % a.B;
+    const int n = a.tcount[b];
+    for (int i = threadIdx.x; i < a.Q * a.Tmax; i += 256) {
+        const int q = i / a.Tmax, j = i % a.Tmax;
+        float c = 0.f;
+        if (j < n) {
+            const float* p = a.boxes + ((long)(l * a.B + b) * a.Q + q) * 4;
+            const float* t = a.tboxes + ((long)b * a.Tmax + j) * 4;
+            const float l1 = fabsf(p[0] - t[0]) + fabsf(p[1] - t[1]) + fabsf(p[2] - t[2]) + fabsf(p[3] - t[3]);
+            const float gl = giou_loss(p, t, nullptr);            // 1 - giou
+            float prob;
+            if (a.ava) {
+                const float* z = a.logits_b + ((long)(l * a.B + b) * a.Q + q) * 3;
+                const float m = fmaxf(z[0], fmaxf(z[1], z[2]));
+                const float e0 = __expf(z[0] - m), e1 = __expf(z[1] - m), e2 = __expf(z[2] - m);
+                prob = e1 / (e0 + e1 + e2);
+            } else {
+                const float* z = a.logits + ((long)(l * a.B + b) * a.Q + q) * a.C;
+                const int cls = (int)a.tlabels[(long)b * a.Tmax + j];
+                float m = -INFINITY;
+                for (int k = 0; k < a.C; ++k) m = fmaxf(m, z[k]);
+                float s = 0.f;
+                for (int k = 0; k < a.C; ++k) s += __expf(z[k] - m);
+                prob = __expf(z[cls] - m) / s;
+            }
+            c = a.w_bbox * l1 + a.w_giou * (gl - 1.f) - a.w_class * prob;
+        }
+        cost[((long)(l * a.B + b) * a.Q + q) * a.Tmax + j] = c;
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one block per decoder layer
+__global__ __launch_bounds__(256) void criterion_loss_kernel(CritArgs a) {
+    extern __shared__ int tq[];          // [B*Q] matched target of (b,q) or -1
+    __shared__ float red[4];
+    const int l = blockIdx.x;
+    const int BQ = a.B * a.Q;
+    for (int i = threadIdx.x; i < BQ; i += 256) tq[i] = -1;
+    __syncthreads();
+    int nb_local = 0;
+    for (int i = threadIdx.x; i < a.B * a.Tmax; i += 256) {
+        const int b = i / a.Tmax, j = i % a.Tmax;
+        if (j < a.tcount[b]) {
+            ++nb_local;
+            const int q = a.match[((long)l * a.B + b) * a.Tmax + j];
+            if (q >= 0 && q < a.Q) tq[b * a.Q + q] = j;
+        }
+    }
+    const float num_boxes = fmaxf(block_sum((float)nb_local, red), 1.f);
+    int nm_local = 0;
+    for (int i = threadIdx.x; i < BQ; i += 256) nm_local += tq[i] >= 0;
+    const float nmatched = block_sum((float)nm_local, red);
+    const long base = (long)l * BQ;
+
+    // ---- actor / no-object classification -------------------------------------------------
+    float ce_b = 0.f, ce = 0.f;
+    if (a.ava) {
+        const float wsum = nmatched + (BQ - nmatched) * a.eos;        // targets: 1 (matched, w 1) / 2 (unmatched, w eos)
+        for (int i = threadIdx.x; i < BQ; i += 256) {
+            const float* z = a.logits_b + (base + i) * 3;
+            const int t = tq[i] >= 0 ? 1 : 2;
+            const float w = t == 2 ? a.eos : 1.f;
+            const float m = fmaxf(z[0], fmaxf(z[1], z[2]));
+            const float e0 = __expf(z[0] - m), e1 = __expf(z[1] - m), e2 = __expf(z[2] - m), s = e0 + e1 + e2;
+            const float p[3] = {e0 / s, e1 / s, e2 / s};
+            ce_b += w * -(z[t] - m - __logf(s));
+            float* g = a.g_logits_b + (base + i) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] = w * (p[k] - (k == t ? 1.f : 0.f)) / wsum;
+        }
+        ce_b = block_sum(ce_b, red) / wsum;
+        // weighted multi-label BCE on logits (== F.binary_cross_entropy(sigmoid(x), t, w), mean over B*Q*C)
+        const float inv = 1.f / ((float)BQ * a.C);
+        for (long i = threadIdx.x; i < (long)BQ * a.C; i += 256) {
+            const int bq = (int)(i / a.C), c = (int)(i % a.C);
+            const int j = tq[bq];
+            const float x = a.logits[(base + bq) * a.C + c];
+            const float t = j >= 0 ? a.tlabels[((long)(bq / a.Q) * a.Tmax + j) * a.C + c] : 0.f;
+            const float w = j >= 0 ? a.pos_weight : 1.f;
+            ce += w * (t * softplus_clamped(-x) + (1.f - t) * softplus_clamped(x));
+            const float sg = 1.f / (1.f + __expf(-x));
+            a.g_logits[(base + bq) * a.C + c] = w * (sg - t) * inv;
+        }
+        ce = block_sum(ce, red) * inv;
+    } else {
+        // (C)-way CE with the last class = no-object weighted eos  (C here already counts the no-object slot)
+        const float wsum = nmatched + (BQ - nmatched) * a.eos;
+        for (int i = threadIdx.x; i < BQ; i += 256) {
+            const float* z = a.logits + (base + i) * a.C;
+            const int j = tq[i];
+            const int t = j >= 0 ? (int)a.tlabels[(long)(i / a.Q) * a.Tmax + j] : a.C - 1;
+            const float w = t == a.C - 1 ? a.eos : 1.f;
+            float m = -INFINITY;
+            for (int k = 0; k < a.C; ++k) m = fmaxf(m, z[k]);
+            float s = 0.f;
+            for (int k = 0; k < a.C; ++k) s += __expf(z[k] - m);
+            ce += w * -(z[t] - m - __logf(s));
+            float* g = a.g_logits + (base + i) * a.C;
+            for (int k = 0; k < a.C; ++k) g[k] = w * (__expf(z[k] - m) / s - (k == t ? 1.f : 0.f)) / wsum;
+        }
+        ce = block_sum(ce, red) / wsum;
+    }
+
+    // ---- boxes ---------------------------------------------------------------------------------
+    float l1 = 0.f, gi = 0.f;
+    for (int i = threadIdx.x; i < BQ; i += 256) {
+        float* gb = a.g_bbox + (base + i) * 4;
+        float* gg = a.g_giou + (base + i) * 4;
+        const int j = tq[i];
+        if (j < 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gb[k] = 0.f; gg[k] = 0.f; }
+            continue;
+        }
+        const float* p = a.boxes + (base + i) * 4;
+        const float* t = a.tboxes + ((long)(i / a.Q) * a.Tmax + j) * 4;
+        float g4[4];
+        gi += giou_loss(p, t, g4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = p[k] - t[k];
+            l1 += fabsf(d);
+            gb[k] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / num_boxes;
+            gg[k] = g4[k] / num_boxes;
+        }
+    }
+    l1 = block_sum(l1, red) / num_boxes;
+    gi = block_sum(gi, red) / num_boxes;
+    if (threadIdx.x == 0) {
+        a.losses[l * 4 + 0] = ce;
+        a.losses[l * 4 + 1] = ce_b;
+        a.losses[l * 4 + 2] = l1;
+        a.losses[l * 4 + 3] = gi;
+    }
+}
+
+extern "C" {
+
+int tuber_criterion_cost(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
+                         const int* tcount, int L, int B, int Q, int C, int Tmax, int ava, float w_class, float w_bbox, float w_giou,
+                         float* cost, hipStream_t stream) {
+    if (L <= 0 || B <= 0 || Q <= 0 || C <= 0 || Tmax <= 0) return TUBER_EINVAL;
+    CritArgs a{};
+    a.logits = logits; a.logits_b = logits_b; a.boxes = boxes; a.tboxes = tboxes; a.tlabels = tlabels; a.tcount = tcount;
+    a.L = L; a.B = B; a.Q = Q; a.C = C; a.Tmax = Tmax; a.ava = ava; a.w_class = w_class; a.w_bbox = w_bbox; a.w_giou = w_giou;
+    hipLaunchKernelGGL(criterion_cost_kernel, dim3(L * B), dim3(256), 0, stream, a, cost);
+    TUBER_RETURN_LAUNCH();
+}
+
+int tuber_criterion_loss(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
+                         const int* tcount, const int* match, int L, int B, int Q, int C, int Tmax, int ava, float eos,
+                         float pos_weight, float* losses, float* g_logits, float* g_logits_b, float* g_bbox, float* g_giou,
+                         hipStream_t stream) {
+    if (L <= 0 || B <= 0 || Q <= 0 || C <= 0 || Tmax <= 0 || (long)B * Q > 12000) return TUBER_EINVAL;
+    CritArgs a{};
+    a.logits = logits; a.logits_b = logits_b; a.boxes = boxes; a.tboxes = tboxes; a.tlabels = tlabels; a.tcount = tcount;
+    a.match = match; a.L = L; a.B = B; a.Q = Q; a.C = C; a.Tmax = Tmax; a.ava = ava; a.eos = eos; a.pos_weight = pos_weight;
+    a.losses = losses; a.g_logits = g_logits; a.g_logits_b = g_logits_b; a.g_bbox = g_bbox; a.g_giou = g_giou;
+    hipLaunchKernelGGL(criterion_loss_kernel, dim3(L), dim3(256), (size_t)B * Q * sizeof(int), stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -218,68 +218,119 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
 }
 
 // weight gradient partials: P[block][tap][C] = sum over the block's output positions of
-// g[o][c] * relu(bn1(x))[in(o,tap)][c].  thread = 2 channels x 1 position slot (8 slots).
+// g[o][c] * relu(bn1(x))[in(o,tap)][c].  Same register tiling as the forward kernel: a thread owns
+// 4 channels x 4 consecutive output columns, so every activated input vector it loads feeds up to
+// 3 taps x 4 outputs; 27 x 4 fp32 accumulators live in registers across the block's segments and
+// are reduced over the 16 position slots (wave shuffles + LDS) once at the end.
+template <int SS>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
     const bf16* __restrict__ gout, const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-    float* __restrict__ P, DwGeom g, long pos_per_block) {
-    __shared__ float red[8][27][64 + 1];
-    const int cl = threadIdx.x & 31, ps = threadIdx.x >> 5;
-    const int c0 = blockIdx.y * 64, c = c0 + cl * 2;
-    const float a0 = sc[c], a1 = sc[c + 1], b0 = sh[c], b1 = sh[c + 1];
-    float acc[27][2];
+    float* __restrict__ P, DwGeom g, int iters) {
+    constexpr int NIN = 3 * SS + 3;
+    __shared__ float red[4][27][64];
+    const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
+    float a4[4], b4[4];
+    {
+        const float4 s = *(const float4*)(sc + c), h = *(const float4*)(sh + c);
+        a4[0] = s.x; a4[1] = s.y; a4[2] = s.z; a4[3] = s.w; b4[0] = h.x; b4[1] = h.y; b4[2] = h.z; b4[3] = h.w;
+    }
+    float acc[27][4];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
-    const long total = (long)g.N * g.To * g.Ho * g.Wo;
-    const long p0 = (long)blockIdx.x * pos_per_block, p1 = min(total, p0 + pos_per_block);
-    for (long o = p0 + ps; o < p1; o += 8) {
-        int wo = (int)(o % g.Wo); long r = o / g.Wo;
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    const int Wg = (g.Wo + 3) >> 2;
+    const long segs = (long)g.N * g.To * g.Ho * Wg;
+    for (int it = 0; it < iters; ++it) {
+        const long seg = ((long)blockIdx.x * iters + it) * 16 + ps;
+        if (seg >= segs) break;
+        int wg = (int)(seg % Wg); long r = seg / Wg;
         const int ho = (int)(r % g.Ho); r /= g.Ho;
         const int to = (int)(r % g.To); const int n = (int)(r / g.To);
-        const bf16x2 gv = *(const bf16x2*)(gout + o * g.C + c);
-        const float g0 = bf2f(gv[0]), g1 = bf2f(gv[1]);
+        const int wo0 = wg * 4;
+        float gv[4][4];
+        const bf16* grow = gout + ((((long)n * g.To + to) * g.Ho + ho) * (long)g.Wo + wo0) * g.C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (wo0 + j < g.Wo) {
+                const bf16x4 v = as_bf16x4(*(const uint2*)(grow + (long)j * g.C));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[j][e] = bf2f(v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[j][e] = 0.f;
+            }
+        }
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) {
             const int ti = to * g.st + dt - 1;
             if (ti < 0 || ti >= g.Ti) continue;
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh) {
-                const int hi = ho * g.ss + dh - 1;
+                const int hi = ho * SS + dh - 1;
                 if (hi < 0 || hi >= g.Hi) continue;
                 const bf16* row = x + (((long)n * g.Ti + ti) * g.Hi + hi) * (long)g.Wi * g.C + c;
+                float in[NIN][4];
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) {
+                    const int wi = wo0 * SS - 1 + i;
+                    if (wi >= 0 && wi < g.Wi) {
+                        const bf16x4 v = as_bf16x4(*(const uint2*)(row + (long)wi * g.C));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) in[i][e] = fmaxf(fmaf(bf2f(v[e]), a4[e], b4[e]), 0.f);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) in[i][e] = 0.f;
+                    }
+                }
 #pragma unroll
                 for (int dw = 0; dw < 3; ++dw) {
-                    const int wi = wo * g.ss + dw - 1;
-                    if (wi < 0 || wi >= g.Wi) continue;
-                    const bf16x2 xv = *(const bf16x2*)(row + (long)wi * g.C);
-                    const float x0 = fmaxf(fmaf(bf2f(xv[0]), a0, b0), 0.f), x1 = fmaxf(fmaf(bf2f(xv[1]), a1, b1), 0.f);
                     const int tap = (dt * 3 + dh) * 3 + dw;
-                    acc[tap][0] = fmaf(g0, x0, acc[tap][0]);
-                    acc[tap][1] = fmaf(g1, x1, acc[tap][1]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tap][e] = fmaf(gv[j][e], in[j * SS + dw][e], acc[tap][e]);
                 }
             }
         }
     }
+    // reduce over the 16 position slots: lanes (ps & 3) within a wave by shuffles (lane = (ps&3)*16 + cl), waves via LDS
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < 27; ++t) { red[ps][t][cl * 2] = acc[t][0]; red[ps][t][cl * 2 + 1] = acc[t][1]; }
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[t][e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if ((threadIdx.x & 63) < 16) red[wave][t][cl * 4 + e] = v;
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * 64; i += 256) {
         const int tap = i >> 6, cc = i & 63;
-        float a = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) a += red[s][tap][cc];
-        if (c0 + cc < g.C) P[((long)blockIdx.x * 27 + tap) * g.C + c0 + cc] = a;
+        if (c0 + cc < g.C)
+            P[((long)blockIdx.x * 27 + tap) * g.C + c0 + cc] = red[0][tap][cc] + red[1][tap][cc] + red[2][tap][cc] + red[3][tap][cc];
     }
 }
 
-// out[c][tap] (+)= sum_r P[r][tap][c]
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, int R, int C, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over tap*C + c
-    if (i >= 27 * C) return;
-    const int tap = i / C, c = i % C;
+// out[c][tap] (+)= sum_r P[r][tap][c]: 32 row-groups x 32 (tap,c) columns per block
+__global__ __launch_bounds__(1024) void dw_wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, int R, int C, int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;            // over tap*C + c
+    const int n = 27 * C;
     float a = 0.f;
-    for (int r = 0; r < R; ++r) a += P[(long)r * 27 * C + i];
-    float* o = out + (long)c * 27 + tap;
-    *o = accumulate ? *o + a : a;
+    if (i < n) for (int r = rg; r < R; r += 32) a += P[(long)r * n + i];
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && i < n) {
+        a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a += red[k][cl];
+        float* o = out + (long)(i % C) * 27 + i / C;
+        *o = accumulate ? *o + a : a;
+    }
 }
 
 static int dw_blocks(long segs, int* iters) {
@@ -304,10 +355,8 @@ int tuber_dwconv_bwd_data_stat_rows(int N, int Ti, int Hi, int Wi) {
     return dw_blocks((long)N * Ti * Hi * ((Wi + 3) / 4), &it);
 }
 int tuber_dwconv_bwd_weight_blocks(int N, int To, int Ho, int Wo) {
-    const long total = (long)N * To * Ho * Wo;
-    long nb = (total + 1023) / 1024;
-    if (nb > 512) nb = 512;
-    return (int)nb;
+    int it;
+    return dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &it);
 }
 
 int tuber_dwconv_fwd(const void* x, const float* sc, const float* sh, const float* w, void* out, float* st0, float* st1,
@@ -341,12 +390,12 @@ int tuber_dwconv_bwd_weight(const void* gout, const void* x, const float* sc, co
                             hipStream_t stream) {
     if (!dw_ok(C, st, ss)) return TUBER_EINVAL;
     DwGeom g{N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss};
-    const int nb = tuber_dwconv_bwd_weight_blocks(N, To, Ho, Wo);
-    const long total = (long)N * To * Ho * Wo;
-    const long ppb = (total + nb - 1) / nb;
-    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(nb, C / 64), dim3(256), 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh,
-                       partial, g, ppb);
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div(27 * C, 256)), dim3(256), 0, stream, partial, dw, nb, C, accumulate);
+    int iters;
+    const int nb = dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &iters);
+    dim3 grid(nb, C / 64), block(256);
+    if (ss == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);
+    else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div(27 * C, 32)), dim3(1024), 0, stream, partial, dw, nb, C, accumulate);
     TUBER_RETURN_LAUNCH();
 }
 

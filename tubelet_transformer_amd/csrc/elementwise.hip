@@ -67,7 +67,9 @@ __global__ void axpby_kernel(const bf16* __restrict__ a, const bf16* __restrict_
 }
 
 // in-place (or out-of-place) dropout with the stateless hash RNG: y = keep ? x/(1-p) : 0
-__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long n8, uint32_t thresh, float inv_keep, uint64_t seed) {
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long n8, uint32_t thresh, float inv_keep,
+                               const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
+    const uint64_t seed = (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const bf16x8 v = as_bf16x8(((const uint4*)x)[i]);
         bf16x8 o;
@@ -204,10 +206,10 @@ int tuber_axpby(const void* a, const void* b, void* out, long n, float alpha, fl
     hipLaunchKernelGGL(axpby_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)out, n / 8, alpha, beta);
     TUBER_RETURN_LAUNCH();
 }
-int tuber_dropout(const void* x, void* y, long n, float p, unsigned long long seed, hipStream_t stream) {
+int tuber_dropout(const void* x, void* y, long n, float p, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
     if ((n & 7) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), (uint64_t)seed);
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), (const uint64_t*)seed_ptr, (uint64_t)salt);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_sigmoid_fwd(const float* x, float* y, long n, hipStream_t stream) {

@@ -299,6 +299,9 @@ extern "C" {
 
 // number of partial-statistics rows gemm_nt writes for (M, N): the caller sizes stat0/stat1 as
 // [rows][N] floats and hands the same row count to the finalize kernels.
+// tile configuration tuber_gemm_nt picks for (M, N): 0 = 128x128, 1 = 128x64, 2 = 64x64 (profiling / tests)
+int tuber_gemm_nt_cfg(int M, int N) { return nt_pick_cfg(M, N); }
+
 int tuber_gemm_nt_stat_rows(int M, int N) {
     int bm, wm;
     nt_cfg_dims(nt_pick_cfg(M, N), &bm, &wm);
@@ -522,13 +525,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
-// out[j] (+)= sum_s P[s][j]
-__global__ void reduce_slabs_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[j] (+)= sum_s P[s][j]: 32 slab-groups x 32 columns per block, LDS tree over the slab groups
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long j = (long)blockIdx.x * 32 + cl;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += P[(long)s * n + i];
-    out[i] = accumulate ? out[i] + a : a;
+    if (j < n) for (int s = rg; s < S; s += 32) a += P[(long)s * n + j];
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+        a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a += red[i][cl];
+        out[j] = accumulate ? out[j] + a : a;
+    }
 }
 
 extern "C" {
@@ -564,7 +575,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn_kernel<A_BN_RELU>, grid, block, lds, stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<A_PLAIN>, grid, block, lds, stream, p);
     const long n = (long)N * K;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 32)), dim3(1024), 0, stream, partial, out, n, p.S, accumulate);
     TUBER_RETURN_LAUNCH();
 }
 

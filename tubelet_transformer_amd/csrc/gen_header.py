@@ -20,6 +20,7 @@ DOC = {
                      "(n,t*st,h*ss,w*ss) map of the down_sample conv (:155-161). epi 0: +bias, +R, ReLU, bf16|fp32 out; "
                      "epi 1: bf16 out + per-column partial (sum, sum^2) rows for training-mode BatchNorm; epi 2: out = acc*[Cm*m_scale+m_shift>0] "
                      "+ partial (sum dz, sum dz*Cm) rows for BatchNorm backward. K % 64 == 0.",
+    "tuber_gemm_nt_cfg": "tile configuration tuber_gemm_nt uses for (M,N): 0 = 128x128, 1 = 128x64, 2 = 64x64.",
     "tuber_gemm_nt_stat_rows": "rows of partial statistics tuber_gemm_nt(epi 1|2) writes for (M,N).",
     "tuber_gemm_tn": "dW[N,K] (+)= sum_m G[m,N]^T . f(A)[m,K]: weight gradient of the same convs / linears (autograd of the ops above); "
                      "split over M into fp32 slabs `partial` [tuber_gemm_tn_slabs][N][K], then reduced deterministically.",
@@ -45,6 +46,7 @@ DOC = {
     "tuber_layernorm_bwd": "LayerNorm backward: dx (= gradient of both x and res) and dgamma/dbeta via block partials.",
     "tuber_layernorm_bwd_blocks": "blocks used by tuber_layernorm_bwd (partial = 2*blocks*E floats).",
     "tuber_reduce_rows": "out[c] (+)= sum_r P[r][c].",
+    "tuber_colsum_blocks": "row blocks (size of `partial` / C) used by tuber_colsum.",
     "tuber_colsum": "bias gradient: out[c] (+)= sum_m g[m][c] for bf16 g.",
     "tuber_stem_im2col": "patch matrix [N*T*Ho*Wo, 448] bf16 of the stem Conv3d(3,64,(3,7,7),s=(1,2,2),p=(1,3,3)) (ir_CSN_152.py:109-115) from the fp32 NCDHW clip.",
     "tuber_stem_pool_fwd": "relu(bn1(.)) + MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1)) (ir_CSN_152.py:119-122) on NDHWC bf16, C=64; saves the argmax tap.",
@@ -59,6 +61,15 @@ DOC = {
     "tuber_attn_wide_bwd": "gradients dq [NQ,2048] and dkv [rows,4096] of tuber_attn_wide_fwd.",
     "tuber_lsap": "rectangular linear sum assignment on HOST doubles; restates scipy.optimize.linear_sum_assignment (call sites "
                   "models/detr/matcher.py:80, matcher_ucf.py:82) incl. its tie-breaking.",
+    "tuber_grad_norm_clip_coef": "global L2 norm of the flat gradient buffer and the clip coefficient min(1, max_norm/(norm+1e-6)), left on the device: "
+                                 "torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1) (utils/video_action_recognition.py:153).",
+    "tuber_adamw_segment": "AdamW update (torch.optim.AdamW semantics: decoupled decay, bias correction) of one contiguous flat segment with the "
+                           "clip coefficient applied to the gradient on the fly (video_action_recognition.py:154; groups train_tuber_ava.py:41-58).",
+    "tuber_scale_f32": "x *= coef: gradient averaging after the RCCL all-reduce (DistributedDataParallel's mean, utils/model_utils.py:47-49).",
+    "tuber_criterion_cost": "Hungarian matching cost C = w_bbox*L1 - w_giou*GIoU - w_class*p of every decoder layer at once, [L,B,Q,Tmax] fp32 "
+                            "(HungarianMatcher.forward, models/detr/matcher.py:61-76 / matcher_ucf.py:61-78; generalized_box_iou utils/box_ops.py:41-65).",
+    "tuber_criterion_loss": "all loss terms of all layers and their gradients w.r.t. logits / actor logits / boxes in one launch: AVA 3-way weighted CE + "
+                            "weighted BCE (models/criterion.py:42-81), JHMDB (C+1)-way CE (:237-262), L1 + GIoU box losses (:97-117).",
     "tuber_cast_f32_bf16": "fp32 -> bf16 copy (bf16 shadow of the fp32 master weights).",
     "tuber_cast_bf16_f32": "bf16 -> fp32 copy.",
     "tuber_cast_transpose": "W[R][C] fp32 -> W^T[C][ldt] bf16 (B operand of the data-gradient GEMM).",

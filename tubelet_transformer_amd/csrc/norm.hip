@@ -356,13 +356,35 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
     }
 }
 
-// partial column sums of a bf16 [M, C] matrix (bias gradient): blocks write [gridDim.x][C]
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ P, long M, int C, long rows_per_block) {
+// partial column sums of a bf16 [M, ld] matrix (bias gradient): block (bx, by) sums rows
+// [bx*rpb, (bx+1)*rpb) of the 8-column groups by*256 .. ; writes P[bx][C].  16-byte loads, thread = 8 columns.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ P, long M, int C, long ld,
+                                                             long rows_per_block) {
+    __shared__ float red[256][8 + 1];
+    const int groups = (C + 7) >> 3;                     // 8-column groups in a row
+    const int tpr = groups < 256 ? groups : 256;         // threads per row in this block
+    const int rpp = 256 / tpr;                           // rows per pass
+    const int cg = blockIdx.y * 256 + threadIdx.x % tpr;
+    const int rs = threadIdx.x / tpr;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f;
-        for (long r = r0; r < r1; ++r) a += bf2f(g[r * C + c]);
-        P[(long)blockIdx.x * C + c] = a;
+    if (cg < groups && rs < rpp) {
+        for (long r = r0 + rs; r < r1; r += rpp) {
+            const bf16x8 v = as_bf16x8(*(const uint4*)(g + r * ld + cg * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < tpr && cg < groups) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+            for (int s = 0; s < rpp; ++s) a += red[s * tpr + threadIdx.x][e];
+            if (cg * 8 + e < C) P[(long)blockIdx.x * C + cg * 8 + e] = a;
+        }
     }
 }
 
@@ -410,23 +432,29 @@ int tuber_block_out_fwd(const void* c4, const float* s4, const float* h4, const 
     TUBER_RETURN_LAUNCH();
 }
 
-// rows of partial stats written by the *_bwd / reduce kernels for M rows
-int tuber_rowblock_count(long M) { return ceil_div(M, 512) > 1024 ? 1024 : ceil_div(M, 512); }
-static inline long rows_per_block(long M) { const int nb = tuber_rowblock_count(M); return (M + nb - 1) / nb; }
+// rows of partial stats written by the row-blocked reduce kernels for an [M, C] tensor: ~16K elements per block
+// (8 passes of 256 threads x 8 channels), at most 1024 blocks
+int tuber_rowblock_count(long M, int C) {
+    long nb = (M * (long)C + 16383) / 16384;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+static inline long rows_per_block(long M, int C) { const int nb = tuber_rowblock_count(M, C); return (M + nb - 1) / nb; }
 
 int tuber_block_out_bwd(const void* dy, const void* y, const void* c4, const void* cds, void* dz, float* st_dz, float* st_c4,
                         float* st_ds, long M, int C, hipStream_t stream) {
     if (!chan_ok(C)) return TUBER_EINVAL;
-    hipLaunchKernelGGL(block_out_bwd_kernel, dim3(tuber_rowblock_count(M)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y,
-                       (const bf16*)c4, (const bf16*)cds, (bf16*)dz, st_dz, st_c4, st_ds, M, C, rows_per_block(M));
+    hipLaunchKernelGGL(block_out_bwd_kernel, dim3(tuber_rowblock_count(M, C)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y,
+                       (const bf16*)c4, (const bf16*)cds, (bf16*)dz, st_dz, st_c4, st_ds, M, C, rows_per_block(M, C));
     TUBER_RETURN_LAUNCH();
 }
 
 int tuber_relu_bn_bwd_reduce(const void* g, const void* x, const float* sc, const float* sh, void* dz, float* st0, float* st1,
                              long M, int C, hipStream_t stream) {
     if (!chan_ok(C)) return TUBER_EINVAL;
-    hipLaunchKernelGGL(relu_bn_bwd_reduce_kernel, dim3(tuber_rowblock_count(M)), dim3(256), 0, stream, (const bf16*)g,
-                       (const bf16*)x, sc, sh, (bf16*)dz, st0, st1, M, C, rows_per_block(M));
+    hipLaunchKernelGGL(relu_bn_bwd_reduce_kernel, dim3(tuber_rowblock_count(M, C)), dim3(256), 0, stream, (const bf16*)g,
+                       (const bf16*)x, sc, sh, (bf16*)dz, st0, st1, M, C, rows_per_block(M, C));
     TUBER_RETURN_LAUNCH();
 }
 
@@ -471,10 +499,16 @@ int tuber_reduce_rows(const float* P, float* out, int R, int C, int accumulate, 
     TUBER_RETURN_LAUNCH();
 }
 
-// dbias[c] (+)= sum_m g[m][c];  partial must hold tuber_rowblock_count(M) * C floats
-int tuber_colsum(const void* g, float* partial, float* out, int accumulate, long M, int C, hipStream_t stream) {
-    const int nb = tuber_rowblock_count(M);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)g, partial, M, C, rows_per_block(M));
+// dbias[c] (+)= sum_m g[m][c] for bf16 g [M, ld] (ld % 8 == 0, readable up to ceil8(C) columns);
+// partial must hold tuber_colsum_blocks(M) * C floats
+int tuber_colsum_blocks(long M) { long nb = (M + 63) / 64; return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb)); }
+
+int tuber_colsum(const void* g, float* partial, float* out, int accumulate, long M, int C, long ld, hipStream_t stream) {
+    if (M <= 0 || C <= 0 || (ld & 7) || ld < ((C + 7) & ~7)) return TUBER_EINVAL;
+    const int nb = tuber_colsum_blocks(M);
+    const long rpb = (M + nb - 1) / nb;
+    const int groups = (C + 7) / 8;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (groups + 255) / 256), dim3(256), 0, stream, (const bf16*)g, partial, M, C, ld, rpb);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, partial, out, nb, C, accumulate);
     TUBER_RETURN_LAUNCH();
 }

@@ -74,6 +74,8 @@ class ParamStore:
         self.ttable = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
         self.nmat = len(entries)
         self.step_seed = 0
+        # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
+        self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     @staticmethod
     def _is_gemm_weight(name, p):
@@ -100,6 +102,15 @@ class ParamStore:
     def zero_grad(self):
         self.gflat.zero_()
         self.ensure_grad_views()
+
+    def begin_step(self, train):
+        """new forward: call-site salts restart at 0; in training the device seed advances (captured in graphs)."""
+        self.step_seed = 0
+        if train:
+            self.seed.add_(1)
+
+    def manual_seed(self, seed):
+        self.seed.fill_(int(seed))
 
     # -- per-step refresh --------------------------------------------------------------------
     def refresh(self):

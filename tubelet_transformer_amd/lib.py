@@ -76,8 +76,23 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_hook = None
+
+
+def set_launch_hook(fn):
+    """Install ``fn(name, args, launch)`` around every kernel launch (bench.py's HIP-event timing); None removes it."""
+    global _hook
+    _hook = fn
+
+
 def call(name, *args):
     """Launch `name` on torch's current HIP stream (appended automatically when the prototype ends with it)."""
+    if _hook is not None:
+        return _hook(name, args, _call)
+    return _call(name, *args)
+
+
+def _call(name, *args):
     lib = load()
     sig = _sigs[name]
     if len(args) == len(sig) - 1 and sig and sig[-1][0] == "hipStream_t":

@@ -75,13 +75,8 @@ class LinearFn(torch.autograd.Function):
         lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         if bname:
             gbias = store.gflat.data_ptr() + 4 * (store.offsets[bname] + r0)
-            R = lib.query("tuber_rowblock_count", M)
-            if ldg == N:
-                lib.call("tuber_colsum", gb, workspace(dev, "cs", R * N), gbias, 1, M, N)
-            else:  # padded gradient: reduce all Np columns into scratch, add the first N
-                tmp = torch.zeros(Np, dtype=torch.float32, device=dev)
-                lib.call("tuber_colsum", gb, workspace(dev, "cs", R * Np), tmp, 0, M, Np)
-                store.gflat[store.offsets[bname] + r0: store.offsets[bname] + r1] += tmp[:N]
+            R = lib.query("tuber_colsum_blocks", M)
+            lib.call("tuber_colsum", gb, workspace(dev, "cs", R * N), gbias, 1, M, N, ldg)
         dx = None
         if ctx.needs_input_grad[0]:
             toff, NN, KK, ldt = store.tinfo[wname]
@@ -163,9 +158,9 @@ class AttentionFn(torch.autograd.Function):
         mo = _map(E, *qmap)
         scale = 32 ** -0.5
         lib.call("tuber_attn_fwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
-                 tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(pdrop), int(seed))
+                 tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(pdrop), store.seed, int(seed))
         ctx.meta = (roles, geom, pdrop, seed, scale)
-        ctx.kpm = kpm
+        ctx.kpm, ctx.seed_t = kpm, store.seed
         ctx.save_for_backward(o, lse, *tensors)
         return o
 
@@ -192,7 +187,7 @@ class AttentionFn(torch.autograd.Function):
         lib.call("tuber_attn_bwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
                  tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, ctx.kpm, g, mo.ctypes.data,
                  grads[qi].data_ptr() + 2 * qo, mq.ctypes.data, grads[ki].data_ptr() + 2 * ko, mk.ctypes.data,
-                 grads[vi].data_ptr() + 2 * vo, mv.ctypes.data, delta, B, H, Lq, Lk, scale, float(pdrop), int(seed))
+                 grads[vi].data_ptr() + 2 * vo, mv.ctypes.data, delta, B, H, Lq, Lk, scale, float(pdrop), ctx.seed_t, int(seed))
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -246,25 +241,25 @@ def gather_sum(x, fwd, bwd):
 
 class DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed_t, salt):
         y = torch.empty_like(x)
-        lib.call("tuber_dropout", x, y, x.numel(), float(p), int(seed))
-        ctx.p, ctx.seed = p, seed
+        lib.call("tuber_dropout", x, y, x.numel(), float(p), seed_t, int(salt))
+        ctx.p, ctx.seed_t, ctx.salt = p, seed_t, salt
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         dx = torch.empty_like(g)
-        lib.call("tuber_dropout", g, dx, g.numel(), float(ctx.p), int(ctx.seed))
-        return dx, None, None
+        lib.call("tuber_dropout", g, dx, g.numel(), float(ctx.p), ctx.seed_t, int(ctx.salt))
+        return dx, None, None, None
 
 
 def dropout(x, p, training, store):
     if not training or p <= 0.0:
         return x
     store.step_seed += 1
-    return DropoutFn.apply(x, p, store.step_seed * 2654435761 % (1 << 62))
+    return DropoutFn.apply(x, p, store.seed, store.step_seed)
 
 
 class SigmoidFn(torch.autograd.Function):
@@ -306,8 +301,8 @@ class ParamRowsFn(torch.autograd.Function):
         name, B, Q, E = ctx.meta
         g = g.contiguous()
         gp = store.gflat.data_ptr() + 4 * store.offsets[name]
-        R = lib.query("tuber_rowblock_count", B)
-        lib.call("tuber_colsum", g, workspace(g.device, "cs", R * Q * E), gp, 1, B, Q * E)
+        R = lib.query("tuber_colsum_blocks", B)
+        lib.call("tuber_colsum", g, workspace(g.device, "cs", R * Q * E), gp, 1, B, Q * E, Q * E)
         return None, None, None, None
 
 
@@ -336,22 +331,23 @@ class AttentionWideFn(torch.autograd.Function):
     """LSTR pooling attention: one query per pixel, 8 heads of 256 (q [NQ,2048]; kv [rows,4096] = [k|v])."""
 
     @staticmethod
-    def forward(ctx, q, kv, HW, T, pdrop, seed):
+    def forward(ctx, q, kv, HW, T, pdrop, seed_t, salt):
         NQ = q.shape[0]
         o = torch.empty(NQ, 2048, dtype=BF, device=q.device)
-        lib.call("tuber_attn_wide_fwd", q, kv, o, NQ, HW, T, float(pdrop), int(seed))
-        ctx.meta = (NQ, HW, T, pdrop, seed)
+        lib.call("tuber_attn_wide_fwd", q, kv, o, NQ, HW, T, float(pdrop), seed_t, int(salt))
+        ctx.meta = (NQ, HW, T, pdrop, salt)
+        ctx.seed_t = seed_t
         ctx.save_for_backward(q, kv)
         return o
 
     @staticmethod
     def backward(ctx, g):
-        NQ, HW, T, pdrop, seed = ctx.meta
+        NQ, HW, T, pdrop, salt = ctx.meta
         q, kv = ctx.saved_tensors
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        lib.call("tuber_attn_wide_bwd", q, kv, g.contiguous(), dq, dkv, NQ, HW, T, float(pdrop), int(seed))
-        return dq, dkv, None, None, None, None
+        lib.call("tuber_attn_wide_bwd", q, kv, g.contiguous(), dq, dkv, NQ, HW, T, float(pdrop), ctx.seed_t, int(salt))
+        return dq, dkv, None, None, None, None, None
 
 
-def attention_wide(q, kv, HW, T, pdrop, seed):
-    return AttentionWideFn.apply(q, kv, HW, T, pdrop, seed)
+def attention_wide(store, q, kv, HW, T, pdrop, salt):
+    return AttentionWideFn.apply(q, kv, HW, T, pdrop, store.seed, salt)

@@ -1,0 +1,150 @@
+"""One optimisation step of TubeR on the MI355X path -- the body of the reference's hot loop
+(``train_tuber_detection``, utils/video_action_recognition.py:96-157) without its per-step host syncs:
+
+    outputs = model(samples) ; loss_dict = criterion(outputs, targets) ; losses = sum_k w_k * loss_k
+    optimizer.zero_grad() ; losses.backward() ; clip_grad_norm_(0.1) ; optimizer.step()
+
+The reference additionally copies ``pred_logits`` to the host every step as a NaN probe (:140) and calls ``.item()`` five
+times on rank 0 (:182-193); here the only device->host transfer of a step is the single matcher cost copy, and logging
+reads the (still on-device) loss tensors only when asked to.
+"""
+import torch
+
+from .ddp import FlatGradReducer, broadcast_parameters
+from .optim import FusedClipAdamW, build_param_groups
+
+
+def deploy_model(model, cfg, device=None):
+    """Counterpart of utils/model_utils.py:39-58 for the flat-gradient data-parallel path: moves the model to this rank's
+    GPU, broadcasts rank 0's parameters and attaches the gradient reducer.  Returns the (unwrapped) model."""
+    import torch.distributed as dist
+    dev = torch.device(device if device is not None else "cuda:%d" % cfg.DDP_CONFIG.GPU)
+    model.to(dev)
+    store, _ = model.engine()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        broadcast_parameters(store)
+        store.reducer = FlatGradReducer(store)
+    return model
+
+
+def build_optimizer(model, cfg):
+    T = cfg.CONFIG.TRAIN
+    return FusedClipAdamW(build_param_groups(model, cfg), lr=T.LR, weight_decay=T.W_DECAY, model=model)
+
+
+def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0, cfg=None):
+    """Returns (total loss tensor, loss dict) -- all on the device, nothing synchronised."""
+    store, _ = model.engine()
+    reducer = getattr(store, "reducer", None)
+    outputs = model(samples)
+    loss_dict = criterion(outputs, targets)
+    weight_dict = criterion.weight_dict
+    if cfg is not None and epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:          # video_action_recognition.py:145-146
+        weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
+    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)
+    optimizer.zero_grad()
+    if reducer is not None:
+        reducer.begin()
+    losses.backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step(max_norm=max_norm if max_norm and max_norm > 0 else None)
+    return losses.detach(), loss_dict
+
+
+class GraphedTrainStep:
+    """The same optimisation step replayed from two captured hipGraphs (HIP graphs instead of a tracing compiler):
+
+        graph A : bf16 weight refresh, forward of the whole model, matching-cost kernel
+        host    : ONE device->host copy of the [L,B,Q,Tmax] cost tensor, tuber_lsap, assignment back to a static buffer
+        graph B : fused criterion (losses + output gradients), backward of the whole model, global-norm clip + AdamW
+                  (with >1 rank: B is split around an eager RCCL all-reduce of the flat gradient buffer)
+
+    ~4000 kernel launches per step are issued by the GPU front-end instead of Python, so the step is GPU-bound.
+    Inputs are copied into static device buffers; targets use the padded [B, Tmax] layout, so clips with a different number
+    of boxes replay the same graphs (shape changes of the clip batch re-capture).  Dropout masks differ every replay (the seed
+    lives in device memory), AdamW reads its step count from device memory.
+    """
+
+    def __init__(self, model, criterion, optimizer, max_norm, tmax=16):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.max_norm, self.tmax = max_norm, tmax
+        self.graphs = {}
+
+    def _capture(self, clips, targets):
+        from .criterion import PaddedTargets
+        from .misc import NestedTensor
+        model, crit, opt = self.model, self.criterion, self.optimizer
+        store, _ = model.engine()
+        dev = store.device
+        world = getattr(getattr(store, "reducer", None), "world", 1)
+        g = type("Captured", (), {})()
+        g.clips = clips.clone()
+        g.mask = torch.zeros(clips.shape[0], clips.shape[-2], clips.shape[-1], dtype=torch.bool, device=dev)
+        g.pt = PaddedTargets(targets, crit.ava, crit.num_classes if crit.ava else crit.num_classes + 1, dev, tmax=self.tmax)
+        g.targets = targets
+        # eager warm-up: sizes every persistent workspace before capture
+        for _ in range(2):
+            train_step(model, crit, opt, NestedTensor(g.clips, g.mask), targets, self.max_norm)
+        torch.cuda.synchronize()
+        g.A = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g.A):
+            outputs = model(NestedTensor(g.clips, g.mask))
+            logits, logits_b, boxes = crit.stacked(outputs)
+            g.logits_s, g.boxes_s = crit.select(logits, boxes, targets)
+            g.logits_b = logits_b
+            with torch.no_grad():
+                g.cost = crit.matcher.cost(g.logits_s.detach().contiguous(),
+                                           (logits_b if crit.ava else g.logits_s).detach().contiguous(),
+                                           g.boxes_s.detach().contiguous(), g.pt)
+        L, B = g.cost.shape[:2]
+        g.match = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32, device=dev)
+        g.match_host = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32).pin_memory()
+        g.cost_host = torch.empty(g.cost.shape, dtype=torch.float32).pin_memory()
+        g.B1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g.B1, pool=g.A.pool()):
+            g.loss_dict = crit.losses_from_match(g.logits_s, g.logits_b, g.boxes_s, g.pt, g.match, targets)
+            g.loss_dict["class_error"] = crit.class_error(g.logits_s[-1], g.pt, g.match[-1])
+            wd = crit.weight_dict
+            g.loss = sum(g.loss_dict[k] * wd[k] for k in g.loss_dict if k in wd)
+            opt.zero_grad()
+            g.loss.backward()
+            if world == 1:
+                opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
+        g.B2 = None
+        if world > 1:
+            g.B2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.B2, pool=g.A.pool()):
+                opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
+        return g
+
+    def __call__(self, clips, targets):
+        key = tuple(clips.shape)
+        g = self.graphs.get(key)
+        if g is None:
+            g = self.graphs[key] = self._capture(clips, targets)
+        store, _ = self.model.engine()
+        g.clips.copy_(clips, non_blocking=True)
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        if targets is not g.targets:
+            g.pt.sizes = sizes
+            g.pt.tboxes.zero_()
+            g.pt.tlabels.zero_()
+            g.pt.tcount.copy_(torch.tensor(sizes, dtype=torch.int32), non_blocking=True)
+            g.pt.fill(targets)
+        g.A.replay()
+        g.cost_host.copy_(g.cost, non_blocking=True)
+        torch.cuda.current_stream().synchronize()                 # the step's one host sync: the assignment needs the costs
+        match, indices = self.criterion.matcher.solve(g.cost_host.numpy(), sizes)
+        g.match_host.copy_(torch.from_numpy(match))
+        g.match.copy_(g.match_host, non_blocking=True)
+        L = len(indices)
+        self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
+        g.B1.replay()
+        if g.B2 is not None:
+            import torch.distributed as dist
+            dist.all_reduce(store.gflat, op=dist.ReduceOp.SUM)
+            from . import lib
+            lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
+            g.B2.replay()
+        return g.loss, g.loss_dict

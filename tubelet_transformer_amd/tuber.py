@@ -236,6 +236,7 @@ class DETR(nn.Module):
         clips = samples.tensors.to(dev, torch.float32).contiguous()
         mask = samples.mask.to(dev)
         st.refresh()
+        st.begin_step(train)
         anchor = self._anchor
         E, H = self.hidden_dim, 8
         enc0 = self.transformer.encoder.layers[0]
@@ -339,6 +340,7 @@ class DETR(nn.Module):
         logits = ops.linear(q_class, st, "class_fc.weight", "class_fc.bias", out_f32=True).view(lay_n, B, Q, -1)
 
         out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_logits_b": logits_b[-1]}
+        out["_stacked"] = (logits, logits_b, boxes)      # all decoder layers, contiguous: what the fused criterion consumes
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a_, "pred_boxes": b_, "pred_logits_b": c_}
                                   for a_, b_, c_ in zip(logits[:-1], boxes[:-1], logits_b[:-1])]
@@ -358,14 +360,14 @@ class DETR(nn.Module):
         q = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(0, E))
         kv = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(E, 3 * E))
         st.step_seed += 1
-        a = ops.attention_wide(q, kv, hw, 1, p, st.step_seed)                       # one key: softmax = 1 (dropout still applies)
+        a = ops.attention_wide(st, q, kv, hw, 1, p, st.step_seed)                       # one key: softmax = 1 (dropout still applies)
         a = ops.linear(a, st, S + ".out_proj.weight", S + ".out_proj.bias")
         tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm1")
         Cx = P + ".multihead_attn"
         q = ops.linear(tgt, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(0, E))
         kv = ops.linear(feat, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(E, 3 * E))
         st.step_seed += 1
-        a = ops.attention_wide(q, kv, hw, Tp, p, st.step_seed)
+        a = ops.attention_wide(st, q, kv, hw, Tp, p, st.step_seed)
         a = ops.linear(a, st, Cx + ".out_proj.weight", Cx + ".out_proj.bias")
         tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm2")
         tgt = ops.layer_norm(self._ffn(st, tgt, P, pr, train), tgt, st, P + ".norm3")
