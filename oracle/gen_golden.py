@@ -258,3 +258,15 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def state_dict_golden():
+    """tests/golden/reference_state_dicts.json: key names + shapes of the reference's model / criterion state_dict and its
+    weight_dict for every published config (the checkpoint-compatibility contract)."""
+    out = {}
+    for y in ["TubeR_CSN152_AVA21", "TubeR_CSN50_AVA21", "Tuber_CSN152_JHMDB", "TubeR_CSN152_AVA22"]:
+        rm, rc, _ = ref_import.build_reference(ref_import.ref_cfg(y + ".yaml"))
+        out[y] = {"model": [[k, list(v.shape)] for k, v in rm.state_dict().items()],
+                  "criterion": [[k, list(v.shape)] for k, v in rc.state_dict().items()],
+                  "weight_dict": {k: float(v) for k, v in rc.weight_dict.items()}}
+    json.dump(out, open(os.path.join(GOLD, "reference_state_dicts.json"), "w"))

@@ -1,0 +1,238 @@
+"""CPU-only suite (runs in the build container and on any box): the oracle against the committed golden vectors,
+the host logic (config, containers, assignment solver, gradient reducer), and the C-ABI library's exports.
+No HIP compute is launched here."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from oracle import tuber_oracle as O                                  # noqa: E402
+from tubelet_transformer_amd import lib, synth                        # noqa: E402
+from tubelet_transformer_amd.config import get_cfg_defaults, load_cfg  # noqa: E402
+from tubelet_transformer_amd.misc import NestedTensor, nested_tensor_from_tensor_list  # noqa: E402
+from tubelet_transformer_amd.tuber import build_model                 # noqa: E402
+
+CFGS = ["TubeR_CSN152_AVA21", "TubeR_CSN50_AVA21", "Tuber_CSN152_JHMDB", "TubeR_CSN152_AVA22"]
+
+
+def cfg_of(name):
+    return load_cfg(os.path.join(ROOT, "configuration", name + ".yaml"))
+
+
+# ---------------------------------------------------------------- oracle vs golden ----------------------------
+def _flat(out):
+    d = {k: v.detach().numpy() for k, v in out.items() if k != "aux_outputs"}
+    for i, a in enumerate(out.get("aux_outputs", [])):
+        for k, v in a.items():
+            d["aux%d.%s" % (i, k)] = v.detach().numpy()
+    return d
+
+
+@pytest.mark.parametrize("name,yaml_name,sizes", [
+    ("csn50_ava21_decode_eval", "TubeR_CSN50_AVA21", [(64, 96)]),
+    ("csn152_ava21_avg_eval_ragged", "TubeR_CSN152_AVA21", [(64, 96), (48, 80)]),
+    ("csn152_jhmdb_eval", "Tuber_CSN152_JHMDB", [(64, 64)]),
+])
+def test_oracle_forward_matches_reference_golden(golden_dir, name, yaml_name, sizes):
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfg_of(yaml_name)
+    model, _, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    clips = (synth.synthetic_clips(len(sizes), 32, sizes[0][0], sizes[0][1], seed=1234) if len(set(sizes)) == 1
+             else synth.synthetic_clips(len(sizes), 32, 0, 0, seed=1234, sizes=sizes))
+    with torch.no_grad():
+        out = O.tuber_forward(state, cfg, clips, train=False)
+    got = _flat(out)
+    worst = max(float(np.abs(got[k] - gold[k]).max()) for k in got)
+    assert worst <= 1e-5, worst
+    tsz = torch.as_tensor(gold["post.target_sizes"])
+    pp = O.post_process(cfg, {k: v for k, v in out.items() if k != "aux_outputs"}, tsz)
+    for a, k in zip(pp, ("post.scores", "post.boxes", "post.out_b")):
+        assert np.abs(a - gold[k]).max() <= 1e-5 * max(1.0, float(np.abs(gold[k]).max()))
+
+
+@pytest.mark.parametrize("name,yaml_name", [("criterion_ava", "TubeR_CSN152_AVA21"), ("criterion_jhmdb", "Tuber_CSN152_JHMDB")])
+def test_oracle_criterion_matches_reference_golden(golden_dir, name, yaml_name):
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfg_of(yaml_name)
+    ava = cfg.CONFIG.DATA.DATASET_NAME == "ava"
+    targets = synth.synthetic_targets(3, "ava" if ava else "jhmdb", cfg.CONFIG.DATA.NUM_CLASSES, seed=int(gold["seed"]) + 1,
+                                      boxes_per_clip=[1, 4, 2] if ava else None)
+    keys = ("pred_logits", "pred_boxes", "pred_logits_b")
+    outs = {k: torch.as_tensor(gold["in." + k]) for k in keys}
+    outs["aux_outputs"] = [{k: torch.as_tensor(gold["in.aux%d.%s" % (i, k)]) for k in keys} for i in range(5)]
+    ld, idx = O.set_criterion(cfg, outs, targets)
+    for k in gold.files:
+        if k.startswith("loss."):
+            assert abs(float(ld[k[5:]]) - float(gold[k])) <= 1e-5 * max(1.0, abs(float(gold[k]))), k
+    for li, per in enumerate(idx):
+        for b, (i, j) in enumerate(per):
+            assert np.array_equal(i.numpy(), gold["match.%d.%d.src" % (li, b)])
+    assert abs(float(O.total_loss(cfg, ld)) - float(gold["total_loss"])) <= 1e-4
+
+
+# ---------------------------------------------------------------- boundary ----------------------------------------
+@pytest.mark.parametrize("name", CFGS)
+def test_state_dict_and_weight_dict_match_the_reference(golden_dir, name):
+    ref = json.load(open(os.path.join(golden_dir, "reference_state_dicts.json")))[name]
+    model, crit, post = build_model(cfg_of(name))
+    mine = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    assert mine == ref["model"]                      # names, shapes AND order (DDP / optimizer param-group order)
+    assert [[k, list(v.shape)] for k, v in crit.state_dict().items()] == ref["criterion"]
+    assert {k: float(v) for k, v in crit.weight_dict.items()} == ref["weight_dict"]
+    assert set(post) == {"bbox"}
+    names = [n for n, _ in model.named_parameters()]
+    assert any("backbone" in n for n in names) and any("class_embed" in n for n in names) and any("query_embed" in n for n in names)
+
+
+def test_drop_in_import_paths():
+    from models.tuber_ava import build_model as b1
+    from models.tuber_jhmdb import build_model as b2
+    from pipelines.video_action_recognition_config import get_cfg_defaults as g
+    from utils.misc import NestedTensor as N2
+    assert b1 is build_model and b2 is build_model and g is get_cfg_defaults and N2 is NestedTensor
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    model, _, _ = build_model(cfg_of("TubeR_CSN152_AVA21"))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 3, 32, 32, 32))
+    with pytest.raises(RuntimeError):
+        model.backbone.body(torch.zeros(1, 3, 32, 32, 32))
+
+
+def test_config_loader_yacs_semantics(tmp_path):
+    cfg = cfg_of("TubeR_CSN50_AVA21")
+    assert isinstance(cfg.CONFIG.TRAIN.LR, float) and cfg.CONFIG.TRAIN.LR == 1e-4          # '1e-4' literal_eval'd like yacs
+    assert cfg.CONFIG.MODEL.BACKBONE_NAME == "CSN-50" and cfg.CONFIG.MODEL.TEMPORAL_DS_STRATEGY == "decode"
+    c2 = cfg.clone()
+    c2.CONFIG.MODEL.QUERY_NUM = 3
+    assert cfg.CONFIG.MODEL.QUERY_NUM == 15
+    c2.CONFIG.NEW_KEY = 5                                                                  # CONFIG nodes are new_allowed
+    with pytest.raises(KeyError):
+        d = get_cfg_defaults()
+        d.merge_from_other_cfg({"DDP_CONFIG": {"NOT_A_KEY": 1}})
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.CONFIG.EVAL_ONLY = True
+    p = tmp_path / "c.yaml"
+    p.write_text(cfg.dump())
+    again = get_cfg_defaults()
+    again.merge_from_file(str(p))
+    assert again.CONFIG.MODEL.QUERY_NUM == 15
+
+
+def test_nested_tensor_padding_and_mask():
+    a, b = torch.ones(3, 4, 5, 7), 2 * torch.ones(3, 4, 6, 3)
+    nt = nested_tensor_from_tensor_list([a, b])
+    assert nt.tensors.shape == (2, 3, 4, 6, 7) and nt.mask.shape == (2, 6, 7)
+    assert not nt.mask[0, :5, :7].any() and nt.mask[0, 5:].all()
+    assert not nt.mask[1, :6, :3].any() and nt.mask[1, :, 3:].all()
+    assert float(nt.tensors[1, :, :, :, 3:].abs().sum()) == 0
+    o_t, o_m = O.nested_from_list([a, b])
+    assert torch.equal(o_t, nt.tensors) and torch.equal(o_m, nt.mask)
+    with pytest.raises(ValueError):
+        nested_tensor_from_tensor_list([torch.zeros(3, 3)])
+
+
+# ---------------------------------------------------------------- C ABI --------------------------------------------
+def test_library_exports_every_symbol_the_header_declares():
+    protos = lib.header_prototypes()
+    assert len(protos) >= 50
+    L = lib.load()                      # binds every prototype; AttributeError = header/library drift
+    for _, name, _ in protos:
+        assert hasattr(L, name), name
+    # pure host helpers may be called without a GPU
+    assert lib.query("tuber_gemm_nt_stat_rows", 348160, 64) == 2720
+    assert lib.query("tuber_gemm_nt_cfg", 30, 256) == 2
+
+
+def test_lsap_matches_scipy_including_ties():
+    from scipy.optimize import linear_sum_assignment
+    from tubelet_transformer_amd.criterion import _lsap
+    rng = np.random.default_rng(0)
+    for trial in range(3000):
+        nr, nc = int(rng.integers(1, 17)), int(rng.integers(1, 8))
+        mode = trial % 4
+        if mode == 0:
+            c = rng.standard_normal((nr, nc))
+        elif mode == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif mode == 2:                       # constant across targets, like the AVA class cost (matcher.py:72)
+            c = np.repeat(rng.integers(0, 4, (nr, 1)).astype(float), nc, 1)
+        else:
+            c = rng.integers(0, 2, (nr, nc)).astype(float) + np.repeat(rng.integers(0, 3, (nr, 1)).astype(float), nc, 1)
+        if trial % 7 == 0:
+            c = np.ascontiguousarray(c.T)
+        a, b = linear_sum_assignment(c)
+        i, j = _lsap(c)
+        assert np.array_equal(a, i) and np.array_equal(b, j)
+    i, j = _lsap(np.zeros((5, 0)))
+    assert len(i) == 0 and len(j) == 0
+
+
+# ---------------------------------------------------------------- data-parallel reducer (gloo, 2 processes) ------------
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from tubelet_transformer_amd.ddp import FlatGradReducer, broadcast_parameters
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(100, 70)
+            self.query_embed = torch.nn.Embedding(15, 64)
+            self.b = torch.nn.Linear(70, 33)
+    torch.manual_seed(rank)
+    m = M()
+    names = [n for n, _ in m.named_parameters()]
+    store = type("S", (), {})()
+    store.module, store.names, store.params = m, names, [p for _, p in m.named_parameters()]
+    off, store.offsets = 0, {}
+    for n, p in zip(names, store.params):
+        store.offsets[n] = off
+        off += (p.numel() + 63) // 64 * 64
+    store.total = off
+    store.flat = torch.randn(off)
+    store.gflat = torch.zeros(off)
+    broadcast_parameters(store)
+    red = FlatGradReducer(store, min_bucket=64)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(off, generator=g)
+    red.begin()
+    # backward fills the flat buffer from its high end down; notify after each "stage"
+    cuts = [store.offsets["b.weight"], store.offsets["query_embed.weight"], store.offsets["a.bias"], 0]
+    hi = off
+    for c in cuts:
+        store.gflat[c:hi] = local[c:hi]
+        if c:
+            red.notify(c)
+        hi = c
+    red.finish()
+    q.put((rank, store.flat.numpy().copy(), store.gflat.numpy().copy(), local.numpy().copy()))   # by value, not shared memory
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    (_, f0, g0, l0), (_, f1, g1, l1) = res
+    assert np.array_equal(f0, f1)                                # parameters broadcast from rank 0
+    mean = (l0 + l1) / 2
+    assert np.allclose(g0, mean, atol=1e-6) and np.allclose(g1, mean, atol=1e-6)   # every slice reduced exactly once
