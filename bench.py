@@ -43,7 +43,8 @@ def alg_cost(name, a):
         return "gemm_nt_kernel<%s,%d,%d>" % (tile, amode, epi), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
-        return "gemm_tn_kernel<%d>" % a[10], 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
+        T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64
+        return "gemm_tn_kernel<%d,%d>" % (a[10], T), 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
     if name in ("tuber_dwconv_fwd", "tuber_dwconv_bwd_data", "tuber_dwconv_bwd_weight"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
         N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss = a[off:off + 10]
@@ -65,6 +66,20 @@ def alg_cost(name, a):
     return name.replace("tuber_", "") + "*", 0, 0
 
 
+def shape_of(name, a):
+    if name == "tuber_gemm_nt":
+        return "M%d N%d K%d amode%d epi%d" % (a[6], a[7], a[8], a[9], a[21])
+    if name == "tuber_gemm_tn":
+        return "M%d N%d K%d amode%d" % (a[7], a[8], a[9], a[10])
+    if name in ("tuber_attn_fwd", "tuber_attn_bwd"):
+        off = 10 if name == "tuber_attn_fwd" else 19
+        return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])
+    if name.startswith("tuber_dwconv"):
+        off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
+        return "N%d in%dx%dx%d out%dx%dx%d C%d st%d ss%d" % tuple(a[off:off + 10])
+    return ""
+
+
 class LaunchTimer:
     """HIP-event timing of kernel launches on torch's current stream (where every tuber_* launch is enqueued)."""
 
@@ -79,12 +94,24 @@ class LaunchTimer:
         e0.record()
         rc = launch(name, *args)
         e1.record()
-        self.rec.append((key, by, fl, e0, e1))
+        self.rec.append((key, by, fl, e0, e1, shape_of(name, args)))
         return rc
+
+    def by_shape(self, top=40):
+        out = {}
+        for key, by, fl, e0, e1, shp in self.rec:
+            d = out.setdefault((key, shp), [0, 0.0, 0, 0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += by
+            d[3] += fl
+        rows = sorted(out.items(), key=lambda kv: -kv[1][1])[:top]
+        return ["%-40s %-44s n=%-3d %8.3f ms  %7.1f GB/s %7.1f TF/s" % (k[0], k[1], v[0], v[1], v[2] / (v[1] * 1e-3) / 1e9 if v[1] else 0,
+                                                                        v[3] / (v[1] * 1e-3) / 1e12 if v[1] else 0) for k, v in rows]
 
     def summary(self):
         out = {}
-        for key, by, fl, e0, e1 in self.rec:
+        for key, by, fl, e0, e1, _ in self.rec:
             d = out.setdefault(key, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -209,6 +236,8 @@ def main():
         torch.cuda.synchronize()
         lib.set_launch_hook(None)
         prepass = timer.summary()
+        if os.environ.get("TUBER_BENCH_SHAPES") and rank == 0:
+            print("\n".join(timer.by_shape()), file=sys.stderr, flush=True)
         dominant = max((k for k in prepass if prepass[k]["bytes"] > 0), key=lambda k: prepass[k]["ms"])
     fence()
     t0 = time.perf_counter()

@@ -10,9 +10,10 @@
 // and the tubelet-query cross attention without materialising any of the reference's
 // view/permute/contiguous copies (tuber_ava.py:133-139, transformer_layers.py:77-91).
 //
-// Round-1 kernel: flash-style online softmax, one query row per thread, K/V tiles of 64 keys
-// staged in LDS and broadcast-read; fp32 math on bf16 storage.  Sequences are <= 1728 tokens
-// (SURVEY.md section 5.7).  Backward recomputes P from the saved log-sum-exp (no P tensor in HBM).
+// Round-1 kernel: flash-style online softmax in fp32 on bf16 storage; every query (key) row is split over
+// 16 lanes that each walk a strided subset of the keys (queries) and are merged with wave shuffles.
+// Sequences are <= 1728 tokens.  Backward recomputes P from the saved
+// log-sum-exp (no P tensor in HBM).
 #include "common.h"
 
 struct TokMap { long ld; long sL, s1, s2; int B2; };
@@ -37,7 +38,9 @@ struct AttnArgs {
     float* delta;                 // [B][H][Lq]
 };
 
-#define KT 64
+__device__ __forceinline__ uint64_t eff_seed(const uint64_t* seed_ptr, uint64_t salt) {
+    return (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
+}
 __device__ __forceinline__ void load_row32(const bf16* p, float (&v)[32]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -55,214 +58,314 @@ __device__ __forceinline__ void store_row32(bf16* p, const float (&v)[32]) {
         ((uint4*)p)[i] = as_uint4(t);
     }
 }
-// stage rows [r0, r0+KT) of a strided [L][32] bf16 operand into LDS [KT][32]
-__device__ __forceinline__ void stage_tile(bf16 (*dst)[32], const bf16* base, const TokMap& m, int b, int h, int r0, int L) {
-    for (int i = threadIdx.x; i < KT * 4; i += blockDim.x) {
-        const int r = i >> 2, c = i & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + r < L) v = *(const uint4*)(base + tok_row(m, r0 + r, b) * m.ld + h * 32 + c * 8);
-        *(uint4*)&dst[r][c * 8] = v;
+__device__ __forceinline__ float dot32(const float (&a)[32], const float (&b)[32]) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        s0 = fmaf(a[d], b[d], s0); s1 = fmaf(a[d + 1], b[d + 1], s1);
+        s2 = fmaf(a[d + 2], b[d + 2], s2); s3 = fmaf(a[d + 3], b[d + 3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// Thread layout of the three main kernels: 256 threads = 16 rows x 16 "split" lanes; the 16 lanes of a row are an aligned
+// 16-lane group of one wave, so partial results are combined with xor-shuffles 1,2,4,8.  Splitting the key (or query)
+// loop over 16 lanes gives the small-batch calls of this model (B*H = 16, Lq = 15 tubelet queries) 16x more parallelism
+// than one-row-per-thread.  The other operand is staged through LDS in tiles of 64 rows (80-byte padded rows: the 16
+// lanes of a row read 16 different LDS rows conflict-free with ds_read_b128).
+#define KT 64
+#define KPAD 40
+__device__ __forceinline__ void stage_rows(bf16 (*dst)[KPAD], const bf16* base, const TokMap& m, int b, int h, int r0, int L) {
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;          // 64 rows x 4 chunks of 16 B = 256 threads
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < L) v = *(const uint4*)(base + tok_row(m, r0 + r, b) * m.ld + h * 32 + c * 8);
+    *(uint4*)&dst[r][c * 8] = v;
+}
+__device__ __forceinline__ void lds_row32(const bf16 (*src)[KPAD], int r, float (&v)[32]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x8 t = as_bf16x8(*(const uint4*)&src[r][i * 8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i * 8 + e] = bf2f(t[e]);
     }
 }
 
-__device__ __forceinline__ uint64_t eff_seed(const uint64_t* seed_ptr, uint64_t salt) {
-    return (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
-}
-
-__global__ __launch_bounds__(128) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[KT][32];
-    __shared__ __attribute__((aligned(16))) bf16 vs[KT][32];
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 ks[KT][KPAD];
+    __shared__ __attribute__((aligned(16))) bf16 vs[KT][KPAD];
     __shared__ uint8_t msk[KT];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qi = blockIdx.x * 128 + threadIdx.x;
+    const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), kl = threadIdx.x & 15;
     const bool active = qi < a.Lq;
+    const int qc = active ? qi : a.Lq - 1;
     float q[32], o[32];
+    load_row32(a.Q + tok_row(a.mq, qc, b) * a.mq.ld + h * 32, q);
 #pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] = 0.f; o[d] = 0.f; }
-    if (active) load_row32(a.Q + tok_row(a.mq, qi, b) * a.mq.ld + h * 32, q);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) q[d] *= a.scale;
+    for (int d = 0; d < 32; ++d) { q[d] *= a.scale; o[d] = 0.f; }
     float mx = -INFINITY, l = 0.f;
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
-    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + (active ? qi : 0)) * (uint64_t)a.Lk;
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
+    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
         __syncthreads();
-        stage_tile(ks, a.K, a.mk, b, h, k0, a.Lk);
-        stage_tile(vs, a.V, a.mv, b, h, k0, a.Lk);
-        if (threadIdx.x < KT) msk[threadIdx.x] = (a.kpm && k0 + threadIdx.x < a.Lk) ? a.kpm[(long)b * a.Lk + k0 + threadIdx.x] : 0;
+        stage_rows(ks, a.K, a.mk, b, h, k0, a.Lk);
+        stage_rows(vs, a.V, a.mv, b, h, k0, a.Lk);
+        if (threadIdx.x < KT) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
         __syncthreads();
-        const int kn = min(KT, a.Lk - k0);
-        for (int c0 = 0; c0 < kn; c0 += 16) {
-            float s[16];
-            float cmax = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int kk = c0 + j;
-                float acc = 0.f;
+        for (int j = 0; j < KT / 16; ++j) {
+            const int kk = kl + 16 * j;
+            if (msk[kk]) continue;
+            float kv[32];
+            lds_row32(ks, kk, kv);
+            const float sc = dot32(q, kv);
+            if (sc > mx) {
+                const float alpha = __expf(mx - sc);
+                l *= alpha;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x8 t = as_bf16x8(*(const uint4*)&ks[kk][i * 8]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc = fmaf(q[i * 8 + e], bf2f(t[e]), acc);
-                }
-                const bool valid = kk < kn && !msk[kk];
-                s[j] = valid ? acc : -INFINITY;
-                cmax = fmaxf(cmax, s[j]);
+                for (int d = 0; d < 32; ++d) o[d] *= alpha;
+                mx = sc;
             }
-            const float mnew = fmaxf(mx, cmax);
-            if (mnew == -INFINITY) continue;          // every key so far masked
-            const float alpha = __expf(mx - mnew);
-            l *= alpha;
+            const float p = __expf(sc - mx);
+            l += p;
+            float pv = p;
+            if (a.pdrop > 0.f) pv = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? p * inv_keep : 0.f;
+            lds_row32(vs, kk, kv);
 #pragma unroll
-            for (int d = 0; d < 32; ++d) o[d] *= alpha;
-            mx = mnew;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int kk = c0 + j;
-                const float p = __expf(s[j] - mx);     // exp(-inf) = 0 for masked / tail keys
-                l += p;
-                float pv = p;
-                if (a.pdrop > 0.f) pv = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? p * inv_keep : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x8 t = as_bf16x8(*(const uint4*)&vs[kk][i * 8]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[i * 8 + e] = fmaf(pv, bf2f(t[e]), o[i * 8 + e]);
-                }
-            }
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(pv, kv[d], o[d]);
         }
     }
-    if (active) {
+    // combine the 16 partial softmaxes of this query row
+    float M = mx;
+    M = fmaxf(M, __shfl_xor(M, 1)); M = fmaxf(M, __shfl_xor(M, 2)); M = fmaxf(M, __shfl_xor(M, 4)); M = fmaxf(M, __shfl_xor(M, 8));
+    const float f = mx == -INFINITY ? 0.f : __expf(mx - M);
+    l = quad16_sum(l * f);
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = quad16_sum(o[d] * f);
+    if (active && kl == 0) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] *= inv;
         store_row32(a.O + tok_row(a.mo, qi, b) * a.mo.ld + h * 32, o);
-        if (a.lse) a.lse[((long)b * a.H + h) * a.Lq + qi] = mx + __logf(l);
+        if (a.lse) a.lse[((long)b * a.H + h) * a.Lq + qi] = M + __logf(l);
     }
 }
 
-// dQ: one query row per thread.  Also writes delta = dO . O for the dK/dV kernel.
-__global__ __launch_bounds__(128) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[KT][32];
-    __shared__ __attribute__((aligned(16))) bf16 vs[KT][32];
+// dQ (and delta = dO . O for the dK/dV kernel): rows = queries, split = keys
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 ks[KT][KPAD];
+    __shared__ __attribute__((aligned(16))) bf16 vs[KT][KPAD];
     __shared__ uint8_t msk[KT];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qi = blockIdx.x * 128 + threadIdx.x;
+    const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), kl = threadIdx.x & 15;
     const bool active = qi < a.Lq;
+    const int qc = active ? qi : a.Lq - 1;
     float q[32], dov[32], dq[32];
-    float lse = 0.f, delta = 0.f;
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] = 0.f; dov[d] = 0.f; dq[d] = 0.f; }
-    if (active) {
-        load_row32(a.Q + tok_row(a.mq, qi, b) * a.mq.ld + h * 32, q);
-        load_row32(a.dO + tok_row(a.mdo, qi, b) * a.mdo.ld + h * 32, dov);
+    load_row32(a.Q + tok_row(a.mq, qc, b) * a.mq.ld + h * 32, q);
+    load_row32(a.dO + tok_row(a.mdo, qc, b) * a.mdo.ld + h * 32, dov);
+    float delta;
+    {
         float ov[32];
-        load_row32(a.O + tok_row(a.mo, qi, b) * a.mo.ld + h * 32, ov);
-#pragma unroll
-        for (int d = 0; d < 32; ++d) delta = fmaf(dov[d], ov[d], delta);
-        lse = a.lse[((long)b * a.H + h) * a.Lq + qi];
-        a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
+        load_row32(a.O + tok_row(a.mo, qc, b) * a.mo.ld + h * 32, ov);
+        delta = dot32(dov, ov);
     }
+    const float lse = a.lse[((long)b * a.H + h) * a.Lq + qc];
+    if (active && kl == 0) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
-    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + (active ? qi : 0)) * (uint64_t)a.Lk;
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
+    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
         __syncthreads();
-        stage_tile(ks, a.K, a.mk, b, h, k0, a.Lk);
-        stage_tile(vs, a.V, a.mv, b, h, k0, a.Lk);
-        if (threadIdx.x < KT) msk[threadIdx.x] = (a.kpm && k0 + threadIdx.x < a.Lk) ? a.kpm[(long)b * a.Lk + k0 + threadIdx.x] : 0;
+        stage_rows(ks, a.K, a.mk, b, h, k0, a.Lk);
+        stage_rows(vs, a.V, a.mv, b, h, k0, a.Lk);
+        if (threadIdx.x < KT) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
         __syncthreads();
-        const int kn = min(KT, a.Lk - k0);
-        for (int kk = 0; kk < kn; ++kk) {
+#pragma unroll
+        for (int j = 0; j < KT / 16; ++j) {
+            const int kk = kl + 16 * j;
             if (msk[kk]) continue;
-            float s = 0.f, dp = 0.f;
-            float kv[32];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 t = as_bf16x8(*(const uint4*)&ks[kk][i * 8]);
-                const bf16x8 u = as_bf16x8(*(const uint4*)&vs[kk][i * 8]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    kv[i * 8 + e] = bf2f(t[e]);
-                    s = fmaf(q[i * 8 + e], kv[i * 8 + e], s);
-                    dp = fmaf(dov[i * 8 + e], bf2f(u[e]), dp);
-                }
-            }
-            const float p = __expf(s * a.scale - lse);
+            float kv[32], vv[32];
+            lds_row32(ks, kk, kv);
+            lds_row32(vs, kk, vv);
+            const float p = __expf(dot32(q, kv) * a.scale - lse);
+            float dp = dot32(dov, vv);
             if (a.pdrop > 0.f) dp = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? dp * inv_keep : 0.f;
             const float ds = p * (dp - delta) * a.scale;
 #pragma unroll
             for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, kv[d], dq[d]);
         }
     }
-    if (active) store_row32(a.dQ + tok_row(a.mdq, qi, b) * a.mdq.ld + h * 32, dq);
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = quad16_sum(dq[d]);
+    if (active && kl == 0) store_row32(a.dQ + tok_row(a.mdq, qi, b) * a.mdq.ld + h * 32, dq);
 }
 
-// dK, dV: one key row per thread; Q / dO tiles (+ lse, delta) staged in LDS.
-__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 qs[KT][32];
-    __shared__ __attribute__((aligned(16))) bf16 dos[KT][32];
+// dK, dV: rows = keys, split = queries (Q / dO / lse / delta tiles staged in LDS)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 qs[KT][KPAD];
+    __shared__ __attribute__((aligned(16))) bf16 dos[KT][KPAD];
     __shared__ float lses[KT], dels[KT];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int ki = blockIdx.x * 128 + threadIdx.x;
+    const int ki = blockIdx.x * 16 + (threadIdx.x >> 4), ql = threadIdx.x & 15;
     const bool active = ki < a.Lk;
-    const bool masked = active && a.kpm && a.kpm[(long)b * a.Lk + ki];
+    const int kc = active ? ki : a.Lk - 1;
+    const bool masked = a.kpm && a.kpm[(long)b * a.Lk + kc];
     float k[32], v[32], dk[32], dv[32];
+    load_row32(a.K + tok_row(a.mk, kc, b) * a.mk.ld + h * 32, k);
+    load_row32(a.V + tok_row(a.mv, kc, b) * a.mv.ld + h * 32, v);
 #pragma unroll
-    for (int d = 0; d < 32; ++d) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
-    if (active) {
-        load_row32(a.K + tok_row(a.mk, ki, b) * a.mk.ld + h * 32, k);
-        load_row32(a.V + tok_row(a.mv, ki, b) * a.mv.ld + h * 32, v);
-    }
+    for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     for (int q0 = 0; q0 < a.Lq; q0 += KT) {
         __syncthreads();
-        stage_tile(qs, a.Q, a.mq, b, h, q0, a.Lq);
-        stage_tile(dos, a.dO, a.mdo, b, h, q0, a.Lq);
+        stage_rows(qs, a.Q, a.mq, b, h, q0, a.Lq);
+        stage_rows(dos, a.dO, a.mdo, b, h, q0, a.Lq);
         if (threadIdx.x < KT) {
             const bool ok = q0 + threadIdx.x < a.Lq;
-            lses[threadIdx.x] = ok ? a.lse[((long)b * a.H + h) * a.Lq + q0 + threadIdx.x] : 0.f;
+            lses[threadIdx.x] = ok ? a.lse[((long)b * a.H + h) * a.Lq + q0 + threadIdx.x] : INFINITY;   // exp(-inf) = 0 beyond Lq
             dels[threadIdx.x] = ok ? a.delta[((long)b * a.H + h) * a.Lq + q0 + threadIdx.x] : 0.f;
         }
         __syncthreads();
-        if (!active || masked) continue;
-        const int qn = min(KT, a.Lq - q0);
-        for (int qq = 0; qq < qn; ++qq) {
-            float s = 0.f, dp = 0.f;
-            float qv[32], dv_[32];
+        if (masked) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 t = as_bf16x8(*(const uint4*)&qs[qq][i * 8]);
-                const bf16x8 u = as_bf16x8(*(const uint4*)&dos[qq][i * 8]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    qv[i * 8 + e] = bf2f(t[e]);
-                    dv_[i * 8 + e] = bf2f(u[e]);
-                    s = fmaf(qv[i * 8 + e], k[i * 8 + e], s);
-                    dp = fmaf(dv_[i * 8 + e], v[i * 8 + e], dp);
-                }
-            }
-            const float p = __expf(s * a.scale - lses[qq]);
-            float pd = p;
+        for (int j = 0; j < KT / 16; ++j) {
+            const int qq = ql + 16 * j;
+            if (q0 + qq >= a.Lq) continue;
+            float qv[32], dov[32];
+            lds_row32(qs, qq, qv);
+            lds_row32(dos, qq, dov);
+            const float p = __expf(dot32(qv, k) * a.scale - lses[qq]);
+            float dp = dot32(dov, v), pd = p;
             if (a.pdrop > 0.f) {
-                const uint64_t idx = ((uint64_t)(b * a.H + h) * a.Lq + (q0 + qq)) * (uint64_t)a.Lk + ki;
+                const uint64_t idx = ((uint64_t)(b * a.H + h) * a.Lq + (q0 + qq)) * (uint64_t)a.Lk + kc;
                 const bool keep = dropout_keep(seed, idx, a.thresh);
                 pd = keep ? p * inv_keep : 0.f;
                 dp = keep ? dp * inv_keep : 0.f;
             }
             const float ds = p * (dp - dels[qq]) * a.scale;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { dv[d] = fmaf(pd, dv_[d], dv[d]); dk[d] = fmaf(ds, qv[d], dk[d]); }
+            for (int d = 0; d < 32; ++d) { dv[d] = fmaf(pd, dov[d], dv[d]); dk[d] = fmaf(ds, qv[d], dk[d]); }
         }
     }
-    if (active) {
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { dk[d] = quad16_sum(dk[d]); dv[d] = quad16_sum(dv[d]); }
+    if (active && ql == 0) {
         store_row32(a.dK + tok_row(a.mdk, ki, b) * a.mdk.ld + h * 32, dk);
         store_row32(a.dV + tok_row(a.mdv, ki, b) * a.mdv.ld + h * 32, dv);
     }
 }
 
+// ---- tiny sequences (Lq, Lk <= 8: the class branch's attention over the 4 temporal slots, batch = layers x clips x h*w) ----
+// one thread per (batch, head, row); every row is a handful of 64-byte loads that the 4 sibling threads share in L1.
+#define SMALL_L 8
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)a.B * a.H * a.Lq) return;
+    const int qi = (int)(t % a.Lq); const long bh = t / a.Lq;
+    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    float q[32], o[32], s[SMALL_L];
+    load_row32(a.Q + tok_row(a.mq, qi, b) * a.mq.ld + h * 32, q);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SMALL_L; ++k) {
+        s[k] = -INFINITY;
+        if (k < a.Lk && !(a.kpm && a.kpm[(long)b * a.Lk + k])) {
+            float kv[32];
+            load_row32(a.K + tok_row(a.mk, k, b) * a.mk.ld + h * 32, kv);
+            s[k] = dot32(q, kv) * a.scale;
+            mx = fmaxf(mx, s[k]);
+        }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
+#pragma unroll
+    for (int k = 0; k < SMALL_L; ++k) {
+        if (k < a.Lk && s[k] != -INFINITY) {
+            const float p = __expf(s[k] - mx);
+            l += p;
+            float pv = p;
+            if (a.pdrop > 0.f) pv = dropout_keep(seed, (uint64_t)t * a.Lk + k, a.thresh) ? p * inv_keep : 0.f;
+            float vv[32];
+            load_row32(a.V + tok_row(a.mv, k, b) * a.mv.ld + h * 32, vv);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(pv, vv[d], o[d]);
+        }
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] *= inv;
+    store_row32(a.O + tok_row(a.mo, qi, b) * a.mo.ld + h * 32, o);
+    if (a.lse) a.lse[t] = mx + __logf(l);
+}
+
+// thread i of a (batch, head): dQ of query i (i < Lq) and dK, dV of key i (i < Lk); delta recomputed locally
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a) {
+    const int Lm = max(a.Lq, a.Lk);
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)a.B * a.H * Lm) return;
+    const int i = (int)(t % Lm); const long bh = t / Lm;
+    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
+    if (i < a.Lq) {
+        float q[32], dov[32], ov[32], dq[32];
+        load_row32(a.Q + tok_row(a.mq, i, b) * a.mq.ld + h * 32, q);
+        load_row32(a.dO + tok_row(a.mdo, i, b) * a.mdo.ld + h * 32, dov);
+        load_row32(a.O + tok_row(a.mo, i, b) * a.mo.ld + h * 32, ov);
+        const float delta = dot32(dov, ov);
+        const long li = bh * a.Lq + i;
+        const float lse = a.lse[li];
+        a.delta[li] = delta;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+        for (int k = 0; k < a.Lk; ++k) {
+            if (a.kpm && a.kpm[(long)b * a.Lk + k]) continue;
+            float kv[32], vv[32];
+            load_row32(a.K + tok_row(a.mk, k, b) * a.mk.ld + h * 32, kv);
+            load_row32(a.V + tok_row(a.mv, k, b) * a.mv.ld + h * 32, vv);
+            const float p = __expf(dot32(q, kv) * a.scale - lse);
+            float dp = dot32(dov, vv);
+            if (a.pdrop > 0.f) dp = dropout_keep(seed, (uint64_t)li * a.Lk + k, a.thresh) ? dp * inv_keep : 0.f;
+            const float ds = p * (dp - delta) * a.scale;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, kv[d], dq[d]);
+        }
+        store_row32(a.dQ + tok_row(a.mdq, i, b) * a.mdq.ld + h * 32, dq);
+    }
+    if (i < a.Lk) {
+        float k[32], v[32], dk[32], dv[32];
+        load_row32(a.K + tok_row(a.mk, i, b) * a.mk.ld + h * 32, k);
+        load_row32(a.V + tok_row(a.mv, i, b) * a.mv.ld + h * 32, v);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        const bool masked = a.kpm && a.kpm[(long)b * a.Lk + i];
+        for (int qq = 0; qq < a.Lq && !masked; ++qq) {
+            float qv[32], dov[32], ov[32];
+            load_row32(a.Q + tok_row(a.mq, qq, b) * a.mq.ld + h * 32, qv);
+            load_row32(a.dO + tok_row(a.mdo, qq, b) * a.mdo.ld + h * 32, dov);
+            load_row32(a.O + tok_row(a.mo, qq, b) * a.mo.ld + h * 32, ov);
+            const long li = bh * a.Lq + qq;
+            const float p = __expf(dot32(qv, k) * a.scale - a.lse[li]);
+            float dp = dot32(dov, v), pd = p;
+            if (a.pdrop > 0.f) {
+                const bool keep = dropout_keep(seed, (uint64_t)li * a.Lk + i, a.thresh);
+                pd = keep ? p * inv_keep : 0.f;
+                dp = keep ? dp * inv_keep : 0.f;
+            }
+            const float ds = p * (dp - dot32(dov, ov)) * a.scale;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dv[d] = fmaf(pd, dov[d], dv[d]); dk[d] = fmaf(ds, qv[d], dk[d]); }
+        }
+        store_row32(a.dK + tok_row(a.mdk, i, b) * a.mdk.ld + h * 32, dk);
+        store_row32(a.dV + tok_row(a.mdv, i, b) * a.mdv.ld + h * 32, dv);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Wide-head, single-query attention of the LSTR pooling decoder (TEMPORAL_DS_STRATEGY 'decode',
@@ -378,7 +481,10 @@ int tuber_attn_fwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.O = (bf16*)O; a.mo = mk_map(mo); a.lse = lse; a.kpm = (const uint8_t*)key_padding_mask;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.pdrop = pdrop;
     a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(128), 0, stream, a);
+    if (Lq <= SMALL_L && Lk <= SMALL_L)
+        hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(ceil_div((long)B * H * Lq, 256)), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
     TUBER_RETURN_LAUNCH();
 }
 
@@ -394,8 +500,12 @@ int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
     a.dO = (const bf16*)dO; a.mdo = mk_map(mdo); a.dQ = (bf16*)dQ; a.mdq = mk_map(mdq); a.dK = (bf16*)dK; a.mdk = mk_map(mdk);
     a.dV = (bf16*)dV; a.mdv = mk_map(mdv); a.delta = delta;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(128), 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(128), 0, stream, a);
+    if (Lq <= SMALL_L && Lk <= SMALL_L) {
+        hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(ceil_div((long)B * H * (Lq > Lk ? Lq : Lk), 256)), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(Lk, 16), H, B), dim3(256), 0, stream, a);
+    }
     TUBER_RETURN_LAUNCH();
 }
 

@@ -40,49 +40,59 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(
     for (int it = 0; it < iters; ++it) {
         const long seg = ((long)blockIdx.x * iters + it) * 16 + ps;
         if (seg >= segs) break;
-        int wg = (int)(seg % Wg); long r = seg / Wg;
-        const int ho = (int)(r % g.Ho); r /= g.Ho;
-        const int to = (int)(r % g.To); const int n = (int)(r / g.To);
+        const int sg32 = (int)seg;
+        int wg = sg32 % Wg; int r = sg32 / Wg;
+        const int ho = r % g.Ho; r /= g.Ho;
+        const int to = r % g.To; const int n = r / g.To;
         const int wo0 = wg * 4;
         float acc[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+        // all 9 x NIN input vectors are loaded unconditionally from clamped addresses (one latency, not nine) and
+        // zeroed afterwards where the tap falls into the padding
+        uint2 raw[9][NIN];
+        unsigned okr = 0;                           // bit r: row (dt,dh) inside the volume
+        int wok = 0;                                // bit i: column i inside the row
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-            const int ti = to * g.st + dt - 1;
-            if (ti < 0 || ti >= g.Ti) continue;
+        for (int i = 0; i < NIN; ++i) { const int wi = wo0 * SS - 1 + i; wok |= (wi >= 0 && wi < g.Wi) ? (1 << i) : 0; }
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh) {
-                const int hi = ho * SS + dh - 1;
-                if (hi < 0 || hi >= g.Hi) continue;
-                const bf16* row = x + (((long)n * g.Ti + ti) * g.Hi + hi) * (long)g.Wi * g.C + c;
-                float in[NIN][4];
+        for (int r = 0; r < 9; ++r) {
+            const int dt = r / 3, dh = r % 3;
+            const int ti = to * g.st + dt - 1, hi = ho * SS + dh - 1;
+            const bool ok = ti >= 0 && ti < g.Ti && hi >= 0 && hi < g.Hi;
+            okr |= ok ? (1u << r) : 0u;
+            const int tc = min(max(ti, 0), g.Ti - 1), hc = min(max(hi, 0), g.Hi - 1);
+            const bf16* row = x + (((long)n * g.Ti + tc) * g.Hi + hc) * (long)g.Wi * g.C + c;
 #pragma unroll
-                for (int i = 0; i < NIN; ++i) {
-                    const int wi = wo0 * SS - 1 + i;
-                    if (wi >= 0 && wi < g.Wi) {
-                        const bf16x4 v = as_bf16x4(*(const uint2*)(row + (long)wi * g.C));
+            for (int i = 0; i < NIN; ++i) {
+                const int wc = min(max(wo0 * SS - 1 + i, 0), g.Wi - 1);
+                raw[r][i] = *(const uint2*)(row + (long)wc * g.C);
+            }
+        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float f = fmaf(bf2f(v[e]), a4[e], b4[e]);
-                            in[i][e] = sc ? fmaxf(f, 0.f) : f;
-                        }
-                    } else {
+        for (int r = 0; r < 9; ++r) {
+            if (!((okr >> r) & 1)) continue;
+            float in[NIN][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) in[i][e] = 0.f;
-                    }
+            for (int i = 0; i < NIN; ++i) {
+                const bf16x4 v = as_bf16x4(raw[r][i]);
+                const bool ok = (wok >> i) & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f = fmaf(bf2f(v[e]), a4[e], b4[e]);
+                    in[i][e] = ok ? (sc ? fmaxf(f, 0.f) : f) : 0.f;
                 }
+            }
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const float4 wv = *(const float4*)&wl[(dt * 3 + dh) * 3 + dw][cl * 4];
-                    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+            for (int dw = 0; dw < 3; ++dw) {
+                const float4 wv = *(const float4*)&wl[r * 3 + dw][cl * 4];
+                const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(in[j * SS + dw][e], ww[e], acc[j][e]);
-                }
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(in[j * SS + dw][e], ww[e], acc[j][e]);
             }
         }
         bf16* orow = out + ((((long)n * g.To + to) * g.Ho + ho) * (long)g.Wo + wo0) * g.C + c;
@@ -134,56 +144,61 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
     for (int it = 0; it < iters; ++it) {
         const long seg = ((long)blockIdx.x * iters + it) * 16 + ps;
         if (seg >= segs) break;
-        int wg = (int)(seg % Wg); long r = seg / Wg;
-        const int hi = (int)(r % g.Hi); r /= g.Hi;
-        const int ti = (int)(r % g.Ti); const int n = (int)(r / g.Ti);
+        const int sg32 = (int)seg;
+        int wg = sg32 % Wg; int r = sg32 / Wg;
+        const int hi = r % g.Hi; r /= g.Hi;
+        const int ti = r % g.Ti; const int n = r / g.Ti;
         const int wi0 = wg * 4;
         float acc[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+        // all 9 x NG gradient vectors are loaded unconditionally from clamped addresses (one latency) and masked afterwards
+        uint2 raw[9][NG];
+        unsigned okr = 0;
+        int wok = 0;
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-            const int tn = ti + 1 - dt;
-            if (tn < 0 || (tn % g.st) != 0) continue;
-            const int to = tn / g.st;
-            if (to >= g.To) continue;
+        for (int i = 0; i < NG; ++i) { const int wo = SS == 1 ? wi0 - 1 + i : (wi0 >> 1) + i; wok |= (wo >= 0 && wo < g.Wo) ? (1 << i) : 0; }
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh) {
-                const int hn = hi + 1 - dh;
-                if (hn < 0 || (hn % SS) != 0) continue;
-                const int ho = hn / SS;
-                if (ho >= g.Ho) continue;
-                const bf16* row = gout + (((long)n * g.To + to) * g.Ho + ho) * (long)g.Wo * g.C + c;
-                // window of output columns: SS=1: wo = wi0-1+i (i<6); SS=2: wo = wi0/2 + i (i<3)
-                float gw[NG][4];
+        for (int r = 0; r < 9; ++r) {
+            const int dt = r / 3, dh = r % 3;
+            const int tn = ti + 1 - dt, hn = hi + 1 - dh;
+            const int to = tn / g.st, ho = hn / SS;
+            const bool ok = tn >= 0 && (tn % g.st) == 0 && to < g.To && hn >= 0 && (hn % SS) == 0 && ho < g.Ho;
+            okr |= ok ? (1u << r) : 0u;
+            const int tc = min(max(to, 0), g.To - 1), hc = min(max(ho, 0), g.Ho - 1);
+            const bf16* row = gout + (((long)n * g.To + tc) * g.Ho + hc) * (long)g.Wo * g.C + c;
 #pragma unroll
-                for (int i = 0; i < NG; ++i) {
-                    const int wo = SS == 1 ? wi0 - 1 + i : (wi0 >> 1) + i;
-                    if (wo >= 0 && wo < g.Wo) {
-                        const bf16x4 v = as_bf16x4(*(const uint2*)(row + (long)wo * g.C));
+            for (int i = 0; i < NG; ++i) {
+                const int wo = SS == 1 ? wi0 - 1 + i : (wi0 >> 1) + i;
+                raw[r][i] = *(const uint2*)(row + (long)min(max(wo, 0), g.Wo - 1) * g.C);
+            }
+        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) gw[i][e] = bf2f(v[e]);
-                    } else {
+        for (int r = 0; r < 9; ++r) {
+            if (!((okr >> r) & 1)) continue;
+            float gw[NG][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) gw[i][e] = 0.f;
-                    }
-                }
+            for (int i = 0; i < NG; ++i) {
+                const bf16x4 v = as_bf16x4(raw[r][i]);
+                const bool ok = (wok >> i) & 1;
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const float4 wv = *(const float4*)&wl[(dt * 3 + dh) * 3 + dw][cl * 4];
-                    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+                for (int e = 0; e < 4; ++e) gw[i][e] = ok ? bf2f(v[e]) : 0.f;
+            }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int num = j + 1 - dw;           // wo*SS = wi0 + num
-                        if (SS == 1) {
+            for (int dw = 0; dw < 3; ++dw) {
+                const float4 wv = *(const float4*)&wl[r * 3 + dw][cl * 4];
+                const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gw[num + 1][e], ww[e], acc[j][e]);
-                        } else if (num >= 0 && (num & 1) == 0) {
+                for (int j = 0; j < 4; ++j) {
+                    const int num = j + 1 - dw;           // wo*SS = wi0 + num
+                    if (SS == 1) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gw[num >> 1][e], ww[e], acc[j][e]);
-                        }
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gw[num + 1][e], ww[e], acc[j][e]);
+                    } else if (num >= 0 && (num & 1) == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gw[num >> 1][e], ww[e], acc[j][e]);
                     }
                 }
             }
@@ -245,9 +260,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
     for (int it = 0; it < iters; ++it) {
         const long seg = ((long)blockIdx.x * iters + it) * 16 + ps;
         if (seg >= segs) break;
-        int wg = (int)(seg % Wg); long r = seg / Wg;
-        const int ho = (int)(r % g.Ho); r /= g.Ho;
-        const int to = (int)(r % g.To); const int n = (int)(r / g.To);
+        const int sg32 = (int)seg;
+        int wg = sg32 % Wg; int r = sg32 / Wg;
+        const int ho = r % g.Ho; r /= g.Ho;
+        const int to = r % g.To; const int n = r / g.To;
         const int wo0 = wg * 4;
         float gv[4][4];
         const bf16* grow = gout + ((((long)n * g.To + to) * g.Ho + ho) * (long)g.Wo + wo0) * g.C + c;
@@ -262,27 +278,35 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
                 for (int e = 0; e < 4; ++e) gv[j][e] = 0.f;
             }
         }
+        int wok = 0;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) { const int wi = wo0 * SS - 1 + i; wok |= (wi >= 0 && wi < g.Wi) ? (1 << i) : 0; }
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) {
             const int ti = to * g.st + dt - 1;
-            if (ti < 0 || ti >= g.Ti) continue;
+            if (ti < 0 || ti >= g.Ti) continue;           // wave-uniform for most waves (a wave spans <= 4 segments)
+            // the 3 x NIN activation vectors of this temporal slab: unconditional clamped loads, masked afterwards
+            uint2 raw[3][NIN];
+            int okh = 0;
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh) {
                 const int hi = ho * SS + dh - 1;
-                if (hi < 0 || hi >= g.Hi) continue;
-                const bf16* row = x + (((long)n * g.Ti + ti) * g.Hi + hi) * (long)g.Wi * g.C + c;
+                okh |= (hi >= 0 && hi < g.Hi) ? (1 << dh) : 0;
+                const bf16* row = x + (((long)n * g.Ti + ti) * g.Hi + min(max(hi, 0), g.Hi - 1)) * (long)g.Wi * g.C + c;
+#pragma unroll
+                for (int i = 0; i < NIN; ++i)
+                    raw[dh][i] = *(const uint2*)(row + (long)min(max(wo0 * SS - 1 + i, 0), g.Wi - 1) * g.C);
+            }
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                if (!((okh >> dh) & 1)) continue;
                 float in[NIN][4];
 #pragma unroll
                 for (int i = 0; i < NIN; ++i) {
-                    const int wi = wo0 * SS - 1 + i;
-                    if (wi >= 0 && wi < g.Wi) {
-                        const bf16x4 v = as_bf16x4(*(const uint2*)(row + (long)wi * g.C));
+                    const bf16x4 v = as_bf16x4(raw[dh][i]);
+                    const bool ok = (wok >> i) & 1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) in[i][e] = fmaxf(fmaf(bf2f(v[e]), a4[e], b4[e]), 0.f);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) in[i][e] = 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) in[i][e] = ok ? fmaxf(fmaf(bf2f(v[e]), a4[e], b4[e]), 0.f) : 0.f;
                 }
 #pragma unroll
                 for (int dw = 0; dw < 3; ++dw) {
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(1024) void dw_wgrad_reduce_kernel(const float* __re
 
 static int dw_blocks(long segs, int* iters) {
     long groups = (segs + 15) / 16;
-    int it = (int)((groups + 1023) / 1024);
+    int it = (int)((groups + 4095) / 4096);     // <= 4096 blocks: one or two segments per thread, latency hidden by occupancy
     if (it < 1) it = 1;
     *iters = it;
     return (int)((groups + it - 1) / it);

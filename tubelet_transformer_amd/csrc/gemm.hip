@@ -83,31 +83,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + q * 8;
     }
 
-    uint4 ra[CA], rb[CB];
-    float4 sc0, sc1, sh0, sh1;
-    auto load_tile = [&](int kt) {
+    // k-tiles are fetched in groups of G: all global loads of a group are in flight together (one HBM latency per
+    // group instead of one per tile -- these GEMMs have K <= 2048, often only 1-4 tiles), then each tile goes
+    // registers -> (BN prologue) -> LDS -> MFMA.
+    constexpr int G = (BM * BN >= 128 * 128) ? 2 : 4;
+    uint4 ra[G][CA], rb[G][CB];
+    float* lsc = (float*)(smem + 2 * STAGE);       // A_BN_RELU: scale[K] | shift[K] staged once
+    float* lsh = lsc + p.K;
+    if (AMODE == A_BN_RELU) {
+        for (int i = tid; i < p.K; i += 256) { lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i]; }
+    }
+    auto load_tile = [&](int kt, uint4 (&xa)[CA], uint4 (&xb)[CB]) {
         const int k0 = kt * 64;
 #pragma unroll
-        for (int i = 0; i < CA; ++i) ra[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < CA; ++i) xa[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < CB; ++i) rb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
-        if (AMODE == A_BN_RELU) {
-            const float4* s = (const float4*)(p.a_scale + k0 + q * 8);
-            const float4* h = (const float4*)(p.a_shift + k0 + q * 8);
-            sc0 = s[0]; sc1 = s[1]; sh0 = h[0]; sh1 = h[1];
-        }
+        for (int i = 0; i < CB; ++i) xb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int kt, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB]) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + BM * 128;
+        float sc[8], sh[8];
+        if (AMODE == A_BN_RELU) {
+            const float4* s4 = (const float4*)(lsc + kt * 64 + q * 8);
+            const float4* h4 = (const float4*)(lsh + kt * 64 + q * 8);
+            const float4 s0 = s4[0], s1 = s4[1], h0 = h4[0], h1 = h4[1];
+            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        }
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const int row = (tid >> 3) + 32 * i;
-            uint4 v = ra[i];
+            uint4 v = xa[i];
             if (AMODE == A_BN_RELU) {
                 bf16x8 x = as_bf16x8(v), y;
-                const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-                const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sc[e], sh[e]), 0.f));
                 v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
             const int row = (tid >> 3) + 32 * i;
-            *(uint4*)(sb + row * 128 + ((q ^ swz_wgt<NT>(row)) << 4)) = rb[i];
+            *(uint4*)(sb + row * 128 + ((q ^ swz_wgt<NT>(row)) << 4)) = xb[i];
         }
     };
 
@@ -134,12 +143,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);
 
-    load_tile(0);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tile(buf);
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -158,7 +162,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
-        buf ^= 1;
+    };
+    int buf = 0;
+    if (AMODE == A_BN_RELU) __syncthreads();            // scale/shift staged
+    for (int g0 = 0; g0 < nk; g0 += G) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (g0 + j < nk) load_tile(g0 + j, ra[j], rb[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (g0 + j < nk) {
+                store_tile(g0 + j, buf, ra[j], rb[j]);
+                __syncthreads();
+                compute(buf);
+                buf ^= 1;
+            }
+        }
     }
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 template <int BM, int BN, int WM, int WN>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : 0);
     dim3 grid(tiles), block(256);
 #define LNT(AM, EP) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AM, EP>), grid, block, lds, s, p)
     if (amode == A_PLAIN) {
@@ -287,7 +306,7 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
 static int nt_pick_cfg(int M, int N) {
     if (N <= 64) return (long)ceil_div(M, 128) >= 256 ? 1 : 2;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    return t128 >= 192 ? 0 : 2;
+    return t128 >= 1024 ? 0 : 2;     // mid-size problems: 64x64 tiles keep >= 4 workgroups per CU in flight
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0) { *bm = 128; *wm = 2; }
@@ -346,7 +365,7 @@ struct GemmTN {
     const bf16* G; long ldg;     // [M, N]
     const bf16* A; long lda;     // [M, K]
     float* P;                    // partials [S][N][K]
-    int M, N, K, S, rows_per_slab;
+    int M, N, K, S, rows_per_slab, accumulate;
     const float* a_scale; const float* a_shift;   // A_BN_RELU on A (per k column)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
 };
@@ -354,7 +373,7 @@ struct GemmTN {
 // transposed staging: the 64 x 128 tile (m x col) is cut in 4x4 blocks; thread -> block
 // (mi = 0..15 along m, ci = 0..31 along col).  Lane mapping keeps 128-byte global segments
 // (16 consecutive ci per row) and spreads the transposed 8-byte LDS writes over banks.
-template <int AMODE>
+template <int AMODE, int NTW>
 __device__ __forceinline__ void tn_stage_store(char* dst, const uint2 (&r)[4], int mi, int ci, bool is_a, bool ok,
                                                const float (&sc)[4], const float (&sh)[4]) {
     // r[j] = row (mi*4 + j), cols ci*4 .. ci*4+3
@@ -374,14 +393,16 @@ __device__ __forceinline__ void tn_stage_store(char* dst, const uint2 (&r)[4], i
         const int col = ci * 4 + c;
         const int chunk = mi >> 1;                      // 16-byte chunk along m (8 per 128-byte row)
         // rows are 128 bytes (64 m); swizzle chunk with the same functions the fragment reads use
-        const int sw = is_a ? swz_act(col) : swz_wgt<4>(col);
+        const int sw = is_a ? swz_act(col) : swz_wgt<NTW>(col);
         *(uint2*)(dst + col * 128 + ((chunk ^ sw) << 4) + ((mi & 1) << 3)) = as_uint2(y);
     }
 }
 
-template <int AMODE>
+// T = output tile edge (128: 2x2 waves of 64x64; 64: 2x2 waves of 32x32 -- 4x more workgroups for small N*K)
+template <int AMODE, int T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
-    constexpr int BN = 128, BKo = 128, TM = 64, TN = 64, MT = 4, NT = 4;
+    constexpr int BN = T, BKo = T, TM = T / 2, TN = T / 2, MT = TM / 16, NT = TN / 16;
+    constexpr int NB = T / 64;                 // 4x4 blocks per thread per operand per 64-row step
     constexpr int STAGE = (BN + BKo) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,36 +416,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     const int m_begin = slab * p.rows_per_slab;
     const int m_end = min(p.M, m_begin + p.rows_per_slab);
 
-    // staging: two 4x4 blocks per thread per operand per step: block id = tid + 256*i -> (mi, ci)
-    // wave covers 4 mi x 16 ci; lane: ci_lo = (l & 3) | ((l >> 4) << 2), mi_lo = (l >> 2) & 3
+    // staging: the 64 x T tile (m x col) of each operand is cut in 4x4 blocks (16 along m, T/4 along col); a wave covers
+    // 4 mi x 16 ci with lane -> (ci_lo = (l&3) | ((l>>4)<<2), mi_lo = (l>>2)&3): 128-byte global segments per row and
+    // 2-way-only LDS write conflicts for the transposed 8-byte stores.
     const int ci_lo = (lane & 3) | ((lane >> 4) << 2);      // 0..15
     const int mi_lo = (lane >> 2) & 3;                       // 0..3
-    // 512 blocks per operand per step (16 mi x 32 ci): wave w, iteration i -> mi_hi = (w*2+i)>>1 ... lay out:
-    // block group id gidx = wave*2 + i in 0..7 -> mi_hi = gidx & 3 (x4 mi), ci_hi = gidx >> 2 (x16 ci)
-    int mi[2], ci[2];
+    int mi[NB], ci[NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gidx = wave * 2 + i;
+    for (int i = 0; i < NB; ++i) {
+        const int gidx = wave * NB + i;                      // 0 .. 4*NB-1 block groups of (4 mi x 16 ci)
         mi[i] = (gidx & 3) * 4 + mi_lo;
         ci[i] = (gidx >> 2) * 16 + ci_lo;
     }
-    float asc[2][4], ash[2][4];
+    float asc[NB][4], ash[NB][4];
+    bool g_col_ok[NB], a_col_ok[NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = k0 + ci[i] * 4 + c;
             asc[i][c] = (AMODE == A_BN_RELU && k < p.K) ? p.a_scale[k] : 1.f;
             ash[i][c] = (AMODE == A_BN_RELU && k < p.K) ? p.a_shift[k] : 0.f;
         }
-    const bool g_col_ok[2] = {n0 + ci[0] * 4 < p.N, n0 + ci[1] * 4 < p.N};   // N, K multiples of 4
-    const bool a_col_ok[2] = {k0 + ci[0] * 4 < p.K, k0 + ci[1] * 4 < p.K};
+        g_col_ok[i] = n0 + ci[i] * 4 < p.N;
+        a_col_ok[i] = k0 + ci[i] * 4 < p.K;
+    }
 
-    uint2 rg[2][4], rav[2][4];
-    bool rok[2][4];
-    auto load_step = [&](int ms) {
+    // 64-row steps are fetched in groups of GS so their global loads overlap (one HBM latency per group)
+    constexpr int GS = 4;
+    uint2 rgs[GS][NB][4], ravs[GS][NB][4];
+    bool roks[GS][NB][4];
+    auto load_step = [&](int ms, uint2 (&rg)[NB][4], uint2 (&rav)[NB][4], bool (&rok)[NB][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = ms + mi[i] * 4 + j;
@@ -441,20 +465,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
                 rav[i][j] = (ok && a_col_ok[i]) ? *(const uint2*)(p.A + arow * p.lda + k0 + ci[i] * 4) : make_uint2(0, 0);
             }
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, const uint2 (&rg)[NB][4], const uint2 (&rav)[NB][4], const bool (&rok)[NB][4]) {
         char* sg = smem + buf * STAGE;       // G^T tile: [n][m]  (MFMA A operand -> "weight" swizzle)
         char* sa = sg + BN * 128;            // A^T tile: [k][m]  (MFMA B operand -> "act" swizzle)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // rows beyond m_end must contribute zero: zero both operands (prologue of zero != 0)
+        for (int i = 0; i < NB; ++i) {
             uint2 g4[4], a4[4];
             bool any_bad = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { g4[j] = rg[i][j]; a4[j] = rav[i][j]; any_bad |= !rok[i][j]; }
             const float one[4] = {1.f, 1.f, 1.f, 1.f}, zero[4] = {0.f, 0.f, 0.f, 0.f};
-            tn_stage_store<A_PLAIN>(sg, g4, mi[i], ci[i], false, true, one, zero);
+            tn_stage_store<A_PLAIN, NT>(sg, g4, mi[i], ci[i], false, true, one, zero);
             if (AMODE == A_BN_RELU && any_bad) {
-                // slow path at the slab tail: transform then zero the invalid rows individually
+                // slab tail: rows beyond m_end must contribute zero (the prologue of a zero row is not zero)
                 bf16x4 x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -464,9 +487,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
                         x[j][c] = rok[i][j] ? f2bf(fmaxf(fmaf(bf2f(x[j][c]), asc[i][c], ash[i][c]), 0.f)) : (bf16)0.f;
                     a4[j] = as_uint2(x[j]);
                 }
-                tn_stage_store<A_PLAIN>(sa, a4, mi[i], ci[i], true, true, one, zero);
+                tn_stage_store<A_PLAIN, NT>(sa, a4, mi[i], ci[i], true, true, one, zero);
             } else {
-                tn_stage_store<AMODE>(sa, a4, mi[i], ci[i], true, true, asc[i], ash[i]);
+                tn_stage_store<AMODE, NT>(sa, a4, mi[i], ci[i], true, true, asc[i], ash[i]);
             }
         }
     };
@@ -479,37 +502,42 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     const int g = lane >> 4, li = lane & 15;
     int a_row[MT], w_row[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_row[i] = wm * TM + i * 16 + li;                       // k index (A^T rows)
+    for (int i = 0; i < MT; ++i) a_row[i] = wm * TM + i * 16 + li;                              // k index (A^T rows)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * 16 + j * 4 + (li & 3);  // n index (G^T rows)
+    for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);  // n index (G^T rows)
 
     int buf = 0;
-    if (m_begin < m_end) load_step(m_begin);
-    for (int ms = m_begin; ms < m_end; ms += 64) {
-        store_step(buf);
-        __syncthreads();
-        if (ms + 64 < m_end) load_step(ms + 64);
-        const char* sg = smem + buf * STAGE;
-        const char* sa = sg + BN * 128;
+    for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int qq = ks * 4 + g;
-            bf16x8 xa[MT], wb[NT];
+        for (int j = 0; j < GS; ++j)
+            if (ms + 64 * j < m_end) load_step(ms + 64 * j, rgs[j], ravs[j], roks[j]);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                xa[i] = as_bf16x8(*(const uint4*)(sa + a_row[i] * 128 + ((qq ^ swz_act(a_row[i])) << 4)));
+        for (int j = 0; j < GS; ++j) {
+            if (ms + 64 * j >= m_end) continue;
+            store_step(buf, rgs[j], ravs[j], roks[j]);
+            __syncthreads();
+            const char* sg = smem + buf * STAGE;
+            const char* sa = sg + BN * 128;
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                wb[j] = as_bf16x8(*(const uint4*)(sg + w_row[j] * 128 + ((qq ^ swz_wgt<4>(w_row[j])) << 4)));
+            for (int ks = 0; ks < 2; ++ks) {
+                const int qq = ks * 4 + g;
+                bf16x8 xa[MT], wb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
+                    xa[i] = as_bf16x8(*(const uint4*)(sa + a_row[i] * 128 + ((qq ^ swz_act(a_row[i])) << 4)));
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                for (int jj = 0; jj < NT; ++jj)
+                    wb[jj] = as_bf16x8(*(const uint4*)(sg + w_row[jj] * 128 + ((qq ^ swz_wgt<NT>(w_row[jj])) << 4)));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[jj], xa[i], acc[i][jj], 0, 0, 0);
+            }
+            buf ^= 1;
         }
-        buf ^= 1;
     }
-    // D[i = n_local][j = k_local]: lane holds k = k0 + wm*64 + mt*16 + li, n = n0 + wn*64 + g*16 + (nt*4 + r)
+    // D[i = n_local][j = k_local]: lane holds k = k0 + wm*TM + mt*16 + li, n = n0 + wn*TN + g*(4NT) + (nt*4 + r)
     float* P = p.P + (long)slab * p.N * p.K;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -519,10 +547,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * TN + g * 16 + j * 4 + r;
-                if (n < p.N) P[(long)n * p.K + k] = acc[i][j][r];
+                const int n = n0 + wn * TN + g * (4 * NT) + j * 4 + r;
+                if (n < p.N) {
+                    float* o = P + (long)n * p.K + k;
+                    *o = (p.S == 1 && p.accumulate) ? *o + acc[i][j][r] : acc[i][j][r];
+                }
             }
     }
+}
+
+// out[j] (+)= sum_s P[s][j], few slabs: one thread per element
+__global__ void reduce_slabs_flat_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += P[(long)s * n + i];
+    out[i] = accumulate ? out[i] + a : a;
 }
 
 // out[j] (+)= sum_s P[s][j]: 32 slab-groups x 32 columns per block, LDS tree over the slab groups
@@ -544,14 +584,23 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 
 extern "C" {
 
-// slabs gemm_tn will use for (M, N, K): the caller sizes the partial buffer as [S][N][K] floats.
+// Tile / slab choice of gemm_tn: 128x128 tiles when they alone give >= 128 workgroups, else 64x64; slabs over M fill the
+// chip to ~256 workgroups but never more than 8 (bounds the fp32 slab traffic to <= the size of the operands) and
+// at least 256 rows each.
+static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
 int tuber_gemm_tn_slabs(int M, int N, int K) {
-    const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
-    int S = ceil_div(768, tiles);
-    const int maxS = ceil_div(M, 256);
+    const int T = tn_tile(N, K);
+    const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
+    long S = (512 + tiles - 1) / tiles;
+    // bound the fp32 slab traffic (S*N*K*4 B written + read) by the size of the operands (2*M*(N+K) B);
+    // tiny outputs (<= 16 tiles: <= 256 KB per slab) may split deeply
+    long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);
+    if (cap < 1) cap = 1;
+    if (S > cap) S = cap;
+    const long maxS = ceil_div(M, 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    return S;
+    return (int)S;
 }
 
 int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* partial, float* out, int accumulate,
@@ -561,21 +610,32 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     // N / K need not be multiples of 4, but G / A must be readable up to ceil4(N) / ceil4(K) columns (padded ld)
     if (M <= 0 || N <= 0 || K <= 0 || (ldg & 3) || (lda & 3) || ldg < ((N + 3) & ~3) || lda < ((K + 3) & ~3)) return TUBER_EINVAL;
     GemmTN p;
-    p.G = (const bf16*)G; p.ldg = ldg; p.A = (const bf16*)A; p.lda = lda; p.P = partial;
+    p.G = (const bf16*)G; p.ldg = ldg; p.A = (const bf16*)A; p.lda = lda;
     p.M = M; p.N = N; p.K = K; p.S = tuber_gemm_tn_slabs(M, N, K);
     int rps = ceil_div(M, p.S);
     rps = ceil_div(rps, 64) * 64;
     p.rows_per_slab = rps;
     p.S = ceil_div(M, rps);
+    p.accumulate = accumulate;
+    p.P = p.S == 1 ? out : partial;            // a single slab writes (or accumulates into) the gradient directly
     p.a_scale = a_scale; p.a_shift = a_shift;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
-    const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
+    const int T = tn_tile(N, K);
+    const int tiles = ceil_div(N, T) * ceil_div(K, T);
     dim3 grid(tiles * p.S), block(256);
-    const size_t lds = 2 * 256 * 128;
-    if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn_kernel<A_BN_RELU>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(gemm_tn_kernel<A_PLAIN>, grid, block, lds, stream, p);
-    const long n = (long)N * K;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 32)), dim3(1024), 0, stream, partial, out, n, p.S, accumulate);
+    const size_t lds = 2 * 2 * T * 128;
+    if (T == 128) {
+        if (amode == A_BN_RELU) hipLaunchKernelGGL((gemm_tn_kernel<A_BN_RELU, 128>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, 128>), grid, block, lds, stream, p);
+    } else {
+        if (amode == A_BN_RELU) hipLaunchKernelGGL((gemm_tn_kernel<A_BN_RELU, 64>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, 64>), grid, block, lds, stream, p);
+    }
+    if (p.S > 1) {
+        const long n = (long)N * K;
+        if (p.S <= 16) hipLaunchKernelGGL(reduce_slabs_flat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);
+        else hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 32)), dim3(1024), 0, stream, partial, out, n, p.S, accumulate);
+    }
     TUBER_RETURN_LAUNCH();
 }
 

@@ -77,7 +77,11 @@ class GraphedTrainStep:
         model, crit, opt = self.model, self.criterion, self.optimizer
         store, _ = model.engine()
         dev = store.device
-        world = getattr(getattr(store, "reducer", None), "world", 1)
+        # the hooks of the eager reducer must not fire inside a stream capture: in graph mode the gradient all-reduce is
+        # issued eagerly between graph B1 (backward) and B2 (optimizer), so detach the reducer for good
+        red = getattr(store, "reducer", None)
+        world = getattr(red, "world", 1) if red is not None else getattr(self, "world", 1)
+        self.world = world
         g = type("Captured", (), {})()
         g.clips = clips.clone()
         g.mask = torch.zeros(clips.shape[0], clips.shape[-2], clips.shape[-1], dtype=torch.bool, device=dev)
@@ -87,6 +91,7 @@ class GraphedTrainStep:
         for _ in range(2):
             train_step(model, crit, opt, NestedTensor(g.clips, g.mask), targets, self.max_norm)
         torch.cuda.synchronize()
+        store.reducer = None
         g.A = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g.A):
             outputs = model(NestedTensor(g.clips, g.mask))
