@@ -236,3 +236,64 @@ def test_flat_gradient_reducer_gloo_world2():
     assert np.array_equal(f0, f1)                                # parameters broadcast from rank 0
     mean = (l0 + l1) / 2
     assert np.allclose(g0, mean, atol=1e-6) and np.allclose(g1, mean, atol=1e-6)   # every slice reduced exactly once
+
+
+# ---------------------------------------------------------------- checkpoints -----------------------
+def test_checkpoint_roundtrip_with_ddp_prefix(tmp_path):
+    from tubelet_transformer_amd import checkpoint as ck
+    cfg = cfg_of("TubeR_CSN50_AVA21")
+    cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+    cfg.CONFIG.LOG.BASE_PATH, cfg.CONFIG.LOG.EXP_NAME = str(tmp_path), "exp"
+    m1, _, _ = build_model(cfg)
+    synth.load_name_hashed(m1, salt=3)
+    path = ck.save_checkpoint(cfg, 7, m1, 0.0, None, None)
+    saved = torch.load(path, weights_only=False)
+    assert all(k.startswith("module.") for k in saved["model"]) and saved["epoch"] == 7      # interchangeable with the reference
+    m2, _, _ = build_model(cfg)
+    cfg.CONFIG.MODEL.PRETRAINED_PATH = path
+    ck.load_model(m2, cfg)
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    # DETR initialisation: transformer.*, bbox_embed.*, first QUERY_NUM query rows from a 'detr.'-prefixed file
+    detr = {"model": {"detr." + k: v.clone() for k, v in m1.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
+    detr["model"]["detr.query_embed.weight"] = torch.arange(100 * 256, dtype=torch.float32).view(100, 256)
+    p2 = str(tmp_path / "detr.pth")
+    torch.save(detr, p2)
+    m3, _, _ = build_model(cfg)
+    ck.load_detr_weights(m3, p2, cfg)
+    assert torch.equal(m3.query_embed.weight, detr["model"]["detr.query_embed.weight"][:15])
+    assert torch.equal(m3.transformer.decoder.norm.weight, m1.transformer.decoder.norm.weight)
+
+
+def test_csn_mat_loader_maps_caffe2_names_and_freezes(tmp_path):
+    import scipy.io as sio
+    from tubelet_transformer_amd import checkpoint as ck
+    from tubelet_transformer_amd.backbone import ResNeXt
+    body = ResNeXt([2, 2, 2, 2])
+    rng = np.random.default_rng(0)
+    mat, count = {}, 0
+
+    def bn(name, c):
+        for sfx in ("_s", "_b", "_rm", "_riv"):
+            mat[name + sfx] = rng.standard_normal((1, c)).astype(np.float32)
+    mat["conv1_w"] = rng.standard_normal((64, 3, 3, 7, 7)).astype(np.float32)
+    bn("conv1_spatbn_relu", 64)
+    for stage in (body.layer1, body.layer2, body.layer3, body.layer4):
+        for blk in stage:
+            for j, conv in ((1, blk.conv1), (3, blk.conv3), (4, blk.conv4)):
+                mat["comp_%d_conv_%d_w" % (count, j)] = rng.standard_normal(tuple(conv.weight.shape)).astype(np.float32)
+                bn("comp_%d_spatbn_%d" % (count, j), conv.weight.shape[0])
+            if blk.down_sample is not None:
+                mat["shortcut_projection_%d_w" % count] = rng.standard_normal(tuple(blk.down_sample[0].weight.shape)).astype(np.float32)
+                bn("shortcut_projection_%d_spatbn" % count, blk.down_sample[0].weight.shape[0])
+            count += 1
+    path = str(tmp_path / "csn.mat")
+    sio.savemat(path, mat)
+    ck.load_csn_mat(body, path, "CSN-TEST", verbose=False)
+    assert np.allclose(body.conv1.weight.detach().numpy(), mat["conv1_w"])
+    assert np.allclose(body.layer3[1].conv3.weight.detach().numpy(), mat["comp_5_conv_3_w"])
+    assert np.allclose(body.layer2[0].down_sample[1].running_var.numpy(), mat["shortcut_projection_2_spatbn_riv"].reshape(-1))
+    assert np.allclose(body.layer4[1].bn4.bias.detach().numpy(), mat["comp_7_spatbn_4_b"].reshape(-1))
+    # tune_point 4 (build_CSN): stem, layer1, layer2 frozen; layer3, layer4 trainable (ir_CSN_152.py:251-254,301-303)
+    assert not body.conv1.weight.requires_grad and not body.layer2[1].bn3.weight.requires_grad
+    assert body.layer3[0].conv1.weight.requires_grad and body.layer4[1].bn4.bias.requires_grad

@@ -274,6 +274,7 @@ class CSNRunner:
         B = saved["stem"][4][0]
         red = getattr(self.store, "reducer", None)
         if red is not None:           # everything behind the body (transformer, heads, pool decoder) is final
+            self.store.side_join()
             red.notify(self.body_end, force=True)
         for d, sv in zip(reversed(self.blocks), reversed(saved["blocks"])):
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
@@ -289,7 +290,8 @@ class CSNRunner:
             dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout)
             dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout) if d["ds"] else None
             # conv4: weight grad (A = relu(bn3(c3)) recomputed on load) and data grad fused with relu/bn3 backward
-            self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
+            with self.store.side(dc4, c3):
+                self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
             R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
             s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
             dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
@@ -298,15 +300,17 @@ class CSNRunner:
             dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             nb = lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
-            lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
-                     To, Hq, Wq, P, st, ss)
+            with self.store.side(dc3, c1):
+                lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
+                         To, Hq, Wq, P, st, ss)
             R1 = lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
             s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
             dz1 = torch.empty(Min, P, dtype=BF, device=dev)
             lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
             dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min)
             # conv1: weight grad and data grad (+ identity shortcut gradient as residual)
-            self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
+            with self.store.side(dc1, x):
+                self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
             dx = torch.empty(Min, cin, dtype=BF, device=dev)
             strided = st != 1 or ss != 1
             if not d["ds"]:
@@ -317,7 +321,8 @@ class CSNRunner:
                 res = None
             if d["ds"]:
                 gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
-                self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
+                with self.store.side(dcd, x):
+                    self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
                 dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
                 lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
                          0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None)
@@ -329,6 +334,7 @@ class CSNRunner:
                 lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
             dy = dx
             if red is not None:
+                self.store.side_join()           # the slice handed to RCCL must include the side-stream weight gradients
                 red.notify(d["off0"])
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
         _, col, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
@@ -339,4 +345,6 @@ class CSNRunner:
         bn = self.stem_bn
         lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
         dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0)
-        self._wgrad(dc0, 64, col, 448, self.stem_g, M0, 64, 441)
+        with self.store.side(dc0, col):
+            self._wgrad(dc0, 64, col, 448, self.stem_g, M0, 64, 441)
+        self.store.side_join()

@@ -19,6 +19,8 @@
 // (a = relu(x*scale[k]+shift[k])), optional strided row gather (down_sample convs).
 // Fused epilogues: bias / ReLU / residual add; per-column partial statistics (sum, sum of
 // squares) for training-mode BatchNorm; ReLU-mask + BN-backward partial statistics.
+#include <cstdlib>
+
 #include "common.h"
 
 enum { A_PLAIN = 0, A_BN_RELU = 1 };
@@ -303,10 +305,17 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
 }
 
 // tile choice: (cfg 0) 128x128, (1) 128x64, (2) 64x64
+static int nt_force_cfg() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("TUBER_NT_CFG"); v = e ? atoi(e) : -1; }
+    return v;
+}
 static int nt_pick_cfg(int M, int N) {
-    if (N <= 64) return (long)ceil_div(M, 128) >= 256 ? 1 : 2;
+    if (nt_force_cfg() >= 0) return nt_force_cfg();       // tuning / experiments only
+    // measured on MI355X (profiles/r01_c_*): the 64x64 tile (4-5 workgroups resident per CU) beats 128x128 on every
+    // HBM-bound / small-K shape of the backbone; 128x128 only pays for the big class-branch GEMMs.
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    return t128 >= 1024 ? 0 : 2;     // mid-size problems: 64x64 tiles keep >= 4 workgroups per CU in flight
+    return (N >= 512 && t128 >= 1024) ? 0 : 2;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0) { *bm = 128; *wm = 2; }

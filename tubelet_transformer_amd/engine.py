@@ -10,6 +10,8 @@ Layout in HBM (per model, per GPU):
                operands of the data-gradient GEMMs; leading dimension padded to a multiple of 64.
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -74,6 +76,7 @@ class ParamStore:
         self.ttable = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
         self.nmat = len(entries)
         self.step_seed = 0
+        self.side_stream, self._side_keep, self._side_dirty = None, [], False
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
 
@@ -100,11 +103,35 @@ class ParamStore:
                 p.grad = want
 
     def zero_grad(self):
+        self.side_join()
         self.gflat.zero_()
         self.ensure_grad_views()
 
+    # -- side stream for weight gradients -----------------------------------------------------
+    # dW GEMMs / depthwise weight gradients / bias column sums feed nothing until the optimizer, so they run on a second
+    # HIP stream concurrently with the data-gradient chain (these kernels are too small to fill 256 CUs on their own).
+    # Inside a hipGraph capture this becomes a fork/join in the graph.
+    @contextlib.contextmanager
+    def side(self, *keep):
+        """``with store.side(t1, t2, ...):`` -- launches inside run on the side stream after everything enqueued so far;
+        the listed tensors (inputs produced on the main stream) are kept alive until ``side_join``."""
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream.wait_stream(torch.cuda.current_stream())
+        self._side_keep.extend(keep)
+        self._side_dirty = True
+        with torch.cuda.stream(self.side_stream):
+            yield
+
+    def side_join(self):
+        if self._side_dirty:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            self._side_dirty = False
+        self._side_keep.clear()
+
     def begin_step(self, train):
         """new forward: call-site salts restart at 0; in training the device seed advances (captured in graphs)."""
+        self.side_join()
         self.step_seed = 0
         if train:
             self.seed.add_(1)

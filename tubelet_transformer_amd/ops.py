@@ -71,12 +71,13 @@ class LinearFn(torch.autograd.Function):
         # weight / bias gradients straight into the flat gradient buffer
         gw = store.gflat.data_ptr() + 4 * (store.offsets[wname] + r0 * K)
         S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-        part = workspace(dev, "tn", S * N * K)
-        lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
-        if bname:
-            gbias = store.gflat.data_ptr() + 4 * (store.offsets[bname] + r0)
-            R = lib.query("tuber_colsum_blocks", M)
-            lib.call("tuber_colsum", gb, workspace(dev, "cs", R * N), gbias, 1, M, N, ldg)
+        with store.side(gb, x):            # weight / bias gradients: off the critical path, on the side stream
+            part = workspace(dev, "tn", S * N * K)
+            lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            if bname:
+                gbias = store.gflat.data_ptr() + 4 * (store.offsets[bname] + r0)
+                R = lib.query("tuber_colsum_blocks", M)
+                lib.call("tuber_colsum", gb, workspace(dev, "cs", R * N), gbias, 1, M, N, ldg)
         dx = None
         if ctx.needs_input_grad[0]:
             toff, NN, KK, ldt = store.tinfo[wname]

@@ -60,6 +60,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
     def step(self, closure=None, max_norm=None):
         """AdamW step; with ``max_norm`` the global-norm clipping is fused in (else call clip_grad_norm_ yourself)."""
         st = self.store
+        st.side_join()
         clip = None
         if max_norm is not None and max_norm > 0:
             clip = self.grad_norm(max_norm)

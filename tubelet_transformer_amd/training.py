@@ -46,6 +46,7 @@ def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0,
     if reducer is not None:
         reducer.begin()
     losses.backward()
+    store.side_join()
     if reducer is not None:
         reducer.finish()
     optimizer.step(max_norm=max_norm if max_norm and max_norm > 0 else None)
@@ -114,6 +115,7 @@ class GraphedTrainStep:
             g.loss = sum(g.loss_dict[k] * wd[k] for k in g.loss_dict if k in wd)
             opt.zero_grad()
             g.loss.backward()
+            store.side_join()
             if world == 1:
                 opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
         g.B2 = None
