@@ -1,0 +1,37 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs, as the MI355X guide
+prescribes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+streaming reads, so the corrected read bytes are 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM section).
+usage: python scripts/rocpd_pmc.py fetch.db write.db [steps]"""
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    T = lambda p: [t for t in tabs if t.startswith(p)][0]
+    kd, ks, pe, ip = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
+    scol = [r[1] for r in cur.execute("pragma table_info(%s)" % ks)]
+    namecol = "display_name" if "display_name" in scol else "kernel_name"
+    q = ("select s.%s, count(*), sum(e.value), sum(d.end - d.start) from %s e join %s p on e.pmc_id = p.id "
+         "join %s d on e.event_id = d.event_id join %s s on d.kernel_id = s.id where p.name = ? group by s.%s" % (namecol, pe, ip, kd, ks, namecol))
+    return {re.sub(r"\s+", " ", r[0]): (r[1], r[2], r[3]) for r in cur.execute(q, (counter,))}
+
+
+f = per_kernel(sys.argv[1], "FETCH_SIZE")
+w = per_kernel(sys.argv[2], "WRITE_SIZE")
+rows = []
+for k in f:
+    n, fk, dur = f[k]
+    wk = w.get(k, (0, 0, 0))[1]
+    rows.append((2 * fk * 1024 + wk * 1024, k, n, fk, wk, dur))
+rows.sort(reverse=True)
+print("# per-kernel HBM traffic (bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE doubled per the gfx950 correction)")
+print("%-100s %7s %14s %14s %14s %12s %9s" % ("kernel", "calls", "fetch_KB(raw)", "write_KB", "traffic_MB", "MB/launch", "GB/s"))
+tot = 0
+for tb, k, n, fk, wk, dur in rows[:45]:
+    tot += tb
+    print("%-100s %7d %14.0f %14.0f %14.1f %12.2f %9.1f" % (k[:98], n, fk, wk, tb / 1e6, tb / 1e6 / n, tb / max(dur, 1)))
+print("# total traffic of listed kernels: %.2f GB" % (tot / 1e9))

@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_k = (p.K + BKo - 1) / BKo;
-    int b = blockIdx.x;
+    // XCD-aware order: the tiles of one M-slab read the same G / A rows, so they get consecutive logical ids (= one XCD's L2)
+    int b = xcd_remap(blockIdx.x, gridDim.x);
     const int slab = b / (tiles_n * tiles_k);
     b -= slab * tiles_n * tiles_k;
     const int tile_n = b % tiles_n, tile_k = b / tiles_n;
