@@ -60,6 +60,14 @@ def alg_cost(name, a):
         return "block_out_bwd_kernel", 2 * (5 if a[3] is not None else 4) * a[8] * a[9], 0
     if name == "tuber_bn_bwd_apply":
         return "bn_bwd_apply_kernel", 2 * 3 * a[6] * a[7], 0
+    if name == "tuber_stem_conv_fwd":
+        B, T, H, W = a[5:9]
+        Mo = B * T * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        return "stem_conv_fwd_kernel", 4 * B * 3 * T * H * W + 2 * Mo * 64, 2 * Mo * 64 * 441
+    if name == "tuber_stem_conv_bwd_weight":
+        B, T, H, W = a[5:9]
+        Mo = B * T * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        return "stem_conv_bwd_w_kernel", 4 * B * 3 * T * H * W + 2 * Mo * 64, 2 * Mo * 64 * 441
     if name == "tuber_stem_im2col":
         N, T, H, W, Ho, Wo = a[2:8]
         return "stem_im2col_kernel", 4 * N * 3 * T * H * W + 2 * N * T * Ho * Wo * 448, 0

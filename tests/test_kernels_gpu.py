@@ -366,8 +366,8 @@ def test_attention_strided_maps_and_dropout(dev):
     assert 0.02 < rel < 0.6
 
 
-def test_stem(dev):
-    N, T, H, W = 1, 4, 30, 38
+@pytest.mark.parametrize("N,T,H,W", [(1, 4, 30, 38), (2, 3, 64, 340)])
+def test_stem(dev, N, T, H, W):
     clip = rnd(N, 3, T, H, W, dev=dev, seed=1)
     w = rnd(64, 3, 3, 7, 7, dev=dev, seed=2, scale=441 ** -0.5)
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
@@ -379,6 +379,23 @@ def test_stem(dev):
     C, st0, st1 = gemm_nt(col, wb, M, 64, 448, epi=1)
     ref = F.conv3d(bfr(clip), bfr(w), stride=(1, 2, 2), padding=(1, 3, 3)).permute(0, 2, 3, 4, 1).reshape(M, 64)
     close("stem conv via im2col+gemm", C, ref)
+    # implicit-GEMM stem conv (the shipped path): forward + BN partial stats + weight gradient
+    wp = torch.zeros(64, 512, device=dev, dtype=BF)
+    lib.call("tuber_stem_pack_weight", w.contiguous(), wp)
+    R = lib.query("tuber_stem_conv_blocks", N, T, H, W)
+    c2 = torch.empty(M, 64, device=dev, dtype=BF)
+    a0, a1 = torch.zeros(R, 64, device=dev), torch.zeros(R, 64, device=dev)
+    lib.call("tuber_stem_conv_fwd", clip, wp, c2, a0, a1, N, T, H, W)
+    close("stem conv implicit gemm", c2, ref)
+    close("stem conv implicit stats sum", a0.sum(0), ref.sum(0), abs_=2e-3 * float(ref.abs().sum(0).max()))
+    close("stem conv implicit stats sumsq", a1.sum(0), (ref * ref).sum(0), rel=2e-3)
+    gg = rnd(M, 64, dev=dev, seed=8).to(BF)
+    wr = bfr(w).clone().requires_grad_(True)
+    F.conv3d(bfr(clip), wr, stride=(1, 2, 2), padding=(1, 3, 3)).backward(gg.float().view(N, T, Ho, Wo, 64).permute(0, 4, 1, 2, 3))
+    dwt = torch.zeros(64, 441, device=dev)
+    part = torch.empty(min(R, 256) * 512 * 64, device=dev)
+    lib.call("tuber_stem_conv_bwd_weight", clip, gg, part, dwt, 0, N, T, H, W)
+    close("stem conv implicit dW", dwt, wr.grad.view(64, 441), rel=2e-3)
     # pool fwd
     sc, sh = 1 + 0.1 * rnd(64, dev=dev, seed=3), 0.1 * rnd(64, dev=dev, seed=4)
     Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1

@@ -144,7 +144,7 @@ class CSNRunner:
 
         self.stem_w32 = store.flat.data_ptr() + 4 * store.offsets[prefix + "conv1.weight"]
         self.stem_g = store.gflat.data_ptr() + 4 * store.offsets[prefix + "conv1.weight"]
-        self.stem_wpad = torch.zeros(64, 448, dtype=BF, device=dev)
+        self.stem_wpad = torch.zeros(64, 512, dtype=BF, device=dev)      # k' = (c,kt,kh)*8 + kw packing of conv1.weight
         self.stem_bn = mk_bn(prefix + "bn1", body.bn1)
         for li in range(1, 5):
             layer = getattr(body, "layer%d" % li)
@@ -205,16 +205,23 @@ class CSNRunner:
         dev = self.dev
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         M0 = B * T * Ho * Wo
-        lib.call("tuber_cast_pad_rows", self.stem_w32, self.stem_wpad, 64, 441, 448)
-        col = torch.empty(M0, 448, dtype=BF, device=dev)
-        lib.call("tuber_stem_im2col", clips, col, B, T, H, W, Ho, Wo)
+        # stem conv: implicit GEMM straight from the fp32 clip (no patch matrix in HBM), BN statistics fused
+        lib.call("tuber_stem_pack_weight", self.stem_w32, self.stem_wpad)
         c0 = torch.empty(M0, 64, dtype=BF, device=dev)
-        self._gemm_stats(col, 448, self.stem_wpad, 448, c0, M0, 64, 448, 0, None, None, None, self.stem_bn, train)
+        bn0 = self.stem_bn
+        if train:
+            R = lib.query("tuber_stem_conv_blocks", B, T, H, W)
+            st0, st1 = self.ws("st0", R * 64), self.ws("st1", R * 64)
+            lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, st0, st1, B, T, H, W)
+            self._bn_train(bn0, st0, st1, R, M0)
+        else:
+            lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, None, None, B, T, H, W)
+            self._bn_eval(bn0)
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         x = torch.empty(B * T * Hp * Wp, 64, dtype=BF, device=dev)
         arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
         lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
-        saved = {"stem": (clips.shape, col if train else None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": []}
+        saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": []}
         Ti, Hi, Wi = T, Hp, Wp
         for d in self.blocks:
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
@@ -337,7 +344,7 @@ class CSNRunner:
                 self.store.side_join()           # the slice handed to RCCL must include the side-stream weight gradients
                 red.notify(d["off0"])
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
-        _, col, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
+        clips, _, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
         M0 = B * T * Ho * Wo
         R = lib.query("tuber_stem_pool_bwd_stat_rows", M0)
         s0, s1 = self.ws("st0", R * 64), self.ws("st1", R * 64)
@@ -345,6 +352,8 @@ class CSNRunner:
         bn = self.stem_bn
         lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
         dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0)
-        with self.store.side(dc0, col):
-            self._wgrad(dc0, 64, col, 448, self.stem_g, M0, 64, 441)
+        H, W = clips.shape[-2:]
+        with self.store.side(dc0, clips):
+            nwg = min(lib.query("tuber_stem_conv_blocks", B, T, H, W), 256)
+            lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
         self.store.side_join()
