@@ -82,6 +82,9 @@ def shape_of(name, a):
     if name in ("tuber_attn_fwd", "tuber_attn_bwd"):
         off = 10 if name == "tuber_attn_fwd" else 19
         return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])
+    if name in ("tuber_bn_bwd_apply", "tuber_block_out_fwd", "tuber_block_out_bwd", "tuber_bn_finalize", "tuber_bn_bwd_finalize",
+                "tuber_reduce_rows", "tuber_colsum", "tuber_reduce_slabs", "tuber_layernorm_fwd", "tuber_layernorm_bwd", "tuber_dropout"):
+        return " ".join(str(x) for x in a if isinstance(x, int) and not isinstance(x, bool))[:44]
     if name.startswith("tuber_dwconv"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
         return "N%d in%dx%dx%d out%dx%dx%d C%d st%d ss%d" % tuple(a[off:off + 10])
@@ -245,7 +248,7 @@ def main():
         lib.set_launch_hook(None)
         prepass = timer.summary()
         if os.environ.get("TUBER_BENCH_SHAPES") and rank == 0:
-            print("\n".join(timer.by_shape()), file=sys.stderr, flush=True)
+            print("\n".join(timer.by_shape(int(os.environ["TUBER_BENCH_SHAPES"]))), file=sys.stderr, flush=True)
         dominant = max((k for k in prepass if prepass[k]["bytes"] > 0), key=lambda k: prepass[k]["ms"])
     fence()
     t0 = time.perf_counter()

@@ -1,0 +1,66 @@
+"""Isolated timing of tuber_gemm_nt / tuber_gemm_tn on the backbone's shapes under forced tile configurations.
+usage: python scripts/gemm_bench.py [nt|tn]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tubelet_transformer_amd import lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+NT_SHAPES = [  # (M, N, K, amode, epi, residual)
+    (5632, 256, 1024, 0, 1, 0), (5632, 1024, 256, 1, 1, 0), (5632, 256, 1024, 0, 2, 0), (5632, 1024, 256, 0, 0, 0),
+    (44032, 128, 512, 0, 1, 0), (44032, 512, 128, 1, 1, 0), (44032, 128, 512, 0, 2, 0), (44032, 512, 128, 0, 0, 0),
+    (348160, 64, 256, 0, 1, 0), (348160, 256, 64, 1, 1, 0), (348160, 64, 256, 0, 2, 0), (348160, 256, 64, 0, 0, 0),
+    (704, 512, 2048, 0, 1, 0), (704, 2048, 512, 1, 1, 0), (704, 256, 256, 0, 0, 0), (30, 256, 256, 0, 0, 0),
+    (16896, 2048, 512, 0, 0, 0),
+]
+
+
+def time_it(fn, iters=20, reps=5):
+    """GPU-side time per launch: `iters` back-to-back launches captured in a hipGraph (no host launch cost), replayed."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (iters * reps) * 1e3
+
+
+def bench_nt(cfgs):
+    print("%-34s" % "shape (M N K amode epi)" + "".join("  cfg%d us" % c for c in cfgs))
+    for M, N, K, amode, epi, res in NT_SHAPES:
+        A = torch.randn(M, K, device=dev).to(BF)
+        B = torch.randn(N, K, device=dev).to(BF)
+        C = torch.empty(M, N, device=dev, dtype=BF)
+        Cm = torch.randn(M, N, device=dev).to(BF)
+        sc, sh = torch.rand(max(K, N), device=dev) + 0.5, torch.randn(max(K, N), device=dev)
+        st0, st1 = torch.empty(M // 32 + 8, N, device=dev), torch.empty(M // 32 + 8, N, device=dev)
+        row = "%-34s" % ("%d %d %d %d %d" % (M, N, K, amode, epi))
+        for c in cfgs:
+            lib.call("tuber_gemm_nt_set_cfg", c)
+
+            def fn():
+                lib.call("tuber_gemm_nt", A, K, B, K, C, N, M, N, K, amode, sc if amode else None, sh if amode else None,
+                         0, 0, 0, 0, 0, 0, 0, 0, 0, epi, None, None, 0, 0, 0, st0 if epi else None, st1 if epi else None,
+                         Cm if epi == 2 else None, N, sc if epi == 2 else None, sh if epi == 2 else None, 1.0, 0.0, None, 0)
+            row += "  %7.1f" % time_it(fn)
+        by = 2 * (M * K + N * K + M * N) + (2 * M * N if epi == 2 else 0)
+        print(row + "   | alg %.1f MB, %.2f GF" % (by / 1e6, 2 * M * N * K / 1e9), flush=True)
+    lib.call("tuber_gemm_nt_set_cfg", -1)
+
+
+if __name__ == "__main__":
+    bench_nt([int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5".split(","))])

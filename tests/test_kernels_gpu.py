@@ -41,7 +41,7 @@ def gemm_nt(A, B, M, N, K, amode=0, sc=None, sh=None, gather=None, epi=0, bias=N
     st1 = torch.zeros(rows, N, device=dev) if epi else None
     g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
     lib.call("tuber_gemm_nt", A, lda or K, B, K, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, epi, bias, R, N, relu,
-             out_f32, st0, st1, Cm, N, msc, msh)
+             out_f32, st0, st1, Cm, N, msc, msh, 1.0, 0.0, None, 0)
     return C, st0, st1
 
 
@@ -269,7 +269,7 @@ def test_layernorm(dev, M, E):
     y = torch.empty(M, E, device=dev, dtype=BF)
     xh = torch.empty(M, E, device=dev, dtype=BF)
     rstd = torch.empty(M, device=dev)
-    lib.call("tuber_layernorm_fwd", x, r, g, b, y, xh, rstd, M, E, 1e-5)
+    lib.call("tuber_layernorm_fwd", x, r, g, b, y, E, xh, rstd, M, E, 1e-5, 0.0, None, 0)
     xin = (x.float() + r.float()).requires_grad_(True)
     gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = F.layer_norm(xin, (E,), gp, bp, 1e-5)
@@ -279,14 +279,92 @@ def test_layernorm(dev, M, E):
     nb = lib.query("tuber_layernorm_bwd_blocks", M)
     part = torch.empty(2 * nb * E, device=dev)
     dx = torch.empty(M, E, device=dev, dtype=BF)
-    dg, db = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
-    lib.call("tuber_layernorm_bwd", dy, xh, rstd, g, dx, part, dg, db, 0, M, E)
+    # adjacent (one reduction launch) and separate dgamma / dbeta buffers
+    dgb = torch.zeros(2 * E, device=dev)
+    lib.call("tuber_layernorm_bwd", dy, E, xh, rstd, g, dx, None, part, dgb, dgb.data_ptr() + 4 * E, 0, M, E, 0.0, None, 0)
     close("layernorm bwd dx", dx, xin.grad, rel=2 ** -6)
-    close("layernorm bwd dgamma", dg, gp.grad, rel=1e-2)
-    close("layernorm bwd dbeta", db, bp.grad, rel=1e-2)
+    close("layernorm bwd dgamma", dgb[:E], gp.grad, rel=1e-2)
+    close("layernorm bwd dbeta", dgb[E:], bp.grad, rel=1e-2)
+    dg, db = torch.ones(E, device=dev), torch.ones(E, device=dev)
+    lib.call("tuber_layernorm_bwd", dy, E, xh, rstd, g, dx, None, part, dg, db, 1, M, E, 0.0, None, 0)
+    close("layernorm bwd dgamma (accumulate, separate)", dg - 1, gp.grad, rel=1e-2)
+    close("layernorm bwd dbeta (accumulate, separate)", db - 1, bp.grad, rel=1e-2)
     y2 = torch.empty(M, E, device=dev, dtype=BF)
-    lib.call("tuber_layernorm_fwd", x, None, g, b, y2, None, None, M, E, 1e-5)
+    lib.call("tuber_layernorm_fwd", x, None, g, b, y2, E, None, None, M, E, 1e-5, 0.0, None, 0)
     close("layernorm fwd (no res)", y2, F.layer_norm(x.float(), (E,), g, b, 1e-5))
+
+
+@pytest.mark.parametrize("M,E", [(704, 256), (77, 2048)])
+def test_layernorm_dropout_and_window(dev, M, E):
+    """LayerNorm(Dropout(x) + res) written into a column window of a wider buffer; the mask is the one tuber_dropout makes."""
+    p, salt = 0.1, 7
+    seed = torch.tensor([1234], dtype=torch.int64, device=dev)
+    x = rnd(M, E, dev=dev, seed=1).to(BF)
+    r = rnd(M, E, dev=dev, seed=2).to(BF)
+    g, b = 1 + 0.1 * rnd(E, dev=dev, seed=3), 0.1 * rnd(E, dev=dev, seed=4)
+    ones = torch.ones(M, E, device=dev, dtype=BF)
+    keep = torch.empty_like(ones)
+    lib.call("tuber_dropout", ones, keep, M * E, p, seed, salt)
+    keep = keep.float()                                       # 0 or 1/(1-p)
+    assert 0.85 < float((keep > 0).float().mean()) < 0.95
+    wide = torch.zeros(M + 3, 2 * E, device=dev, dtype=BF)
+    xh = torch.empty(M, E, device=dev, dtype=BF)
+    rstd = torch.empty(M, device=dev)
+    lib.call("tuber_layernorm_fwd", x, r, g, b, wide.data_ptr() + 2 * (2 * (2 * E) + E), 2 * E, xh, rstd, M, E, 1e-5, p, seed, salt)
+    xin = x.float().requires_grad_(True)
+    rin = r.float().requires_grad_(True)
+    ref = F.layer_norm(xin * keep + rin, (E,), g, b, 1e-5)
+    close("layernorm(dropout) fwd window", wide[2:2 + M, E:], ref.detach())
+    assert float(wide[:2].abs().max()) == 0 and float(wide[2:2 + M, :E].abs().max()) == 0 and float(wide[2 + M:].abs().max()) == 0
+    dyw = rnd(M + 3, 2 * E, dev=dev, seed=5).to(BF)
+    ref.backward(dyw[2:2 + M, E:].float())
+    nb = lib.query("tuber_layernorm_bwd_blocks", M)
+    part = torch.empty(2 * nb * E, device=dev)
+    dx, dxd = torch.empty(M, E, device=dev, dtype=BF), torch.empty(M, E, device=dev, dtype=BF)
+    dg, db = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    lib.call("tuber_layernorm_bwd", dyw.data_ptr() + 2 * (2 * (2 * E) + E), 2 * E, xh, rstd, g, dx, dxd, part, dg, db, 0, M, E, p, seed, salt)
+    close("layernorm(dropout) bwd d res", dx, rin.grad, rel=2 ** -6)
+    close("layernorm(dropout) bwd d x", dxd, xin.grad, rel=2 ** -6)
+
+
+def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
+    """FFN pieces: h = Dropout(ReLU(x W1^T + b)) as one GEMM; the backward mask alpha*g*[h>0] as the epilogue of the next dgrad."""
+    M, K, N, p, salt = 300, 256, 512, 0.1, 11
+    seed = torch.tensor([99], dtype=torch.int64, device=dev)
+    x = rnd(M, K, dev=dev, seed=1).to(BF)
+    w = (rnd(N, K, dev=dev, seed=2) / 16).to(BF)
+    bias = 0.1 * rnd(N, dev=dev, seed=3)
+    h = torch.empty(M, N, device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt", x, K, w, K, h, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+             0, bias, None, 0, 1, 0, None, None, None, 0, None, None, 1.0, p, seed, salt)
+    ones = torch.ones(M, N, device=dev, dtype=BF)
+    keep = torch.empty_like(ones)
+    lib.call("tuber_dropout", ones, keep, M * N, p, seed, salt)
+    ref = torch.relu(x.float() @ w.float().t() + bias) * keep.float()
+    close("gemm relu+dropout epilogue", h, ref)
+    # masked data gradient: dpre = alpha * (g W2) * [h > 0], W2 [K2, N]
+    K2 = 256
+    g = rnd(M, K2, dev=dev, seed=4).to(BF)
+    w2t = (rnd(N, K2, dev=dev, seed=5) / 16).to(BF)            # W2^T rows = N (output features of the dgrad GEMM)
+    dpre = torch.empty(M, N, device=dev, dtype=BF)
+    alpha = 1.0 / (1.0 - p)
+    lib.call("tuber_gemm_nt", g, K2, w2t, K2, dpre, N, M, N, K2, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+             2, None, None, 0, 0, 0, None, None, h, N, None, None, alpha, 0.0, None, 0)
+    refd = alpha * (g.float() @ w2t.float().t()) * (h.float() > 0)
+    close("gemm masked dgrad epilogue", dpre, refd)
+    gm = torch.empty_like(dpre)
+    lib.call("tuber_relu_mask", g.new_ones(M, N), h, gm, M * N, alpha)
+    close("relu_mask alpha", gm, alpha * (h.float() > 0))
+
+
+@pytest.mark.parametrize("M,C,ld", [(704, 256, 256), (30, 2048, 2048), (180, 3, 64), (24, 3840, 3840), (16896, 512, 512), (5000, 80, 128)])
+def test_colsum(dev, M, C, ld):
+    g = rnd(M, ld, dev=dev, seed=1).to(BF)
+    out = torch.ones(C, device=dev)
+    part = torch.empty(lib.query("tuber_colsum_blocks", M) * C, device=dev)
+    lib.call("tuber_colsum", g, part, out, 1, M, C, ld)
+    ref = g.float()[:, :C].sum(0)
+    close("colsum M%d C%d" % (M, C), out - 1, ref, abs_=2e-3 * float(g.float().abs().sum(0).max()))
 
 
 def attn_ref(q, k, v, kpm, scale):

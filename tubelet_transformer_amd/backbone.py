@@ -191,11 +191,11 @@ class CSNRunner:
             R = lib.query("tuber_gemm_nt_stat_rows", M, N)
             st0, st1 = self.ws("st0", R * N), self.ws("st1", R * N)
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 1, None, None, 0, 0, 0,
-                     st0, st1, None, 0, None, None)
+                     st0, st1, None, 0, None, None, 1.0, 0.0, None, 0)
             self._bn_train(bn, st0, st1, R, M)
         else:
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 0, None, None, 0, 0, 0,
-                     None, None, None, 0, None, None)
+                     None, None, None, 0, None, None, 1.0, 0.0, None, 0)
             self._bn_eval(bn)
 
     # -- forward ------------------------------------------------------------------------------------
@@ -303,7 +303,7 @@ class CSNRunner:
             s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
             dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
             lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift)
+                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0)
             dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             nb = lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
@@ -332,11 +332,11 @@ class CSNRunner:
                     self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
                 dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
                 lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
-                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None)
+                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
                 if not strided:
                     res = dxd
             lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, res, cin, 0, 0, None, None, None, 0, None, None)
+                     0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
             if d["ds"] and strided:
                 lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
             dy = dx

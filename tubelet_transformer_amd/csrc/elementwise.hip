@@ -89,14 +89,15 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __
     if (i < n) dx[i] = dy[i] * y[i] * (1.f - y[i]);
 }
 
-// dx = dy * [h > 0]   (ReLU backward from the saved post-activation)
-__global__ void relu_mask_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h, bf16* __restrict__ dx, long n8) {
+// dx = alpha * dy * [h > 0]   (ReLU backward from the saved post-activation; alpha = 1/(1-p) when Dropout followed the ReLU:
+// a dropped element has h == 0 as well)
+__global__ void relu_mask_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h, bf16* __restrict__ dx, long n8, float alpha) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const bf16x8 g = as_bf16x8(((const uint4*)dy)[i]);
         const bf16x8 a = as_bf16x8(((const uint4*)h)[i]);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = bf2f(a[e]) > 0.f ? g[e] : (bf16)0.f;
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(a[e]) > 0.f ? f2bf(bf2f(g[e]) * alpha) : (bf16)0.f;
         ((uint4*)dx)[i] = as_uint4(o);
     }
 }
@@ -220,9 +221,9 @@ int tuber_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, hipStr
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, dy, y, dx, n);
     TUBER_RETURN_LAUNCH();
 }
-int tuber_relu_mask(const void* dy, const void* h, void* dx, long n, hipStream_t stream) {
+int tuber_relu_mask(const void* dy, const void* h, void* dx, long n, float alpha, hipStream_t stream) {
     if (n & 7) return TUBER_EINVAL;
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)h, (bf16*)dx, n / 8);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)h, (bf16*)dx, n / 8, alpha);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_posenc(const void* mask, void* out, int B, int T, int H, int W, int hidden, hipStream_t stream) {

@@ -36,14 +36,16 @@ struct GemmNT {
     const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
     const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
+    float alpha;                                  // accumulators are scaled by alpha before the epilogue
+    uint32_t drop_thresh; float drop_inv_keep; const uint64_t* seed_ptr; uint64_t salt;   // EPI_PLAIN: Dropout after bias/residual/ReLU
 };
 
 __device__ __forceinline__ int swz_act(int row) { return (row >> 1) & 7; }
 template <int NT>
 __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI>
+__global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gemm_nt_kernel(GemmNT p) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
     constexpr int STAGE = (BM + BN) * 128;
@@ -88,13 +90,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     // k-tiles are fetched in groups of G: all global loads of a group are in flight together (one HBM latency per
     // group instead of one per tile -- these GEMMs have K <= 2048, often only 1-4 tiles), then each tile goes
     // registers -> (BN prologue) -> LDS -> MFMA.
-    constexpr int G = (BM * BN >= 128 * 128) ? 2 : 4;
     uint4 ra[G][CA], rb[G][CB];
     float* lsc = (float*)(smem + 2 * STAGE);       // A_BN_RELU: scale[K] | shift[K] staged once
     float* lsh = lsc + p.K;
-    if (AMODE == A_BN_RELU) {
-        for (int i = tid; i < p.K; i += 256) { lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i]; }
-    }
     auto load_tile = [&](int kt, uint4 (&xa)[CA], uint4 (&xb)[CB]) {
         const int k0 = kt * 64;
 #pragma unroll
@@ -165,16 +163,37 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
     };
-    int buf = 0;
-    if (AMODE == A_BN_RELU) __syncthreads();            // scale/shift staged
-    for (int g0 = 0; g0 < nk; g0 += G) {
+    // ---- first k-group and the epilogue's side inputs go out before anything waits ----
+    constexpr int NC = 4 * NT;
+    const int nb = n0 + wn * TN + g * NC;
+    const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
 #pragma unroll
-        for (int j = 0; j < G; ++j)
-            if (g0 + j < nk) load_tile(g0 + j, ra[j], rb[j]);
+    for (int j = 0; j < G; ++j)
+        if (j < nk) load_tile(j, ra[j], rb[j]);
+    uint4 side[EPI == EPI_BWD ? MT : 1][NC / 8];         // EPI_BWD: the mask source c, fetched behind the k-loop
+    const bool side_vec = EPI == EPI_BWD && vec_ok && ((p.ldcm & 7) == 0);
+    if (EPI == EPI_BWD && side_vec) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * TM + i * 16 + li;
+#pragma unroll
+            for (int c8 = 0; c8 < NC / 8; ++c8)
+                side[EPI == EPI_BWD ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (AMODE == A_BN_RELU) {
+        for (int i = tid; i < p.K; i += 256) { lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i]; }
+        __syncthreads();
+    }
+    // software pipeline over k-tiles: register set j holds tile g0+j; as soon as it has been written to LDS the same
+    // registers are re-armed with tile g0+G+j, so G tiles of global loads stay in flight behind the MFMA work.
+    int buf = 0;
+    for (int g0 = 0; g0 < nk; g0 += G) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (g0 + j < nk) {
                 store_tile(g0 + j, buf, ra[j], rb[j]);
+                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j]);
                 __syncthreads();
                 compute(buf);
                 buf ^= 1;
@@ -183,9 +202,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     }
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
-    constexpr int NC = 4 * NT;
-    const int nb = n0 + wn * TN + g * NC;
-    const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
     float s0[NC], s1[NC];
     if (EPI != EPI_PLAIN) {
 #pragma unroll
@@ -208,19 +224,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha;
         if (EPI == EPI_PLAIN) {
             if (p.bias) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += p.bias[nb + c];
             }
             if (p.R && mok) {
+                if (vec_ok && (p.ldr & 7) == 0) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                    for (int c8 = 0; c8 < NC / 8; ++c8) {
+                        const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + (long)m * p.ldr + nb + c8 * 8));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[c8 * 8 + e] += bf2f(rv[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+            if (p.drop_thresh) {
+                const uint64_t seed = (p.seed_ptr ? *p.seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + p.salt;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    v[c] = dropout_keep(seed, (uint64_t)m * p.N + nb + c, p.drop_thresh) ? v[c] * p.drop_inv_keep : 0.f;
             }
         } else if (EPI == EPI_STATS) {
 #pragma unroll
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if (nb + c < p.N) {
-                        const float cv = bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
+                        const float cv = side_vec ? bf2f(as_bf16x8(side[EPI == EPI_BWD ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
                         const float z = fmaf(cv, msc[c], msh[c]);
                         v[c] = z > 0.f ? v[c] : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
@@ -285,12 +316,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int G>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : 0);
     dim3 grid(tiles), block(256);
-#define LNT(AM, EP) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AM, EP>), grid, block, lds, s, p)
+#define LNT(AM, EP) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>), grid, block, lds, s, p)
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
@@ -305,10 +336,10 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
 }
 
 // tile choice: (cfg 0) 128x128, (1) 128x64, (2) 64x64
+static int g_nt_force = -2;
 static int nt_force_cfg() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("TUBER_NT_CFG"); v = e ? atoi(e) : -1; }
-    return v;
+    if (g_nt_force == -2) { const char* e = getenv("TUBER_NT_CFG"); g_nt_force = e ? atoi(e) : -1; }
+    return g_nt_force;
 }
 static int nt_pick_cfg(int M, int N) {
     if (nt_force_cfg() >= 0) return nt_force_cfg();       // tuning / experiments only
@@ -318,8 +349,8 @@ static int nt_pick_cfg(int M, int N) {
     return (N >= 512 && t128 >= 1024) ? 0 : 2;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
-    if (cfg == 0) { *bm = 128; *wm = 2; }
-    else if (cfg == 1) { *bm = 128; *wm = 4; }
+    if (cfg == 0 || cfg == 3) { *bm = 128; *wm = 2; }
+    else if (cfg == 1 || cfg == 5) { *bm = 128; *wm = 4; }
     else { *bm = 64; *wm = 2; }
 }
 
@@ -329,6 +360,8 @@ extern "C" {
 // [rows][N] floats and hands the same row count to the finalize kernels.
 // tile configuration tuber_gemm_nt picks for (M, N): 0 = 128x128, 1 = 128x64, 2 = 64x64 (profiling / tests)
 int tuber_gemm_nt_cfg(int M, int N) { return nt_pick_cfg(M, N); }
+
+int tuber_gemm_nt_set_cfg(int cfg) { g_nt_force = cfg < 0 ? -1 : cfg; return 0; }
 
 int tuber_gemm_nt_stat_rows(int M, int N) {
     int bm, wm;
@@ -342,21 +375,29 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
                   int epi, const float* bias, const void* R, long ldr, int relu, int out_f32,
                   float* stat0, float* stat1,
                   const void* Cm, long ldcm, const float* m_scale, const float* m_shift,
+                  float alpha, float drop_p, const void* seed_ptr, unsigned long long salt,
                   hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7)) return TUBER_EINVAL;
     if (amode == A_BN_RELU && (!a_scale || !a_shift)) return TUBER_EINVAL;
     if (epi == EPI_BWD && !Cm) return TUBER_EINVAL;
     if (epi != EPI_PLAIN && out_f32) return TUBER_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && epi != EPI_PLAIN)) return TUBER_EINVAL;
     GemmNT p;
+    p.alpha = alpha;
+    p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_inv_keep = 1.f / (1.f - drop_p);
+    p.seed_ptr = (const uint64_t*)seed_ptr; p.salt = (uint64_t)salt;
     p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.a_scale = a_scale; p.a_shift = a_shift;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
     switch (nt_pick_cfg(M, N)) {
-        case 0: return launch_nt_cfg<128, 128, 2, 2>(p, amode, epi, stream);
-        case 1: return launch_nt_cfg<128, 64, 4, 1>(p, amode, epi, stream);
-        default: return launch_nt_cfg<64, 64, 2, 2>(p, amode, epi, stream);
+        case 0: return launch_nt_cfg<128, 128, 2, 2, 2>(p, amode, epi, stream);
+        case 1: return launch_nt_cfg<128, 64, 4, 1, 2>(p, amode, epi, stream);
+        case 3: return launch_nt_cfg<128, 128, 2, 2, 4>(p, amode, epi, stream);
+        case 4: return launch_nt_cfg<64, 64, 2, 2, 8>(p, amode, epi, stream);
+        case 5: return launch_nt_cfg<128, 64, 4, 1, 4>(p, amode, epi, stream);
+        default: return launch_nt_cfg<64, 64, 2, 2, 4>(p, amode, epi, stream);
     }
 }
 

@@ -19,7 +19,9 @@ DOC = {
                      "(BatchNorm apply, ir_CSN_152.py:72-79) into the A load; gather=1 reads A rows through the strided "
                      "(n,t*st,h*ss,w*ss) map of the down_sample conv (:155-161). epi 0: +bias, +R, ReLU, bf16|fp32 out; "
                      "epi 1: bf16 out + per-column partial (sum, sum^2) rows for training-mode BatchNorm; epi 2: out = acc*[Cm*m_scale+m_shift>0] "
-                     "+ partial (sum dz, sum dz*Cm) rows for BatchNorm backward. K % 64 == 0.",
+                     "+ partial (sum dz, sum dz*Cm) rows for BatchNorm backward (stat rows optional: with m_scale NULL it is the ReLU / ReLU+Dropout "
+                     "backward mask from the saved activation). Accumulators are scaled by alpha first; epi 0 can end with Dropout(drop_p) "
+                     "keyed by (seed, salt, m*N+n) -- FFN linear1 (transformer.py:160-162). K % 64 == 0.",
     "tuber_gemm_nt_cfg": "tile configuration tuber_gemm_nt uses for (M,N): 0 = 128x128, 1 = 128x64, 2 = 64x64.",
     "tuber_gemm_nt_stat_rows": "rows of partial statistics tuber_gemm_nt(epi 1|2) writes for (M,N).",
     "tuber_gemm_tn": "dW[N,K] (+)= sum_m G[m,N]^T . f(A)[m,K]: weight gradient of the same convs / linears (autograd of the ops above); "
@@ -41,13 +43,14 @@ DOC = {
     "tuber_block_out_bwd": "backward of the join: dz = dy*[y>0] and the partial statistics of bn4 (and of the down_sample BN).",
     "tuber_relu_bn_bwd_reduce": "dz = g*[x*sc+sh>0] + partial (sum dz, sum dz*x): backward of relu(bn(x)) when not fused elsewhere.",
     "tuber_rowblock_count": "partial-stat rows written by the row-blocked reduce kernels for M rows.",
-    "tuber_layernorm_fwd": "y = LayerNorm(x (+ res)) over E in {256, 2048}, eps 1e-5 (nn.LayerNorm, transformer.py:163-167,229-247,116-123; "
+    "tuber_layernorm_fwd": "y = LayerNorm(Dropout_p(x) (+ res)) over E in {256, 2048}, eps 1e-5 (nn.LayerNorm, transformer.py:163-167,229-247,116-123; "
                            "transformer_layers.py:84,91,96,437-445); saves xhat (bf16) and rstd for backward.",
-    "tuber_layernorm_bwd": "LayerNorm backward: dx (= gradient of both x and res) and dgamma/dbeta via block partials.",
+    "tuber_layernorm_bwd": "backward of tuber_layernorm_fwd: dx (gradient of res), dxd (gradient of x through the regenerated dropout mask) and dgamma/dbeta via block partials.",
     "tuber_layernorm_bwd_blocks": "blocks used by tuber_layernorm_bwd (partial = 2*blocks*E floats).",
     "tuber_reduce_rows": "out[c] (+)= sum_r P[r][c].",
     "tuber_colsum_blocks": "row blocks (size of `partial` / C) used by tuber_colsum.",
     "tuber_colsum": "bias gradient: out[c] (+)= sum_m g[m][c] for bf16 g.",
+    "tuber_gemm_nt_set_cfg": "tuning hook: force tile configuration cfg for every later tuber_gemm_nt (-1 = automatic choice).",
     "tuber_stem_conv_fwd": "stem Conv3d(3,64,(3,7,7),s=(1,2,2),p=(1,3,3)) (ir_CSN_152.py:109-115) as an implicit MFMA GEMM from the fp32 NCDHW clip to NDHWC bf16, "
                            "with the partial statistics of the following BatchNorm; Wp = tuber_stem_pack_weight(conv1.weight).",
     "tuber_stem_conv_bwd_weight": "weight gradient of the stem conv ([64][441] fp32) as an implicit MFMA GEMM (no patch matrix in HBM).",

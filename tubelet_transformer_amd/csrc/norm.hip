@@ -12,6 +12,54 @@
 // ---------------------------------------------------------------------------------------------
 // finalize kernels: one block per 32 channels, 1024 threads = 32 row-groups x 32 channels
 // ---------------------------------------------------------------------------------------------
+// column sums of the partial-statistics rows st0/st1 [R][C] for channels c0..c0+31 (1024 threads): thread = (row group
+// of 128, channel quad); 16-byte loads, 4 row iterations in flight, double accumulation; the result for channel c0+cl is
+// returned in threads 0..31 (cl = threadIdx.x).
+__device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, int c0,
+                                                double (&red)[2][32][33], double& a_out, double& b_out) {
+    const int qd = threadIdx.x & 7, rq = threadIdx.x >> 3;       // 8 quads x 128 row groups
+    const int cq = c0 + qd * 4;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (cq < C) {                                                // C % 4 == 0
+        int r = rq;
+        for (; r + 384 < R; r += 512) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = *(const float4*)(st0 + (long)(r + 128 * u) * C + cq);
+                y[u] = *(const float4*)(st1 + (long)(r + 128 * u) * C + cq);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[0] += x[u].x; a[1] += x[u].y; a[2] += x[u].z; a[3] += x[u].w;
+                b[0] += y[u].x; b[1] += y[u].y; b[2] += y[u].z; b[3] += y[u].w;
+            }
+        }
+        for (; r < R; r += 128) {
+            const float4 x = *(const float4*)(st0 + (long)r * C + cq), y = *(const float4*)(st1 + (long)r * C + cq);
+            a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+            b[0] += y.x; b[1] += y.y; b[2] += y.z; b[3] += y.w;
+        }
+    }
+    // 128 row groups -> 16 (one per wave) via shuffles over the lanes sharing qd (lane bits 3..5), then LDS
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) { a[e] += __shfl_xor(a[e], off, 64); b[e] += __shfl_xor(b[e], off, 64); }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][wave][lane * 4 + e] = a[e]; red[1][wave][lane * 4 + e] = b[e]; }
+    }
+    __syncthreads();
+    a_out = 0.0; b_out = 0.0;
+    if (threadIdx.x < 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a_out += red[0][i][threadIdx.x]; b_out += red[1][i][threadIdx.x]; }
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -21,14 +69,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = rg; r < R; r += 32) { a += (double)st0[(long)r * C + c]; b += (double)st1[(long)r * C + c]; }
-    red[0][rg][cl] = a; red[1][rg][cl] = b;
-    __syncthreads();
+    double a, b;
+    bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
-        a = 0.0; b = 0.0;
-        for (int i = 0; i < 32; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
         const double mean = a / (double)count;
         double var = b / (double)count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -66,14 +109,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = rg; r < R; r += 32) { a += (double)st0[(long)r * C + c]; b += (double)st1[(long)r * C + c]; }
-    red[0][rg][cl] = a; red[1][rg][cl] = b;
-    __syncthreads();
+    double a, b;
+    bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
-        a = 0.0; b = 0.0;
-        for (int i = 0; i < 32; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
         const double mu = mean[c], r = invstd[c], g = gamma[c];
         const double sum_dz = a, sum_dz_xhat = (b - mu * a) * r;
         const double m1 = sum_dz / count, m2 = sum_dz_xhat / count;
@@ -234,13 +272,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 template <int EPL>   // elements per lane = E / 64 (4 for E=256, 32 for E=2048)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     const bf16* __restrict__ x, const bf16* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
-    bf16* __restrict__ y, bf16* __restrict__ xhat_out, float* __restrict__ rstd_out, int M, float eps) {
+    bf16* __restrict__ y, long ldy, bf16* __restrict__ xhat_out, float* __restrict__ rstd_out, int M, float eps,
+    uint32_t thresh, float inv_keep, const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
     constexpr int E = EPL * 64;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float v[EPL];
     const long base = (long)row * E;
+    const uint64_t seed = thresh ? (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt : 0ull;
 #pragma unroll
     for (int i = 0; i < EPL / 4; ++i) {
         const int col = (i * 64 + lane) * 4;
@@ -248,7 +288,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
         bf16x4 r = bf16x4{};
         if (res) r = as_bf16x4(*(const uint2*)(res + base + col));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i * 4 + e] = bf2f(a[e]) + (res ? bf2f(r[e]) : 0.f);
+        for (int e = 0; e < 4; ++e) {
+            float xv = bf2f(a[e]);
+            if (thresh) xv = dropout_keep(seed, (uint64_t)(base + col + e), thresh) ? xv * inv_keep : 0.f;   // Dropout(x) + res
+            v[i * 4 + e] = xv + (res ? bf2f(r[e]) : 0.f);
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -270,7 +314,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
             xh[e] = f2bf(h);
             o[e] = f2bf(fmaf(h, gg[e], bb[e]));
         }
-        *(uint2*)(y + base + col) = as_uint2(o);
+        *(uint2*)(y + (long)row * ldy + col) = as_uint2(o);
         if (xhat_out) *(uint2*)(xhat_out + base + col) = as_uint2(xh);
     }
     if (rstd_out && lane == 0) rstd_out[row] = rstd;
@@ -280,10 +324,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 // over the rows of each block (blocks write [gridDim.x][E] partials).
 template <int EPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
-    const bf16* __restrict__ dy, const bf16* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ gamma,
-    bf16* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb, int M, int rows_per_block) {
+    const bf16* __restrict__ dy, long lddy, const bf16* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    bf16* __restrict__ dx, bf16* __restrict__ dxd, float* __restrict__ part, int M, int rows_per_block,
+    uint32_t thresh, float inv_keep, const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
     constexpr int E = EPL * 64;
     __shared__ float red[2][4][E];
+    const uint64_t seed = thresh ? (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt : 0ull;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float ag[EPL], ab[EPL];
 #pragma unroll
@@ -301,7 +347,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < EPL / 4; ++i) {
             const int col = (i * 64 + lane) * 4;
-            const bf16x4 a = as_bf16x4(*(const uint2*)(dy + base + col));
+            const bf16x4 a = as_bf16x4(*(const uint2*)(dy + (long)row * lddy + col));
             const bf16x4 b = as_bf16x4(*(const uint2*)(xhat + base + col));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { d[i * 4 + e] = bf2f(a[e]); h[i * 4 + e] = bf2f(b[e]); }
@@ -319,10 +365,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < EPL / 4; ++i) {
             const int col = (i * 64 + lane) * 4;
-            bf16x4 o;
+            bf16x4 o, od;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(rs * (d[i * 4 + e] * gm[i * 4 + e] - s1 - h[i * 4 + e] * s2));
-            *(uint2*)(dx + base + col) = as_uint2(o);
+            for (int e = 0; e < 4; ++e) {
+                const float gxe = rs * (d[i * 4 + e] * gm[i * 4 + e] - s1 - h[i * 4 + e] * s2);
+                o[e] = f2bf(gxe);
+                od[e] = (!thresh || dropout_keep(seed, (uint64_t)(base + col + e), thresh)) ? f2bf(gxe * inv_keep) : (bf16)0.f;
+            }
+            if (dx) *(uint2*)(dx + base + col) = as_uint2(o);              // gradient of the residual input
+            if (dxd) *(uint2*)(dxd + base + col) = as_uint2(od);           // gradient of x through Dropout
         }
     }
 #pragma unroll
@@ -335,18 +386,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         }
     __syncthreads();
     for (int col = threadIdx.x; col < E; col += 256) {
-        pg[(long)blockIdx.x * E + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
-        pb[(long)blockIdx.x * E + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        part[(long)blockIdx.x * 2 * E + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+        part[(long)blockIdx.x * 2 * E + E + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
     }
 }
 
 // out[c] (+)= sum_r P[r][c]   (column reduce of partial rows; also used for bias gradients)
-__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ P, float* __restrict__ out, int R, int C, int accumulate) {
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ P, float* __restrict__ out, int R, int C, int accumulate,
+                                                           long ldp) {
     __shared__ float red[32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float a = 0.f;
-    if (c < C) for (int r = rg; r < R; r += 32) a += P[(long)r * C + c];
+    if (c < C) for (int r = rg; r < R; r += 32) a += P[(long)r * ldp + c];
     red[rg][cl] = a;
     __syncthreads();
     if (rg == 0 && c < C) {
@@ -356,35 +408,47 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
     }
 }
 
-// partial column sums of a bf16 [M, ld] matrix (bias gradient): block (bx, by) sums rows
-// [bx*rpb, (bx+1)*rpb) of the 8-column groups by*256 .. ; writes P[bx][C].  16-byte loads, thread = 8 columns.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ P, long M, int C, long ld,
-                                                             long rows_per_block) {
-    __shared__ float red[256][8 + 1];
-    const int groups = (C + 7) >> 3;                     // 8-column groups in a row
-    const int tpr = groups < 256 ? groups : 256;         // threads per row in this block
-    const int rpp = 256 / tpr;                           // rows per pass
-    const int cg = blockIdx.y * 256 + threadIdx.x % tpr;
-    const int rs = threadIdx.x / tpr;
+// partial column sums of a bf16 [M, ld] matrix (bias gradient): block (bx, by) sums rows [bx*rpb, (bx+1)*rpb) of the
+// 64 columns by*64.. ; thread = (row lane of 32, 8-column group of 8): 128-byte row segments, 4 rows in flight.
+// With one row block the result goes straight to out (+= when accumulate); otherwise to P[bx][C].
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ P, float* __restrict__ out,
+                                                             int accumulate, long M, int C, long ld, long rows_per_block) {
+    __shared__ float red[32][8][9];
+    const int groups = (C + 7) >> 3;
+    const int gl = threadIdx.x & 7, rs = threadIdx.x >> 3;
+    const int cg = blockIdx.y * 8 + gl;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    if (cg < groups && rs < rpp) {
-        for (long r = r0 + rs; r < r1; r += rpp) {
-            const bf16x8 v = as_bf16x8(*(const uint4*)(g + r * ld + cg * 8));
+    if (cg < groups) {
+        long r = r0 + rs;
+        for (; r + 96 < r1; r += 128) {
+            uint4 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(g + (r + 32 * u) * ld + cg * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 x = as_bf16x8(v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf2f(x[e]);
+            }
+        }
+        for (; r < r1; r += 32) {
+            const bf16x8 x = as_bf16x8(*(const uint4*)(g + r * ld + cg * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(x[e]);
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    for (int e = 0; e < 8; ++e) red[rs][gl][e] = acc[e];
     __syncthreads();
-    if (threadIdx.x < tpr && cg < groups) {
+    const int og = threadIdx.x >> 3, oe = threadIdx.x & 7;       // threads 0..63 = 8 groups x 8 columns
+    const int col = (blockIdx.y * 8 + og) * 8 + oe;
+    if (threadIdx.x < 64 && col < C) {
+        float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = 0.f;
-            for (int s = 0; s < rpp; ++s) a += red[s * tpr + threadIdx.x][e];
-            if (cg * 8 + e < C) P[(long)blockIdx.x * C + cg * 8 + e] = a;
-        }
+        for (int s = 0; s < 32; ++s) a += red[s][og][oe];
+        if (gridDim.x == 1) out[col] = accumulate ? out[col] + a : a;
+        else P[(long)blockIdx.x * C + col] = a;
     }
 }
 
@@ -466,50 +530,75 @@ int tuber_bn_bwd_apply(const void* dz, const void* x, const float* cA, const flo
     TUBER_RETURN_LAUNCH();
 }
 
-int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* xhat, float* rstd,
-                        int M, int E, float eps, hipStream_t stream) {
+// y = LayerNorm(Dropout_p(x) + res): res may be NULL, p may be 0; y rows have leading dimension ldy (>= E) so two LayerNorms can
+// write the halves of one concatenated buffer; xhat [M,E] and rstd [M] are saved for the backward (NULL in eval).
+int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, long ldy, void* xhat, float* rstd,
+                        int M, int E, float eps, float p, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
+    if (ldy < E || (ldy & 3) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
     dim3 grid(ceil_div(M, 4)), block(256);
-    if (E == 256) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, (bf16*)y, (bf16*)xhat, rstd, M, eps);
-    else if (E == 2048) hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, (bf16*)y, (bf16*)xhat, rstd, M, eps);
+    const uint32_t th = (uint32_t)((double)p * 4294967296.0);
+    const float ik = 1.f / (1.f - p);
+#define LNF(EPL) hipLaunchKernelGGL(layernorm_fwd_kernel<EPL>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, \
+                                    (bf16*)y, ldy, (bf16*)xhat, rstd, M, eps, th, ik, (const uint64_t*)seed_ptr, (uint64_t)salt)
+    if (E == 256) LNF(4);
+    else if (E == 2048) LNF(32);
     else return TUBER_EINVAL;
+#undef LNF
     TUBER_RETURN_LAUNCH();
 }
 
 int tuber_layernorm_bwd_blocks(int M) { const int nb = ceil_div(M, 64); return nb > 512 ? 512 : nb; }
 
-// partial must hold 2 * blocks * E floats; dgamma/dbeta are (accumulated into or) written
-int tuber_layernorm_bwd(const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, float* partial,
-                        float* dgamma, float* dbeta, int accumulate, int M, int E, hipStream_t stream) {
+// backward of tuber_layernorm_fwd: dx = gradient w.r.t. res (and w.r.t. x when p == 0), dxd = gradient w.r.t. x through the
+// dropout mask (either may be NULL); dy rows have leading dimension lddy.  partial must hold 2 * blocks * E floats;
+// dgamma/dbeta are accumulated into or written.
+int tuber_layernorm_bwd(const void* dy, long lddy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dxd,
+                        float* partial, float* dgamma, float* dbeta, int accumulate, int M, int E,
+                        float p, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
+    if (lddy < E || (lddy & 3) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
     const int nb = tuber_layernorm_bwd_blocks(M);
     int rpb = ceil_div(M, nb);
     rpb = ceil_div(rpb, 4) * 4;
-    float* pg = partial;
-    float* pb = partial + (long)nb * E;
     dim3 grid(nb), block(256);
-    if (E == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, (const bf16*)dy, (const bf16*)xhat, rstd, gamma, (bf16*)dx, pg, pb, M, rpb);
-    else if (E == 2048) hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, stream, (const bf16*)dy, (const bf16*)xhat, rstd, gamma, (bf16*)dx, pg, pb, M, rpb);
+    const uint32_t th = (uint32_t)((double)p * 4294967296.0);
+    const float ik = 1.f / (1.f - p);
+#define LNB(EPL) hipLaunchKernelGGL(layernorm_bwd_kernel<EPL>, grid, block, 0, stream, (const bf16*)dy, lddy, (const bf16*)xhat, rstd, gamma, \
+                                    (bf16*)dx, (bf16*)dxd, partial, M, rpb, th, ik, (const uint64_t*)seed_ptr, (uint64_t)salt)
+    if (E == 256) LNB(4);
+    else if (E == 2048) LNB(32);
     else return TUBER_EINVAL;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, pg, dgamma, nb, E, accumulate);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, pb, dbeta, nb, E, accumulate);
+#undef LNB
+    if (dbeta == dgamma + E) {        // weight and bias adjacent in the flat gradient buffer: one reduction over [nb][2E]
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(2 * E, 32)), dim3(1024), 0, stream, partial, dgamma, nb, 2 * E, accumulate, (long)2 * E);
+    } else {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, partial, dgamma, nb, E, accumulate, (long)2 * E);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, partial + E, dbeta, nb, E, accumulate, (long)2 * E);
+    }
     TUBER_RETURN_LAUNCH();
 }
 
 int tuber_reduce_rows(const float* P, float* out, int R, int C, int accumulate, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, P, out, R, C, accumulate);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, P, out, R, C, accumulate, (long)C);
     TUBER_RETURN_LAUNCH();
 }
 
 // dbias[c] (+)= sum_m g[m][c] for bf16 g [M, ld] (ld % 8 == 0, readable up to ceil8(C) columns);
 // partial must hold tuber_colsum_blocks(M) * C floats
-int tuber_colsum_blocks(long M) { long nb = (M + 63) / 64; return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb)); }
+int tuber_colsum_blocks(long M) {
+    if (M <= 4096) return 1;
+    long nb = (M + 255) / 256;
+    return (int)(nb > 256 ? 256 : nb);
+}
 
 int tuber_colsum(const void* g, float* partial, float* out, int accumulate, long M, int C, long ld, hipStream_t stream) {
     if (M <= 0 || C <= 0 || (ld & 7) || ld < ((C + 7) & ~7)) return TUBER_EINVAL;
     const int nb = tuber_colsum_blocks(M);
     const long rpb = (M + nb - 1) / nb;
     const int groups = (C + 7) / 8;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (groups + 255) / 256), dim3(256), 0, stream, (const bf16*)g, partial, M, C, ld, rpb);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, partial, out, nb, C, accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (groups + 7) / 8), dim3(256), 0, stream, (const bf16*)g, partial, out, accumulate,
+                       M, C, ld, rpb);
+    if (nb > 1)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, partial, out, nb, C, accumulate, (long)C);
     TUBER_RETURN_LAUNCH();
 }
 

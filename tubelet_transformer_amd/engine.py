@@ -11,6 +11,7 @@ Layout in HBM (per model, per GPU):
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -115,6 +116,9 @@ class ParamStore:
     def side(self, *keep):
         """``with store.side(t1, t2, ...):`` -- launches inside run on the side stream after everything enqueued so far;
         the listed tensors (inputs produced on the main stream) are kept alive until ``side_join``."""
+        if os.environ.get("TUBER_NO_SIDE_STREAM"):      # profiling: every launch on one stream, in program order
+            yield
+            return
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream(device=self.device)
         self.side_stream.wait_stream(torch.cuda.current_stream())

@@ -40,7 +40,7 @@ class LinearFn(torch.autograd.Function):
         bias = store.flat.data_ptr() + 4 * (store.offsets[bname] + r0) if bname else None
         y = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF, device=x.device)
         lib.call("tuber_gemm_nt", x, K, wb, K, y, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                 0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None)
+                 0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
         ctx.store, ctx.meta = store, (wname, bname, r0, r1, relu, out_f32, M, N, K)
         ctx.save_for_backward(x, y if relu else None)
         return y
@@ -87,7 +87,7 @@ class LinearFn(torch.autograd.Function):
             assert Kred % 64 == 0, "row slices must be multiples of 64"
             dx = torch.empty(M, K, dtype=BF, device=dev)
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, None, 0, 0, 0, None, None, None, 0, None, None)
+                     0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
         return dx, None, None, None, None, None, None, None, None
 
 

@@ -1,0 +1,437 @@
+"""Hand-scheduled forward/backward of the transformer / head part of TubeR over the C ABI.
+
+The transformer half of the training step is ~250 small launches forward and, under torch.autograd, ~950 backward (gradient
+accumulation adds, zero fills, contiguous copies, one kernel per dropout ...).  On MI355X every launch costs 4-8 us of GPU
+time even inside a hipGraph, so this module keeps its own tape instead: each op launches its forward kernels and records
+one backward closure; ``Tape.backward`` replays them in reverse.  What that buys over autograd:
+
+* gradient accumulation is fused into the producing GEMM (``R`` residual input of tuber_gemm_nt) -- a tensor consumed by
+  several ops never costs an add kernel unless two non-GEMM producers meet;
+* Dropout is fused into the consumer: LayerNorm(Dropout(x) + res) is one kernel forward and one backward (the mask is
+  regenerated from the seed), FFN ReLU+Dropout is the epilogue of linear1, and its backward mask is the epilogue of linear2's
+  data-gradient GEMM;
+* ``with_pos_embed`` adds whose second operand has no gradient are aliases in the backward (no kernel);
+* LayerNorms write straight into row / column slices of the consumer's buffer (decoder layer stack ``hs``, the class branch's
+  concatenated [t | s] features), so there are no cat / stack copies in either direction.
+
+Activations are 2-D token-major bf16 tensors [rows, E]; parameter gradients are accumulated by the kernels straight into the
+ParamStore's flat fp32 gradient buffer.  Reference modules: models/transformer/transformer.py, transformer_layers.py,
+models/tuber_ava.py:97-157.
+"""
+import numpy as np
+import torch
+
+from . import lib
+
+BF = torch.bfloat16
+_WS = {}
+
+
+def workspace(dev, key, numel):
+    t = _WS.get((dev, key))
+    if t is None or t.numel() < numel:
+        t = torch.empty(int(numel * 1.25) + 64, dtype=torch.float32, device=dev)
+        _WS[(dev, key)] = t
+    return t
+
+
+def _ceil(x, m):
+    return (x + m - 1) // m * m
+
+
+def _map(ld, sL, s1=0, s2=0, B2=1):
+    return np.array([ld, sL, s1, s2, B2], dtype=np.int64)
+
+
+class Tape:
+    def __init__(self, store, train):
+        self.store, self.train, self.dev = store, train, store.device
+        self.ops = []          # backward closures, forward order
+        self.g = {}            # id(tensor) -> gradient tensor
+        self.alias = {}        # id(tensor) -> tensor that receives its gradient (x + const)
+        self.mask = {}         # id(h) -> 1/(1-p): h = Dropout(ReLU(.)) whose backward mask the consumer's dgrad GEMM applies
+        self.premasked = set()
+        self.stack = {}        # id(tensor) -> list of gradient tensors summed lazily by the producer's backward
+
+    # -- gradient bookkeeping -------------------------------------------------------------------
+    def rec(self, fn):
+        if self.train:
+            self.ops.append(fn)
+
+    def target(self, t):
+        while id(t) in self.alias:
+            t = self.alias[id(t)]
+        return t
+
+    def take(self, t):
+        return self.g.pop(id(self.target(t)), None)
+
+    def peek(self, t):
+        return self.g.get(id(self.target(t)))
+
+    def set(self, t, g):
+        self.g[id(self.target(t))] = g
+
+    def put(self, t, g):
+        """deposit g for t; adds to an existing gradient (one axpby launch) when a GEMM could not fuse the accumulation."""
+        t = self.target(t)
+        if id(t) in self.stack:
+            self.stack[id(t)].append(g)
+            return
+        cur = self.g.get(id(t))
+        if cur is None:
+            self.g[id(t)] = g
+        else:
+            out = torch.empty_like(cur)
+            lib.call("tuber_axpby", cur, g, out, cur.numel(), 1.0, 1.0)
+            self.g[id(t)] = out
+
+    def backward(self, seeds):
+        for t, g in seeds:
+            if g is not None:
+                self.put(t, g)
+        for fn in reversed(self.ops):
+            fn()
+        self.clear()
+
+    def clear(self):
+        self.ops.clear(); self.g.clear(); self.alias.clear(); self.mask.clear(); self.premasked.clear(); self.stack.clear()
+
+    def salt(self):
+        self.store.step_seed += 1
+        return self.store.step_seed
+
+
+# --------------------------------------------------------------------------------------------------
+# ops
+# --------------------------------------------------------------------------------------------------
+def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=0.0):
+    """y = [Dropout]([relu](x @ W[r0:r1]^T + b[r0:r1])) -- nn.Linear / packed in-projection slices / 1x1x1 Conv3d."""
+    st = tp.store
+    M, K = x.shape
+    if rows is None:
+        rows = (0, st.module.get_parameter(wname).shape[0])
+    r0, r1 = rows
+    N = r1 - r0
+    dev = x.device
+    wb = st.shadow.data_ptr() + 2 * (st.offsets[wname] + r0 * K)
+    bias = st.flat.data_ptr() + 4 * (st.offsets[bname] + r0) if bname else None
+    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF, device=dev)
+    p = float(drop)
+    salt = tp.salt() if p > 0.0 else 0
+    lib.call("tuber_gemm_nt", x, K, wb, K, y, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+             0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt)
+    if not tp.train:
+        return y
+    inv_keep = 1.0 / (1.0 - p)
+    if relu:
+        tp.mask[id(y)] = inv_keep
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        Np = _ceil(N, 64)
+        if g.dtype != BF:
+            gb = torch.empty(M, Np, dtype=BF, device=dev)
+            lib.call("tuber_cast_pad_rows", g if g.dtype == torch.float32 else g.float(), gb, M, N, Np)
+            ldg = Np
+        elif Np != N:
+            gb = torch.zeros(M, Np, dtype=BF, device=dev)
+            gb[:, :N] = g
+            ldg = Np
+        else:
+            gb, ldg = g, N
+        if relu and id(y) not in tp.premasked:
+            gm = torch.empty_like(gb)
+            lib.call("tuber_relu_mask", gb, y, gm, M * N, inv_keep)       # dropped elements have y == 0 too
+            gb = gm
+        elif p > 0.0 and not relu:
+            assert ldg == N
+            gm = torch.empty_like(gb)
+            lib.call("tuber_dropout", gb, gm, M * N, p, st.seed, salt)    # same (seed, salt, m*N+n) stream as the epilogue
+            gb = gm
+        gw = st.gflat.data_ptr() + 4 * (st.offsets[wname] + r0 * K)
+        with st.side(gb, x):               # weight / bias gradients feed nothing until the optimizer
+            S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            if bname:
+                gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0)
+                lib.call("tuber_colsum", gb, workspace(dev, "cs", lib.query("tuber_colsum_blocks", M) * N), gbias, 1, M, N, ldg)
+        # data gradient; accumulation with an existing gradient of x and the ReLU/Dropout mask of x are GEMM epilogues
+        toff, _, _, ldt = st.tinfo[wname]
+        wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
+        Kred = Np if (r0 == 0 and Np <= ldt) else N             # padded columns of both operands are zero
+        assert Kred % 64 == 0, "row slices must be multiples of 64"
+        tx = tp.target(x)
+        dx = torch.empty(M, K, dtype=BF, device=dev)
+        if id(tx) in tp.stack:
+            lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+            tp.put(tx, dx)
+            return
+        r = tp.g.pop(id(tx), None)
+        if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous()):
+            tp.g[id(tx)] = r
+            r = None
+        if id(tx) in tp.mask and r is None and tx is x:
+            lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     2, None, None, 0, 0, 0, None, None, x, K, None, None, tp.mask[id(tx)], 0.0, None, 0)
+            tp.premasked.add(id(tx))
+        else:
+            lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     0, None, r, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+        tp.put(tx, dx)
+    tp.rec(bwd)
+    return y
+
+
+def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
+    """LayerNorm(Dropout_p(x) + res).  ``out`` = (base, row0, col0): write into base[row0:row0+M, col0:col0+E] (the consumer reads
+    ``base``; the gradient is read from the same window of base's gradient) -- returns base then."""
+    st = tp.store
+    M, E = x.shape
+    dev = x.device
+    gamma = st.flat.data_ptr() + 4 * st.offsets[prefix + ".weight"]
+    beta = st.flat.data_ptr() + 4 * st.offsets[prefix + ".bias"]
+    if out is None:
+        y, ldy, yptr = torch.empty(M, E, dtype=BF, device=dev), E, None
+        yptr = y.data_ptr()
+    else:
+        base, row0, col0 = out
+        ldy = base.shape[1]
+        yptr = base.data_ptr() + 2 * (row0 * ldy + col0)
+        y = base
+    p = float(drop)
+    salt = tp.salt() if p > 0.0 else 0
+    xhat = torch.empty(M, E, dtype=BF, device=dev) if tp.train else None
+    rstd = torch.empty(M, dtype=torch.float32, device=dev) if tp.train else None
+    lib.call("tuber_layernorm_fwd", x, res, gamma, beta, yptr, ldy, xhat, rstd, M, E, 1e-5, p, st.seed, salt)
+    if not tp.train:
+        return y
+
+    def bwd():
+        if out is None:
+            g = tp.take(y)
+            if g is None:
+                return
+            gptr, ldg = g.data_ptr(), E
+        else:
+            g = tp.peek(base)               # shared with the other writers of base; dropped when the tape is cleared
+            if g is None:
+                return
+            assert g.dtype == BF and g.is_contiguous() and g.shape[1] == ldy
+            gptr, ldg = g.data_ptr() + 2 * (row0 * ldy + col0), ldy
+        dgamma = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".weight"]
+        dbeta = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".bias"]
+        nb = lib.query("tuber_layernorm_bwd_blocks", M)
+        need_res = res is not None or p == 0.0
+        dx = torch.empty(M, E, dtype=BF, device=dev) if need_res else None
+        dxd = torch.empty(M, E, dtype=BF, device=dev) if p > 0.0 else None
+        lib.call("tuber_layernorm_bwd", gptr, ldg, xhat, rstd, gamma, dx, dxd, workspace(dev, "ln", 2 * nb * E), dgamma, dbeta, 1, M, E,
+                 p, st.seed, salt)
+        tp.put(x, dxd if p > 0.0 else dx)
+        if res is not None:
+            tp.put(res, dx)
+    tp.rec(bwd)
+    return y
+
+
+def attention(tp, roles, geom, kpm, pdrop, *tensors):
+    """Multi-head attention core on packed projections (32-wide heads).  ``tensors`` are the distinct 2-D bf16 inputs;
+    ``roles`` = ((ti, col_off),)*3 locate Q, K, V; ``geom`` = (B, H, Lq, Lk, qmap, kmap) with (sL,s1,s2,B2) token maps."""
+    st = tp.store
+    B, H, Lq, Lk, qmap, kmap = geom
+    (qi, qo), (ki, ko), (vi, vo) = roles
+    tq, tk, tv = tensors[qi], tensors[ki], tensors[vi]
+    dev = tq.device
+    E = H * 32
+    o = torch.empty(tq.shape[0], E, dtype=BF, device=dev)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
+    mq, mk, mv = _map(tq.shape[1], *qmap), _map(tk.shape[1], *kmap), _map(tv.shape[1], *kmap)
+    mo = _map(E, *qmap)
+    scale = 32 ** -0.5
+    p = float(pdrop)
+    salt = tp.salt()
+    lib.call("tuber_attn_fwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
+             tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(p), st.seed, salt)
+    if not tp.train:
+        return o
+
+    def bwd():
+        g = tp.take(o)
+        if g is None:
+            return
+        covered = [0] * len(tensors)
+        for ti, _ in roles:
+            covered[ti] += E
+        grads = [torch.empty_like(t) if covered[i] >= t.shape[1] else torch.zeros_like(t) for i, t in enumerate(tensors)]
+        delta = torch.empty(B, H, Lq, dtype=torch.float32, device=dev)
+        lib.call("tuber_attn_bwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
+                 tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, g, mo.ctypes.data,
+                 grads[qi].data_ptr() + 2 * qo, mq.ctypes.data, grads[ki].data_ptr() + 2 * ko, mk.ctypes.data,
+                 grads[vi].data_ptr() + 2 * vo, mv.ctypes.data, delta, B, H, Lq, Lk, scale, float(p), st.seed, salt)
+        for t, gt in zip(tensors, grads):
+            tp.put(t, gt)
+    tp.rec(bwd)
+    return o
+
+
+def attention_wide(tp, q, kv, HW, T, pdrop):
+    """LSTR pooling attention: one query per pixel, 8 heads of 256 (q [NQ,2048]; kv [rows,4096] = [k|v])."""
+    st = tp.store
+    NQ = q.shape[0]
+    o = torch.empty(NQ, 2048, dtype=BF, device=q.device)
+    p = float(pdrop)
+    salt = tp.salt()
+    lib.call("tuber_attn_wide_fwd", q, kv, o, NQ, HW, T, float(p), st.seed, salt)
+    if not tp.train:
+        return o
+
+    def bwd():
+        g = tp.take(o)
+        if g is None:
+            return
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        lib.call("tuber_attn_wide_bwd", q, kv, g, dq, dkv, NQ, HW, T, float(p), st.seed, salt)
+        tp.put(q, dq)
+        tp.put(kv, dkv)
+    tp.rec(bwd)
+    return o
+
+
+def add_const(tp, a, c):
+    """a + c where c carries no gradient (positional encodings): the gradient of the sum IS the gradient of a."""
+    out = torch.empty_like(a)
+    lib.call("tuber_axpby", a, c, out, a.numel(), 1.0, 1.0)
+    if tp.train:
+        tp.alias[id(out)] = a
+        tp.rec(lambda keep=(out, a): None)           # keeps both tensors (and their ids) alive for the alias map
+    return out
+
+
+def add(tp, a, b):
+    """a + b with gradients to both."""
+    out = torch.empty_like(a)
+    lib.call("tuber_axpby", a, b, out, a.numel(), 1.0, 1.0)
+    if tp.train:
+        def bwd():
+            g = tp.take(out)
+            if g is not None:
+                tp.put(a, g)
+                tp.put(b, g)
+        tp.rec(bwd)
+    return out
+
+
+def gather_sum(tp, x, fwd, bwd_map):
+    """out[(a,b,c)] = mul * sum_d x[a*sa+b*sb+c*sc+d*sd]; ``bwd_map`` is the adjoint index map producing the x-shaped gradient."""
+    A, B, C, D, sa, sb, sc, sd, mul = fwd
+    E = x.shape[1]
+    out = torch.empty(A * B * C, E, dtype=BF, device=x.device)
+    lib.call("tuber_rows_gather_sum", x, out, A, B, C, D, sa, sb, sc, sd, E, float(mul))
+    if tp.train:
+        def bwd():
+            g = tp.take(out)
+            if g is None:
+                return
+            A2, B2, C2, D2, ta, tb, tc, td, mul2 = bwd_map
+            assert A2 * B2 * C2 == x.shape[0]
+            dx = torch.empty(x.shape[0], E, dtype=BF, device=x.device)
+            lib.call("tuber_rows_gather_sum", g, dx, A2, B2, C2, D2, ta, tb, tc, td, E, float(mul2))
+            tp.put(x, dx)
+        tp.rec(bwd)
+    return out
+
+
+def param_rows(tp, name, B):
+    """bf16 rows of an embedding-like parameter [Q, E], repeated B times: rows (b, q).  Its consumers' gradients are collected
+    and summed once (query_embed is added to the decoder state twelve times)."""
+    st = tp.store
+    Q, E = st.module.get_parameter(name).shape
+    src = st.shadow.data_ptr() + 2 * st.offsets[name]
+    out = torch.empty(B * Q, E, dtype=BF, device=st.device)
+    lib.call("tuber_rows_gather_sum", src, out, B, 1, Q, 1, 0, 0, 1, 0, E, 1.0)
+    if tp.train:
+        tp.stack[id(out)] = []
+
+        def bwd(keep=out):
+            gs = tp.stack.pop(id(keep), [])
+            if not gs:
+                return
+            gp = st.gflat.data_ptr() + 4 * st.offsets[name]
+            n = len(gs)
+            if n > 1:
+                allg = torch.cat(gs, dim=0)                      # [n*B*Q, E] -> rows (use, b) of [Q*E]
+            else:
+                allg = gs[0]
+            R = lib.query("tuber_colsum_blocks", n * B)
+            lib.call("tuber_colsum", allg, workspace(st.device, "cs", R * Q * E), gp, 1, n * B, Q * E, Q * E)
+        tp.rec(bwd)
+    return out
+
+
+def dropout(tp, x, p):
+    if p <= 0.0:
+        return x
+    st = tp.store
+    salt = tp.salt()
+    y = torch.empty_like(x)
+    lib.call("tuber_dropout", x, y, x.numel(), float(p), st.seed, salt)
+    if not tp.train:
+        return y
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        dx = torch.empty_like(g)
+        lib.call("tuber_dropout", g, dx, g.numel(), float(p), st.seed, salt)
+        tp.put(x, dx)
+    tp.rec(bwd)
+    return y
+
+
+def sigmoid(tp, x):
+    y = torch.empty_like(x)
+    lib.call("tuber_sigmoid_fwd", x, y, x.numel())
+    if tp.train:
+        def bwd():
+            g = tp.take(y)
+            if g is None:
+                return
+            dx = torch.empty_like(y)
+            lib.call("tuber_sigmoid_bwd", g.contiguous(), y, dx, y.numel())
+            tp.put(x, dx)
+        tp.rec(bwd)
+    return y
+
+
+def mid_frame(tp, feat, B, Tp, hw):
+    """feat rows (b,t,hw) -> rows (b,hw) of the middle frame (backbone_builder.py:79-80); plain torch indexing (JHMDB only)."""
+    C = feat.shape[1]
+    out = feat.view(B, Tp, hw, C)[:, Tp // 2].reshape(B * hw, C)
+    if tp.train:
+        def bwd():
+            g = tp.take(out)
+            if g is None:
+                return
+            d = torch.zeros_like(feat)
+            d.view(B, Tp, hw, C)[:, Tp // 2] = g.view(B, hw, C)
+            tp.put(feat, d)
+        tp.rec(bwd)
+    return out
+
+
+def backbone(tp, runner, clips, bn_train):
+    """CSN body: forward / backward are the hand-scheduled kernel sequences of CSNRunner (backbone.py)."""
+    feat, saved = runner.forward(clips, bn_train)
+    runner.last_shape = tuple(feat.shape)
+    f2 = feat.view(-1, feat.shape[-1])
+    if tp.train:
+        def bwd():
+            g = tp.take(f2)
+            if g is not None:
+                runner.backward(saved, g.contiguous())
+        tp.rec(bwd)
+    return f2

@@ -18,7 +18,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import lib, ops
+from . import lib
+from . import tape as T
 from .backbone import build_CSN, CSNRunner
 from .engine import ParamStore
 from .misc import NestedTensor, nested_tensor_from_tensor_list
@@ -210,40 +211,52 @@ class DETR(nn.Module):
                 p.requires_grad = False
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _mha_self(self, st, x, qk_in, prefix, B, L, kpm, p, train):  # p = attention-weight dropout
-        """self-attention with q = k = qk_in, v = x (rows (b, l)); returns out_proj(attn)."""
+    def _mha_self(self, tp, x, qk_in, prefix, B, L, kpm, p):
+        """self-attention with q = k = qk_in, v = x (rows (b, l)); returns out_proj(attn).  p = attention-weight dropout."""
         E = self.hidden_dim
-        qk = ops.linear(qk_in, st, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(0, 2 * E))
-        v = ops.linear(x, st, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(2 * E, 3 * E))
-        geom = (B, 8, L, L, (1, L, 0, 1), (1, L, 0, 1))
-        st.step_seed += 1
-        a = ops.attention(st, ((0, 0), (0, E), (1, 0)), geom, kpm, p if train else 0.0, st.step_seed, qk, v)
-        return ops.linear(a, st, prefix + ".out_proj.weight", prefix + ".out_proj.bias")
+        qk = T.linear(tp, qk_in, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(0, 2 * E))
+        v = T.linear(tp, x, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(2 * E, 3 * E))
+        a = T.attention(tp, ((0, 0), (0, E), (1, 0)), (B, 8, L, L, (1, L, 0, 1), (1, L, 0, 1)), kpm, p, qk, v)
+        return T.linear(tp, a, prefix + ".out_proj.weight", prefix + ".out_proj.bias")
 
-    def _ffn(self, st, x, prefix, p, train):
-        h = ops.linear(x, st, prefix + ".linear1.weight", prefix + ".linear1.bias", relu=True)
-        h = ops.dropout(h, p, train, st)
-        h = ops.linear(h, st, prefix + ".linear2.weight", prefix + ".linear2.bias")
-        return ops.dropout(h, p, train, st)
+    def _ffn(self, tp, x, prefix, p):
+        """linear2(Dropout(ReLU(linear1(x)))); the Dropout that follows linear2 is fused into the caller's LayerNorm."""
+        h = T.linear(tp, x, prefix + ".linear1.weight", prefix + ".linear1.bias", relu=True, drop=p)
+        return T.linear(tp, h, prefix + ".linear2.weight", prefix + ".linear2.bias")
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, samples):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
-        st, runner = self.engine()
+        st, _ = self.engine()
         dev = st.device
-        train = self.training
         clips = samples.tensors.to(dev, torch.float32).contiguous()
         mask = samples.mask.to(dev)
+        record = self.training and torch.is_grad_enabled()
+        logits, logits_b, boxes = _ModelFn.apply(self._anchor, self, clips, mask, record)
+        if self.dataset_mode != "ava":
+            logits_b = logits_b.unsqueeze(0).repeat(logits.shape[0], 1, 1)
+        out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_logits_b": logits_b[-1]}
+        out["_stacked"] = (logits, logits_b, boxes)      # all decoder layers, contiguous: what the fused criterion consumes
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a_, "pred_boxes": b_, "pred_logits_b": c_}
+                                  for a_, b_, c_ in zip(logits[:-1], boxes[:-1], logits_b[:-1])]
+        return out
+
+    def _run(self, clips, mask, record):
+        """the whole network on the tape (tape.py); returns (tape, (logits2d, logits_b2d, boxes2d), output shapes)."""
+        st, runner = self.engine()
+        dev = st.device
         st.refresh()
-        st.begin_step(train)
-        anchor = self._anchor
+        st.begin_step(self.training)
+        tp = T.Tape(st, record)
         E, H = self.hidden_dim, 8
         enc0 = self.transformer.encoder.layers[0]
-        pdrop, pattn = enc0.dropout.p, enc0.self_attn.dropout
+        on = 1.0 if self.training else 0.0       # dropout is a no-op in eval
+        pdrop, pattn = enc0.dropout.p * on, enc0.self_attn.dropout * on
 
         # ---- backbone (Backbone.forward, backbone_builder.py:59-90) ----
-        feat = ops.BackboneFn.apply(clips, anchor, runner, train)          # [B*T'*hw, 2048] rows (b,t,hw)
+        feat = T.backbone(tp, runner, clips, self.training)                        # [B*T'*hw, 2048] rows (b,t,hw)
         B, Tp, h, w, C = runner.last_shape
         hw = h * w
         strat = self.backbone.temporal_ds_strategy
@@ -252,126 +265,131 @@ class DETR(nn.Module):
         if strat == "avg":
             if Tp != self.backbone.pool_len:
                 raise ValueError("TEMPORAL_DS_STRATEGY 'avg' needs T/8 == TEMP_LEN/DS_RATE (got %d vs %d)" % (Tp, self.backbone.pool_len))
-            xs = ops.gather_sum(feat, (B, 1, hw, Tp, Tp * hw, 0, 1, hw, 1.0 / Tp), (B, Tp, hw, 1, hw, 0, 1, 0, 1.0 / Tp))
+            xs = T.gather_sum(tp, feat, (B, 1, hw, Tp, Tp * hw, 0, 1, hw, 1.0 / Tp), (B, Tp, hw, 1, hw, 0, 1, 0, 1.0 / Tp))
         elif strat == "decode":
-            xs = self._lstr_pool(st, feat, B, Tp, hw, train)
+            xs = self._lstr_pool(tp, feat, B, Tp, hw, on)
         elif strat == "max":
             raise NotImplementedError("TEMPORAL_DS_STRATEGY 'max' is not used by any published config")
         else:                                   # mid-frame slice (backbone_builder.py:79-80)
-            xs = feat.view(B, Tp, hw, C)[:, Tp // 2].reshape(B * hw, C)
+            xs = T.mid_frame(tp, feat, B, Tp, hw)
         m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]          # [B,h,w] (backbone_builder.py:85)
         kpm = m.reshape(B, hw).to(torch.uint8).contiguous()
         pos = torch.empty(B * hw, E, dtype=BF, device=dev)
         lib.call("tuber_posenc", kpm, pos, B, 1, h, w, E)
 
         # ---- DETR encoder / decoder (transformer.py:49-64) ----
-        src = ops.linear(xs, st, "input_proj.weight", "input_proj.bias")           # rows (b, hw)
+        src = T.linear(tp, xs, "input_proj.weight", "input_proj.bias")             # rows (b, hw)
         for i in range(self.transformer.encoder.num_layers):
             L = "transformer.encoder.layers.%d" % i
-            a = self._mha_self(st, src, ops.add(src, pos), L + ".self_attn", B, hw, kpm, pattn, train)
-            src = ops.layer_norm(ops.dropout(a, pdrop, train, st), src, st, L + ".norm1")
-            src = ops.layer_norm(self._ffn(st, src, L, pdrop, train), src, st, L + ".norm2")
+            a = self._mha_self(tp, src, T.add_const(tp, src, pos), L + ".self_attn", B, hw, kpm, pattn)
+            src = T.layer_norm(tp, a, src, L + ".norm1", drop=pdrop)
+            src = T.layer_norm(tp, self._ffn(tp, src, L, pdrop), src, L + ".norm2", drop=pdrop)
         memory = src
-        mem_pos = ops.add(memory, pos)
+        mem_pos = T.add_const(tp, memory, pos)
         Q = self.query_embed.num_embeddings
-        qpos = ops.param_rows(st, "query_embed.weight", B, anchor)                 # rows (b, q)
+        qpos = T.param_rows(tp, "query_embed.weight", B)                            # rows (b, q)
         tgt = torch.zeros(B * Q, E, dtype=BF, device=dev)
-        hs_list = []
-        for i in range(self.transformer.decoder.num_layers):
+        lay_n = self.transformer.decoder.num_layers
+        hs = torch.empty(lay_n * B * Q, E, dtype=BF, device=dev)                    # rows (layer, b, q)
+        for i in range(lay_n):
             L = "transformer.decoder.layers.%d" % i
-            a = self._mha_self(st, tgt, ops.add(tgt, qpos), L + ".self_attn", B, Q, None, pattn, train)
-            tgt = ops.layer_norm(ops.dropout(a, pdrop, train, st), tgt, st, L + ".norm1")
+            a = self._mha_self(tp, tgt, T.add(tp, tgt, qpos), L + ".self_attn", B, Q, None, pattn)
+            tgt = T.layer_norm(tp, a, tgt, L + ".norm1", drop=pdrop)
             P = L + ".multihead_attn"
-            q = ops.linear(ops.add(tgt, qpos), st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(0, E))
-            k = ops.linear(mem_pos, st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(E, 2 * E))
-            v = ops.linear(memory, st, P + ".in_proj_weight", P + ".in_proj_bias", rows=(2 * E, 3 * E))
-            st.step_seed += 1
-            a = ops.attention(st, ((0, 0), (1, 0), (2, 0)), (B, H, Q, hw, (1, Q, 0, 1), (1, hw, 0, 1)), kpm,
-                              pattn if train else 0.0, st.step_seed, q, k, v)
-            a = ops.linear(a, st, P + ".out_proj.weight", P + ".out_proj.bias")
-            tgt = ops.layer_norm(ops.dropout(a, pdrop, train, st), tgt, st, L + ".norm2")
-            tgt = ops.layer_norm(self._ffn(st, tgt, L, pdrop, train), tgt, st, L + ".norm3")
-            hs_list.append(ops.layer_norm(tgt, None, st, "transformer.decoder.norm"))
-        lay_n = len(hs_list)
-        hs = torch.cat(hs_list, dim=0)                                              # rows (layer, b, q)
+            q = T.linear(tp, T.add(tp, tgt, qpos), P + ".in_proj_weight", P + ".in_proj_bias", rows=(0, E))
+            k = T.linear(tp, mem_pos, P + ".in_proj_weight", P + ".in_proj_bias", rows=(E, 2 * E))
+            v = T.linear(tp, memory, P + ".in_proj_weight", P + ".in_proj_bias", rows=(2 * E, 3 * E))
+            a = T.attention(tp, ((0, 0), (1, 0), (2, 0)), (B, H, Q, hw, (1, Q, 0, 1), (1, hw, 0, 1)), kpm, pattn, q, k, v)
+            a = T.linear(tp, a, P + ".out_proj.weight", P + ".out_proj.bias")
+            tgt = T.layer_norm(tp, a, tgt, L + ".norm2", drop=pdrop)
+            tgt = T.layer_norm(tp, self._ffn(tp, tgt, L, pdrop), tgt, L + ".norm3", drop=pdrop)
+            T.layer_norm(tp, tgt, None, "transformer.decoder.norm", out=(hs, i * B * Q, 0))
 
         # ---- heads (tuber_ava.py:121-125,142) ----
         if self.dataset_mode == "ava":
-            logits_b = ops.linear(hs, st, "class_embed_b.weight", "class_embed_b.bias", out_f32=True).view(lay_n, B, Q, 3)
+            logits_b = T.linear(tp, hs, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
+            lb_shape = (lay_n, B, Q, 3)
         else:
-            pooled = ops.gather_sum(feat, (B, 1, 1, Tp * hw, Tp * hw, 0, 0, 1, 1.0 / (Tp * hw)),
-                                    (B, 1, Tp * hw, 1, 1, 0, 0, 0, 1.0 / (Tp * hw)))
-            lb = ops.linear(pooled, st, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
-            logits_b = lb.unsqueeze(0).repeat(6, 1, 1)
-        x = ops.linear(hs, st, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
-        x = ops.linear(x, st, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
-        boxes = ops.sigmoid(ops.linear(x, st, "bbox_embed.layers.2.weight", "bbox_embed.layers.2.bias", out_f32=True))
-        boxes = boxes.view(lay_n, B, Q, 4)
+            pooled = T.gather_sum(tp, feat, (B, 1, 1, Tp * hw, Tp * hw, 0, 0, 1, 1.0 / (Tp * hw)),
+                                  (B, 1, Tp * hw, 1, 1, 0, 0, 0, 1.0 / (Tp * hw)))
+            logits_b = T.linear(tp, pooled, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
+            lb_shape = (B, logits_b.shape[1])
+        x = T.linear(tp, hs, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
+        x = T.linear(tp, x, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
+        boxes = T.sigmoid(tp, T.linear(tp, x, "bbox_embed.layers.2.weight", "bbox_embed.layers.2.bias", out_f32=True))
 
         # ---- class branch (tuber_ava.py:127-141; transformer_layers.py:71-97) ----
-        src_c = ops.linear(feat, st, "class_proj.weight", "class_proj.bias")       # rows (b, t, hw)
+        src_c = T.linear(tp, feat, "class_proj.weight", "class_proj.bias")         # rows (b, t, hw)
         R0 = B * Tp * hw
-        rep = ops.gather_sum(src_c, (lay_n, 1, R0, 1, 0, 0, 1, 0, 1.0), (1, 1, R0, lay_n, 0, 0, 1, R0, 1.0))  # rows (l,b,t,hw)
+        rep = T.gather_sum(tp, src_c, (lay_n, 1, R0, 1, 0, 0, 1, 0, 1.0), (1, 1, R0, lay_n, 0, 0, 1, R0, 1.0))  # rows (l,b,t,hw)
         LB = lay_n * B
         cl = self.encoder.layers[0]
-        pa_c, p1_c, pf_c = cl.self_attn_t.dropout, cl.dropout1.p, cl.dropout.p
+        pa_c, p1_c, pf_c = cl.self_attn_t.dropout * on, cl.dropout1.p * on, cl.dropout.p * on
         P = "encoder.layers.0"
-        qkv = ops.linear(rep, st, P + ".self_attn_t.in_proj_weight", P + ".self_attn_t.in_proj_bias")
-        st.step_seed += 1
+        cat = torch.empty(lay_n * R0, 2 * E, dtype=BF, device=dev)                  # [t-attention | s-attention] features
+        qkv = T.linear(tp, rep, P + ".self_attn_t.in_proj_weight", P + ".self_attn_t.in_proj_bias")
         mp = (1, hw, 0, 1)                       # sequence over hw, batch (lb, t)
-        a = ops.attention(st, ((0, 0), (0, E), (0, 2 * E)), (LB * Tp, H, hw, hw, mp, mp), None, pa_c if train else 0.0, st.step_seed, qkv)
-        a = ops.linear(a, st, P + ".self_attn_t.out_proj.weight", P + ".self_attn_t.out_proj.bias")
-        src_t = ops.layer_norm(ops.dropout(a, p1_c, train, st), rep, st, P + ".norm1_t")
-        qkv = ops.linear(rep, st, P + ".self_attn_s.in_proj_weight", P + ".self_attn_s.in_proj_bias")
-        st.step_seed += 1
+        a = T.attention(tp, ((0, 0), (0, E), (0, 2 * E)), (LB * Tp, H, hw, hw, mp, mp), None, pa_c, qkv)
+        a = T.linear(tp, a, P + ".self_attn_t.out_proj.weight", P + ".self_attn_t.out_proj.bias")
+        T.layer_norm(tp, a, rep, P + ".norm1_t", drop=p1_c, out=(cat, 0, 0))
+        qkv = T.linear(tp, rep, P + ".self_attn_s.in_proj_weight", P + ".self_attn_s.in_proj_bias")
         mp = (hw, Tp * hw, 1, hw)                # sequence over t, batch (lb, hw)
-        a = ops.attention(st, ((0, 0), (0, E), (0, 2 * E)), (LB * hw, H, Tp, Tp, mp, mp), None, cl.self_attn_s.dropout if train else 0.0, st.step_seed, qkv)
-        a = ops.linear(a, st, P + ".self_attn_s.out_proj.weight", P + ".self_attn_s.out_proj.bias")
-        src_s = ops.layer_norm(ops.dropout(a, p1_c, train, st), rep, st, P + ".norm1_s")
-        cat = torch.cat((src_t, src_s), dim=1)
-        enc = ops.layer_norm(self._ffn(st, cat, P, pf_c, train), rep, st, P + ".norm2")
-        q = ops.linear(hs, st, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(0, E))
-        kv = ops.linear(enc, st, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(E, 3 * E))
-        st.step_seed += 1
-        a = ops.attention(st, ((0, 0), (1, 0), (1, E)), (LB, H, Q, Tp * hw, (1, Q, 0, 1), (1, Tp * hw, 0, 1)), None,
-                          self.cross_attn.dropout if train else 0.0, st.step_seed, q, kv)
-        q_class = ops.linear(a, st, "cross_attn.out_proj.weight", "cross_attn.out_proj.bias")
-        q_class = ops.dropout(q_class, self.dropout.p, train, st)
-        logits = ops.linear(q_class, st, "class_fc.weight", "class_fc.bias", out_f32=True).view(lay_n, B, Q, -1)
+        a = T.attention(tp, ((0, 0), (0, E), (0, 2 * E)), (LB * hw, H, Tp, Tp, mp, mp), None, cl.self_attn_s.dropout * on, qkv)
+        a = T.linear(tp, a, P + ".self_attn_s.out_proj.weight", P + ".self_attn_s.out_proj.bias")
+        T.layer_norm(tp, a, rep, P + ".norm1_s", drop=p1_c, out=(cat, 0, E))
+        enc = T.layer_norm(tp, self._ffn(tp, cat, P, pf_c), rep, P + ".norm2", drop=pf_c)
+        q = T.linear(tp, hs, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(0, E))
+        kv = T.linear(tp, enc, "cross_attn.in_proj_weight", "cross_attn.in_proj_bias", rows=(E, 3 * E))
+        a = T.attention(tp, ((0, 0), (1, 0), (1, E)), (LB, H, Q, Tp * hw, (1, Q, 0, 1), (1, Tp * hw, 0, 1)), None,
+                        self.cross_attn.dropout * on, q, kv)
+        q_class = T.linear(tp, a, "cross_attn.out_proj.weight", "cross_attn.out_proj.bias", drop=self.dropout.p * on)
+        logits = T.linear(tp, q_class, "class_fc.weight", "class_fc.bias", out_f32=True)
+        shapes = ((lay_n, B, Q, logits.shape[1]), lb_shape, (lay_n, B, Q, 4))
+        return tp, (logits, logits_b, boxes), shapes
 
-        out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_logits_b": logits_b[-1]}
-        out["_stacked"] = (logits, logits_b, boxes)      # all decoder layers, contiguous: what the fused criterion consumes
-        if self.aux_loss:
-            out["aux_outputs"] = [{"pred_logits": a_, "pred_boxes": b_, "pred_logits_b": c_}
-                                  for a_, b_, c_ in zip(logits[:-1], boxes[:-1], logits_b[:-1])]
-        return out
-
-    def _lstr_pool(self, st, feat, B, Tp, hw, train):
+    def _lstr_pool(self, tp, feat, B, Tp, hw, on):
         """TEMPORAL_DS_STRATEGY 'decode' (backbone_builder.py:74-78; transformer_layers.py:380-448): per-pixel one-query
         decoder (d=2048, 8 heads of 256) over the T' temporal slots.  Rows: queries (b, hw); memory (b, t, hw)."""
         E = 2048
         P = "backbone.pool_decoder.layers.0"
         NQ = B * hw
         lay = self.backbone.pool_decoder.layers[0]
-        p = lay.self_attn.dropout if train else 0.0
-        pr = lay.dropout1.p
-        tgt = ops.param_rows(st, "backbone.query_pool.weight", NQ, self._anchor)     # the same learned query for every pixel
+        p = lay.self_attn.dropout * on
+        pr = lay.dropout1.p * on
+        tgt = T.param_rows(tp, "backbone.query_pool.weight", NQ)                    # the same learned query for every pixel
         S = P + ".self_attn"
-        q = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(0, E))
-        kv = ops.linear(tgt, st, S + ".in_proj_weight", S + ".in_proj_bias", rows=(E, 3 * E))
-        st.step_seed += 1
-        a = ops.attention_wide(st, q, kv, hw, 1, p, st.step_seed)                       # one key: softmax = 1 (dropout still applies)
-        a = ops.linear(a, st, S + ".out_proj.weight", S + ".out_proj.bias")
-        tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm1")
+        q = T.linear(tp, tgt, S + ".in_proj_weight", S + ".in_proj_bias", rows=(0, E))
+        kv = T.linear(tp, tgt, S + ".in_proj_weight", S + ".in_proj_bias", rows=(E, 3 * E))
+        a = T.attention_wide(tp, q, kv, hw, 1, p)                                   # one key: softmax = 1 (dropout still applies)
+        a = T.linear(tp, a, S + ".out_proj.weight", S + ".out_proj.bias")
+        tgt = T.layer_norm(tp, a, tgt, P + ".norm1", drop=pr)
         Cx = P + ".multihead_attn"
-        q = ops.linear(tgt, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(0, E))
-        kv = ops.linear(feat, st, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(E, 3 * E))
-        st.step_seed += 1
-        a = ops.attention_wide(st, q, kv, hw, Tp, p, st.step_seed)
-        a = ops.linear(a, st, Cx + ".out_proj.weight", Cx + ".out_proj.bias")
-        tgt = ops.layer_norm(ops.dropout(a, pr, train, st), tgt, st, P + ".norm2")
-        tgt = ops.layer_norm(self._ffn(st, tgt, P, pr, train), tgt, st, P + ".norm3")
-        return ops.layer_norm(tgt, None, st, "backbone.pool_decoder.norm")
+        q = T.linear(tp, tgt, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(0, E))
+        kv = T.linear(tp, feat, Cx + ".in_proj_weight", Cx + ".in_proj_bias", rows=(E, 3 * E))
+        a = T.attention_wide(tp, q, kv, hw, Tp, p)
+        a = T.linear(tp, a, Cx + ".out_proj.weight", Cx + ".out_proj.bias")
+        tgt = T.layer_norm(tp, a, tgt, P + ".norm2", drop=pr)
+        tgt = T.layer_norm(tp, self._ffn(tp, tgt, P, pr), tgt, P + ".norm3", drop=pr)
+        return T.layer_norm(tp, tgt, None, "backbone.pool_decoder.norm")
+
+
+class _ModelFn(torch.autograd.Function):
+    """The whole network as ONE autograd node: forward runs DETR._run on the tape, backward replays the tape.  The criterion
+    (autograd or the fused HIP one) sees ordinary fp32 tensors; ``loss.backward()`` works as in the reference."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, clips, mask, record):
+        tp, outs, shapes = model._run(clips, mask, record)
+        ctx.tp, ctx.outs = tp, outs
+        return tuple(o.view(s) for o, s in zip(outs, shapes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tp, outs = ctx.tp, ctx.outs
+        seeds = [(o, g.contiguous().view(o.shape) if g is not None else None) for o, g in zip(outs, grads)]
+        tp.backward(seeds)
+        ctx.tp = ctx.outs = None
+        return None, None, None, None, None
 
 
 def build_model(cfg):
