@@ -62,5 +62,49 @@ def bench_nt(cfgs):
     lib.call("tuber_gemm_nt_set_cfg", -1)
 
 
+TN_SHAPES = [(30, 256, 256), (704, 256, 256), (704, 2048, 256), (704, 256, 2048), (30, 2048, 256), (180, 256, 256),
+             (5632, 1024, 256), (5632, 256, 1024), (44032, 512, 128), (44032, 128, 512), (348160, 256, 64), (348160, 64, 256),
+             (16896, 768, 256), (16896, 256, 2048), (16896, 2048, 512), (2816, 2048, 512)]
+
+
+def bench_tn():
+    print("%-28s %8s %6s" % ("shape (M N K)", "us", "slabs"))
+    for M, N, K in TN_SHAPES:
+        G = torch.randn(M, N, device=dev).to(BF)
+        A = torch.randn(M, K, device=dev).to(BF)
+        S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+        part = torch.empty(S * N * K, device=dev)
+        out = torch.zeros(N, K, device=dev)
+
+        def fn():
+            lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+        print("%-28s %8.1f %6d   | %.1f MB %.2f GF" % ("%d %d %d" % (M, N, K), time_it(fn), S, (2 * M * (N + K) + 4 * N * K) / 1e6, 2 * M * N * K / 1e9), flush=True)
+
+
+def bench_misc():
+    for M, E in [(30, 256), (704, 256), (16896, 256)]:
+        x = torch.randn(M, E, device=dev).to(BF)
+        g, b = torch.ones(E, device=dev), torch.zeros(E, device=dev)
+        y, xh, rstd = torch.empty_like(x), torch.empty_like(x), torch.empty(M, device=dev)
+        nb = lib.query("tuber_layernorm_bwd_blocks", M)
+        part = torch.empty(2 * nb * E, device=dev)
+        dgb = torch.zeros(2 * E, device=dev)
+        dx = torch.empty_like(x)
+        t1 = time_it(lambda: lib.call("tuber_layernorm_fwd", x, x, g, b, y, E, xh, rstd, M, E, 1e-5, 0.1, None, 3))
+        t2 = time_it(lambda: lib.call("tuber_layernorm_bwd", x, E, xh, rstd, g, dx, y, part, dgb, dgb.data_ptr() + 4 * E, 1, M, E, 0.1, None, 3))
+        print("layernorm M%d E%d: fwd %.1f us, bwd (+reduce) %.1f us" % (M, E, t1, t2), flush=True)
+    for M, C in [(30, 256), (704, 256), (704, 2048), (16896, 768)]:
+        gq = torch.randn(M, C, device=dev).to(BF)
+        out = torch.zeros(C, device=dev)
+        part = torch.empty(lib.query("tuber_colsum_blocks", M) * C, device=dev)
+        print("colsum M%d C%d: %.1f us" % (M, C, time_it(lambda: lib.call("tuber_colsum", gq, part, out, 1, M, C, C))), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tn":
+        bench_tn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "misc":
+        bench_misc()
+        sys.exit(0)
     bench_nt([int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5".split(","))])

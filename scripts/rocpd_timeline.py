@@ -71,3 +71,11 @@ if len(sys.argv) > 4:
             if s - last > 20000: big.append(((s - t0) / 1e6, (s - last) / 1e3, names[k][:40]))
         last = max(last, e)
     print("   idle in window %.3f ms; gaps > 20us:" % (gap / 1e6), big[:30])
+if len(sys.argv) > 5 and sys.argv[5] == "block":
+    # kernels of the N-th bottleneck block in backward (between consecutive block_out_bwd launches) and forward
+    for key, nth in [(k.split(":")[0], int(k.split(":")[1])) for k in (sys.argv[6].split(",") if len(sys.argv) > 6 else ["block_out_bwd:20", "block_out_fwd:25"])]:
+        idx = [i for i, r in enumerate(step) if key in names[r[3]]]
+        a, b = idx[nth], idx[nth + 1]
+        print("---- kernels from %s #%d to #%d" % (key, nth, nth + 1))
+        for s, e, q, k in step[a:b]:
+            print("   %8.1f us  +%6.1f  %s" % ((e - s) / 1e3, (s - step[a][0]) / 1e3, names[k][:90]))

@@ -177,7 +177,17 @@ class CSNRunner:
             self._ws[key] = t
         return t.data_ptr()
 
+    def _stat_rows(self, st0, st1, R, C):
+        """long partial-statistics lists (layer1) get a wide first-stage reduction before the (few-block) finalize kernel"""
+        R2 = lib.query("tuber_stat_rows_reduced", R)
+        if R2 >= R:
+            return st0, st1, R
+        o0, o1 = self.ws("st0r", R2 * C), self.ws("st1r", R2 * C)
+        lib.call("tuber_stat_rows_reduce", st0, st1, R, C, o0, o1)
+        return o0, o1, R2
+
     def _bn_train(self, bn, st0, st1, R, count):
+        st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
         lib.call("tuber_bn_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, BN_MOM, BN_EPS,
                  bn.scale, bn.shift, bn.mean, bn.invstd)
 
@@ -261,6 +271,7 @@ class CSNRunner:
     # -- backward -------------------------------------------------------------------------------------
     def _bn_bwd(self, bn, st0, st1, R, count, dz, x, M):
         """finalize coefficients (+ dgamma/dbeta into the flat grads) and apply: returns dx tensor [M, C]."""
+        st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
         lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
                  bn.dgamma, bn.dbeta, 1)
         dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)

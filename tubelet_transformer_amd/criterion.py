@@ -168,7 +168,33 @@ class _SetCriterionBase(nn.Module):
             out["loss_ce_b" + sfx] = ce_b[l]
             out["loss_bbox" + sfx] = lv[l, 2]
             out["loss_giou" + sfx] = lv[l, 3]
+        self._lv = (lv, ce_b if not self.ava else None)       # for weighted_total: one fused weighted sum instead of 24 scalar ops
         return out
+
+    def weighted_total(self, loss_dict, weight_dict=None):
+        """sum_k weight_dict[k] * loss_dict[k] (train_tuber_ava.py / video_action_recognition.py:147) -- computed as ONE weighted
+        reduction over the stacked [L,4] loss tensor when ``loss_dict`` is the dict this criterion just returned (the 24 scalar
+        multiplies / adds and their autograd nodes cost ~190 tiny launches per step otherwise)."""
+        wd = self.weight_dict if weight_dict is None else weight_dict
+        lv_pack = getattr(self, "_lv", None)
+        if lv_pack is None or loss_dict.get("loss_ce") is None or loss_dict["loss_ce"]._base is not lv_pack[0]:
+            return sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        lv, ce_b = lv_pack
+        L = lv.shape[0]
+        names = ("loss_ce", "loss_ce_b", "loss_bbox", "loss_giou")
+        vals = tuple(float(wd.get(n + ("" if l == L - 1 else "_%d" % l), 0.0)) for l in range(L) for n in names)
+        cache = self.__dict__.setdefault("_w_cache", {})
+        key = (vals, str(lv.device))
+        if key not in cache:            # built once (outside any hipGraph capture: the eager warm-up step fills the cache)
+            W = torch.tensor(vals, dtype=torch.float32).view(L, 4)
+            cache[key] = (W.to(lv.device), W[:, 1].contiguous().to(lv.device))
+        W, wb = cache[key]
+        if ce_b is None:
+            return (lv * W).sum()
+        Wm = W.clone()
+        Wm[:, 1] = 0
+        total = (lv * Wm).sum() + (ce_b * wb).sum()
+        return total
 
     def forward(self, outputs, targets):
         logits, logits_b, boxes = self.stacked(outputs)

@@ -357,13 +357,16 @@ __global__ __launch_bounds__(1024) void dw_wgrad_reduce_kernel(const float* __re
     }
 }
 
-static int dw_blocks(long segs, int* iters) {
+static int dw_blocks(long segs, int* iters, int max_blocks = 4096) {
     long groups = (segs + 15) / 16;
-    int it = (int)((groups + 4095) / 4096);     // <= 4096 blocks: one or two segments per thread, latency hidden by occupancy
+    int it = (int)((groups + max_blocks - 1) / max_blocks);   // <= 4096 blocks: one or two segments per thread, latency hidden by occupancy
     if (it < 1) it = 1;
     *iters = it;
     return (int)((groups + it - 1) / it);
 }
+// the weight-gradient kernel ends with a 108-accumulator cross-thread reduction and a 6.9 KB partial per workgroup: few, long-lived
+// workgroups (2 per CU) amortise that tail and keep the partial buffer (and its reduce pass) small
+static const int DW_WGRAD_BLOCKS = 512;
 
 extern "C" {
 
@@ -380,7 +383,7 @@ int tuber_dwconv_bwd_data_stat_rows(int N, int Ti, int Hi, int Wi) {
 }
 int tuber_dwconv_bwd_weight_blocks(int N, int To, int Ho, int Wo) {
     int it;
-    return dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &it);
+    return dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &it, DW_WGRAD_BLOCKS);
 }
 
 int tuber_dwconv_fwd(const void* x, const float* sc, const float* sh, const float* w, void* out, float* st0, float* st1,
@@ -415,7 +418,7 @@ int tuber_dwconv_bwd_weight(const void* gout, const void* x, const float* sc, co
     if (!dw_ok(C, st, ss)) return TUBER_EINVAL;
     DwGeom g{N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss};
     int iters;
-    const int nb = dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &iters);
+    const int nb = dw_blocks((long)N * To * Ho * ((Wo + 3) / 4), &iters, DW_WGRAD_BLOCKS);
     dim3 grid(nb, C / 64), block(256);
     if (ss == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);
     else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);

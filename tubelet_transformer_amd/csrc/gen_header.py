@@ -36,6 +36,8 @@ DOC = {
     "tuber_dwconv_bwd_weight_blocks": "blocks (size of `partial` / (27*C)) used by tuber_dwconv_bwd_weight.",
     "tuber_bn_finalize": "training-mode nn.BatchNorm3d(eps=1e-3, momentum=0.1) statistics (ir_CSN_152.py:15-16,46,56,64,119,154): partial rows -> "
                          "mean/invstd, scale=gamma*invstd, shift=beta-mean*scale, running_mean/var (unbiased) and num_batches_tracked update.",
+    "tuber_stat_rows_reduce": "first stage for long partial-statistics lists (R > 512 rows: layer1): [R][C] x2 -> [tuber_stat_rows_reduced(R)][C] x2.",
+    "tuber_stat_rows_reduced": "rows left by tuber_stat_rows_reduce (R itself when no first stage is needed).",
     "tuber_bn_eval_affine": "eval-mode BatchNorm3d folded to scale/shift from the running statistics.",
     "tuber_bn_bwd_finalize": "BatchNorm backward coefficients: dx = cA*dz + cB*x + cC, dgamma = sum dz*xhat, dbeta = sum dz.",
     "tuber_bn_bwd_apply": "dx = cA*dz + cB*x + cC (BatchNorm backward apply), bf16 [M,C].",

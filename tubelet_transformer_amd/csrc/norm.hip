@@ -69,6 +69,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    // per-channel parameters are fetched before the partial-row sweep so their latency hides behind it
+    const bool fin = threadIdx.x < 32 && c < C;
+    const float gam = fin ? gamma[c] : 0.f, bet = fin ? beta[c] : 0.f;
+    const float rm0 = (fin && rmean) ? rmean[c] : 0.f, rv0 = (fin && rmean) ? rvar[c] : 0.f;
     double a, b;
     bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
@@ -76,15 +80,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         double var = b / (double)count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
+        const float sc = gam * invstd;
         scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
+        shift[c] = bet - (float)mean * sc;
         mean_out[c] = (float)mean;
         invstd_out[c] = invstd;
         if (rmean) {
             const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+            rmean[c] = (1.f - momentum) * rm0 + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
         }
     }
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
@@ -109,18 +113,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    const bool fin = threadIdx.x < 32 && c < C;
+    const float mu_f = fin ? mean[c] : 0.f, r_f = fin ? invstd[c] : 0.f, g_f = fin ? gamma[c] : 0.f;
+    const float dg0 = (fin && dgamma && accumulate) ? dgamma[c] : 0.f, db0 = (fin && dgamma && accumulate) ? dbeta[c] : 0.f;
     double a, b;
     bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
-        const double mu = mean[c], r = invstd[c], g = gamma[c];
+        const double mu = mu_f, r = r_f, g = g_f;
         const double sum_dz = a, sum_dz_xhat = (b - mu * a) * r;
         const double m1 = sum_dz / count, m2 = sum_dz_xhat / count;
         cA[c] = (float)(g * r);
         cB[c] = (float)(-g * r * r * m2);
         cC[c] = (float)(g * r * r * m2 * mu - g * r * m1);
         if (dgamma) {
-            dgamma[c] = accumulate ? dgamma[c] + (float)sum_dz_xhat : (float)sum_dz_xhat;
-            dbeta[c] = accumulate ? dbeta[c] + (float)sum_dz : (float)sum_dz;
+            dgamma[c] = dg0 + (float)sum_dz_xhat;
+            dbeta[c] = db0 + (float)sum_dz;
         }
     }
 }
@@ -459,7 +466,47 @@ static inline int ew_grid(long M, int C) {
     return (int)nb;
 }
 
+// first stage for long partial-statistics lists (layer1: thousands of rows): [R][C] x2 -> [R2][C] x2, one block per
+// (32 channels, row chunk); 256 threads = 8 channel quads x 32 row lanes
+__global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __restrict__ st0, const float* __restrict__ st1, int R, int C,
+                                                               float* __restrict__ o0, float* __restrict__ o1, int chunk) {
+    __shared__ float red[2][32][33];
+    const int qd = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cq = blockIdx.x * 32 + qd * 4;
+    const int r0 = blockIdx.y * chunk, r1 = min(R, r0 + chunk);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cq < C) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const float4 x = *(const float4*)(st0 + (long)r * C + cq), y = *(const float4*)(st1 + (long)r * C + cq);
+            a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+            b[0] += y.x; b[1] += y.y; b[2] += y.z; b[3] += y.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][rl][qd * 4 + e] = a[e]; red[1][rl][qd * 4 + e] = b[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5, cl = threadIdx.x & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v += red[which][i][cl];
+        const int c = blockIdx.x * 32 + cl;
+        if (c < C) (which ? o1 : o0)[(long)blockIdx.y * C + c] = v;
+    }
+}
+
 extern "C" {
+
+// [R][C] partial-statistics rows -> [R2][C] (R2 = tuber_stat_rows_reduced(R) < R): cheap first stage before the finalize kernels
+int tuber_stat_rows_reduced(int R) { return R > 512 ? 64 : R; }
+
+int tuber_stat_rows_reduce(const float* st0, const float* st1, int R, int C, float* out0, float* out1, hipStream_t stream) {
+    const int R2 = tuber_stat_rows_reduced(R);
+    if (R2 >= R || (C & 3)) return TUBER_EINVAL;
+    const int chunk = ceil_div(R, R2);
+    hipLaunchKernelGGL(stat_rows_reduce_kernel, dim3(ceil_div(C, 32), R2), dim3(256), 0, stream, st0, st1, R, C, out0, out1, chunk);
+    TUBER_RETURN_LAUNCH();
+}
 
 int tuber_bn_finalize(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
@@ -547,7 +594,8 @@ int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, cons
     TUBER_RETURN_LAUNCH();
 }
 
-int tuber_layernorm_bwd_blocks(int M) { const int nb = ceil_div(M, 64); return nb > 512 ? 512 : nb; }
+// 16 rows (4 per wave) per block up to 1024 blocks: the per-block chain is what bounds these small launches
+int tuber_layernorm_bwd_blocks(int M) { const int nb = ceil_div(M, 16); return nb > 1024 ? 1024 : nb; }
 
 // backward of tuber_layernorm_fwd: dx = gradient w.r.t. res (and w.r.t. x when p == 0), dxd = gradient w.r.t. x through the
 // dropout mask (either may be NULL); dy rows have leading dimension lddy.  partial must hold 2 * blocks * E floats;

@@ -41,7 +41,7 @@ def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0,
     weight_dict = criterion.weight_dict
     if cfg is not None and epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:          # video_action_recognition.py:145-146
         weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
-    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)
+    losses = criterion.weighted_total(loss_dict, weight_dict)
     optimizer.zero_grad()
     if reducer is not None:
         reducer.begin()
@@ -111,8 +111,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(g.B1, pool=g.A.pool()):
             g.loss_dict = crit.losses_from_match(g.logits_s, g.logits_b, g.boxes_s, g.pt, g.match, targets)
             g.loss_dict["class_error"] = crit.class_error(g.logits_s[-1], g.pt, g.match[-1])
-            wd = crit.weight_dict
-            g.loss = sum(g.loss_dict[k] * wd[k] for k in g.loss_dict if k in wd)
+            g.loss = crit.weighted_total(g.loss_dict)
             opt.zero_grad()
             g.loss.backward()
             store.side_join()
