@@ -100,7 +100,33 @@ def bench_misc():
         print("colsum M%d C%d: %.1f us" % (M, C, time_it(lambda: lib.call("tuber_colsum", gq, part, out, 1, M, C, C))), flush=True)
 
 
+def bench_dw():
+    for N, T, H, W, C in [(2, 32, 64, 85, 64), (2, 16, 32, 43, 128), (2, 8, 16, 22, 256), (2, 4, 16, 22, 512)]:
+        x = torch.randn(N, T, H, W, C, device=dev).to(BF)
+        g = torch.randn(N, T, H, W, C, device=dev).to(BF)
+        w = torch.randn(C, 27, device=dev) / 5
+        sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        out = torch.empty_like(x)
+        dwg = torch.zeros(C, 27, device=dev)
+        R = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+        R0 = max(lib.query("tuber_dwconv_fwd_stat_rows", N, T, H, W), lib.query("tuber_dwconv_bwd_weight_blocks", N, T, H, W))
+        st0, st1 = torch.empty(max(R, R0), C, device=dev), torch.empty(max(R, R0), C, device=dev)
+        part = torch.empty(max(R, R0) * 27 * C, device=dev)
+        t = [time_it(lambda: lib.call("tuber_dwconv_fwd", x, sc, sh, w, out, st0, st1, N, T, H, W, T, H, W, C, 1, 1)),
+             time_it(lambda: lib.call("tuber_dwconv_tile_fwd", x, sc, sh, w, out, st0, st1, N, T, H, W, C)),
+             time_it(lambda: lib.call("tuber_dwconv_bwd_data", g, w, x, sc, sh, out, st0, st1, N, T, H, W, T, H, W, C, 1, 1)),
+             time_it(lambda: lib.call("tuber_dwconv_tile_bwd_data", g, w, x, sc, sh, out, st0, st1, N, T, H, W, C)),
+             time_it(lambda: lib.call("tuber_dwconv_bwd_weight", g, x, sc, sh, part, dwg, 1, N, T, H, W, T, H, W, C, 1, 1)),
+             time_it(lambda: lib.call("tuber_dwconv_tile_bwd_weight", g, x, sc, sh, part, dwg, 1, N, T, H, W, C))]
+        mb = 2 * x.numel() * 2 / 1e6
+        print("dwconv %dx%dx%dx%d C%d (%.0f MB in+out): fwd %.1f -> tile %.1f us | bwd data %.1f -> %.1f | bwd weight(+reduce) %.1f -> %.1f  [tile WGs %d x %d]"
+              % (N, T, H, W, C, mb, *t, R, C // 64), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dw":
+        bench_dw()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":
         bench_tn()
         sys.exit(0)

@@ -196,6 +196,44 @@ def test_dwconv(dev, N, T, H, W, C, st, ss):
     close("dwconv bwd weight", dw, wp.grad, rel=2e-3)
 
 
+@pytest.mark.parametrize("N,T,H,W,C", [(2, 8, 16, 22, 256), (1, 5, 13, 43, 128), (2, 9, 24, 37, 64), (1, 1, 3, 5, 64), (1, 4, 16, 22, 512)])
+def test_dwconv_tile(dev, N, T, H, W, C):
+    """LDS-staged stride-1 depthwise kernels (ragged 8x16 tiles, several plane chunks) against F.conv3d and its autograd."""
+    x = rnd(N, T, H, W, C, dev=dev, seed=1).to(BF)
+    w = rnd(C, 27, dev=dev, seed=2, scale=27 ** -0.5)
+    sc = 1.0 + 0.2 * rnd(C, dev=dev, seed=5)
+    sh = 0.3 * rnd(C, dev=dev, seed=6)
+    a = (x.float() * sc + sh).relu().permute(0, 4, 1, 2, 3).requires_grad_(True)
+    wp = w.clone().requires_grad_(True)
+    ref = F.conv3d(a, wp.view(C, 1, 3, 3, 3), stride=1, padding=1, groups=C)
+    out = torch.empty(N, T, H, W, C, device=dev, dtype=BF)
+    R = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+    st0, st1 = torch.zeros(R, C, device=dev), torch.zeros(R, C, device=dev)
+    lib.call("tuber_dwconv_tile_fwd", x, sc, sh, w, out, st0, st1, N, T, H, W, C)
+    refl = ref.detach().permute(0, 2, 3, 4, 1)
+    close("dwconv tile fwd", out, refl)
+    close("dwconv tile fwd stats sum", st0.sum(0), refl.sum((0, 1, 2, 3)), abs_=2e-3 * float(refl.abs().sum((0, 1, 2, 3)).max()))
+    close("dwconv tile fwd stats sumsq", st1.sum(0), (refl ** 2).sum((0, 1, 2, 3)), rel=2e-3)
+    out2 = torch.empty_like(out)
+    lib.call("tuber_dwconv_tile_fwd", x, None, None, w, out2, None, None, N, T, H, W, C)
+    close("dwconv tile fwd (no bn)", out2, F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.view(C, 1, 3, 3, 3), padding=1,
+                                                      groups=C).permute(0, 2, 3, 4, 1))
+    g = rnd(N, T, H, W, C, dev=dev, seed=9).to(BF)
+    ref.backward(g.float().permute(0, 4, 1, 2, 3))
+    dz_ref = a.grad.permute(0, 2, 3, 4, 1) * ((x.float() * sc + sh) > 0)
+    dz = torch.empty(N, T, H, W, C, device=dev, dtype=BF)
+    s0, s1 = torch.zeros(R, C, device=dev), torch.zeros(R, C, device=dev)
+    lib.call("tuber_dwconv_tile_bwd_data", g, w, x, sc, sh, dz, s0, s1, N, T, H, W, C)
+    close("dwconv tile bwd data", dz, dz_ref)
+    close("dwconv tile bwd data sum dz", s0.sum(0), dz_ref.sum((0, 1, 2, 3)), abs_=2e-3 * float(dz_ref.abs().sum((0, 1, 2, 3)).max()))
+    close("dwconv tile bwd data sum dz*x", s1.sum(0), (dz_ref * x.float()).sum((0, 1, 2, 3)),
+          abs_=2e-3 * float((dz_ref * x.float()).abs().sum((0, 1, 2, 3)).max()))
+    part = torch.empty(R, 27, C, device=dev)
+    dw = torch.ones(C, 27, device=dev)
+    lib.call("tuber_dwconv_tile_bwd_weight", g, x, sc, sh, part, dw, 1, N, T, H, W, C)
+    close("dwconv tile bwd weight", dw - 1, wp.grad, rel=2e-3)
+
+
 def test_bn_finalize_and_bwd(dev):
     M, C = 5000, 256
     x = rnd(M, C, dev=dev, seed=1, scale=2.0) + 0.5

@@ -13,12 +13,15 @@ Forward schedule per bottleneck (ir_CSN_152.py:70-90), all BN statistics fused i
     cd = gemm_nt(gather(x), Wd)    [+stats]   -> bn_finalize(down_sample.1)      (first block of a stage)
     y  = relu(bn4(c4) + (bn_d(cd) | x))
 """
+import os
+
 import torch
 from torch import nn
 
 from . import lib
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
+DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
 CMAX = 2048
@@ -241,13 +244,19 @@ class CSNRunner:
             self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
             c3 = torch.empty(Mout, P, dtype=BF, device=dev)
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
+            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED        # LDS-staged kernels for the stride-1 blocks (47 of 50)
             if train:
-                R = lib.query("tuber_dwconv_fwd_stat_rows", B, To, Hq, Wq)
+                R = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_fwd_stat_rows", B, To, Hq, Wq)
                 st0, st1 = self.ws("st0", R * P), self.ws("st1", R * P)
+            else:
+                st0 = st1 = None
+            if tile:
+                lib.call("tuber_dwconv_tile_fwd", c1, b1.scale, b1.shift, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, P)
+            else:
                 lib.call("tuber_dwconv_fwd", c1, b1.scale, b1.shift, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+            if train:
                 self._bn_train(b3, st0, st1, R, Mout)
             else:
-                lib.call("tuber_dwconv_fwd", c1, b1.scale, b1.shift, d["w3"], c3, None, None, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
                 self._bn_eval(b3)
             c4 = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
             self._gemm_stats(c3, P, d["w4"], P, c4, Mout, 4 * P, P, 1, b3.scale, b3.shift, None, b4, train)
@@ -317,14 +326,21 @@ class CSNRunner:
                      2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0)
             dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
-            nb = lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
+            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
+            nb = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
             with self.store.side(dc3, c1):
-                lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
-                         To, Hq, Wq, P, st, ss)
-            R1 = lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
+                if tile:
+                    lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi, P)
+                else:
+                    lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
+                             To, Hq, Wq, P, st, ss)
+            R1 = nb if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
             s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
             dz1 = torch.empty(Min, P, dtype=BF, device=dev)
-            lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+            if tile:
+                lib.call("tuber_dwconv_tile_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
+            else:
+                lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
             dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min)
             # conv1: weight grad and data grad (+ identity shortcut gradient as residual)
             with self.store.side(dc1, x):

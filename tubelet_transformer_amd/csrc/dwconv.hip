@@ -411,6 +411,12 @@ int tuber_dwconv_bwd_data(const void* gout, const float* w, const void* x, const
     TUBER_RETURN_LAUNCH();
 }
 
+// dw[c][tap] (+)= sum_r partial[r][tap][c]
+int tuber_dw_wgrad_reduce(const float* partial, float* dw, int R, int C, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div(27 * C, 32)), dim3(1024), 0, stream, partial, dw, R, C, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
 // partial must hold blocks * 27 * C floats; dw is the [C][27] fp32 weight gradient
 int tuber_dwconv_bwd_weight(const void* gout, const void* x, const float* sc, const float* sh, float* partial, float* dw,
                             int accumulate, int N, int Ti, int Hi, int Wi, int To, int Ho, int Wo, int C, int st, int ss,

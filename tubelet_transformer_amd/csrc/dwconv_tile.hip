@@ -1,0 +1,331 @@
+// LDS-staged depthwise 3x3x3 Conv3d for the stride-1 bottlenecks (47 of the 50 CSN-152 blocks) -- gfx950.
+// reference: ResNeXtBottleneck.conv3, models/backbones/ir_CSN_152.py:48-51 (groups = C, padding 1).
+//
+// The register-tiled kernels of dwconv.hip re-activate (BatchNorm apply + ReLU + padding select) every input vector in
+// every thread that touches it -- 13.5x redundant VALU work, which is what bounds them (layer1: 94 us for 89 MB).  Here a
+// 512-thread workgroup owns an 8 x 16 output tile of 64 channels and slides over a range of output planes t:
+//   * each input plane (10 x 18 positions with halo) is fetched ONCE per workgroup, activated once, and parked in a
+//     3-plane LDS ring as fp32 (3 x 46 KB); the fetch of plane t+2 is in flight while plane t is computed;
+//   * a thread owns 4 channels x 4 consecutive output columns of one tile row and reads its 9 x 6 input vectors with
+//     conflict-free ds_read_b128; the 27 x 4 filter taps live in registers; the 432 FMAs per plane are written on float2 so
+//     the compiler can pair them (v_pk_fma_f32);
+//   * zero padding is applied AFTER the activation (the reference pads relu(bn1(.))).
+// Modes: forward (+ partial statistics of bn3), data gradient (flipped taps; fused with the backward of relu(bn1(.)) and
+// bn1's partial statistics), weight gradient (27 x 4 accumulators per thread, one partial [27][64] per workgroup).
+#include "common.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+extern "C" int tuber_dw_wgrad_reduce(const float* partial, float* dw, int R, int C, int accumulate, hipStream_t stream);
+
+namespace {
+
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPOS = PH * PW;     // 180 staged positions per plane
+constexpr int PLANE = NPOS * 64;                                             // floats
+constexpr int NLD = (NPOS * 16 + 511) / 512;                                 // 6 vector loads per thread per plane
+
+struct TileGeom {
+    int N, T, H, W, C;
+    int tc, tchunks, htiles, wtiles;
+};
+
+enum { M_FWD = 0, M_BWD_DATA = 1, M_BWD_WEIGHT = 2 };
+
+struct TileArgs {
+    const bf16* in;        // staged tensor: x (fwd / wgrad: activated on load when sc != NULL) or gout (bwd data)
+    const float* sc; const float* sh;
+    const float* w;        // [C][27] fp32
+    bf16* out;             // fwd: conv output; bwd data: dz
+    const bf16* aux;       // bwd data: x at the output position (mask + statistics);  wgrad: gout
+    float* st0; float* st1;   // partial statistics rows [gridDim.x][C]
+    float* P;              // wgrad partials [gridDim.x][27][C]
+    TileGeom g;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
+    const TileGeom g = a.g;
+    const int tid = threadIdx.x;
+    const int cl = tid & 15, slot = tid >> 4, row = slot >> 2, cg = slot & 3;
+    const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
+    int b = blockIdx.x;
+    const int wt = b % g.wtiles; b /= g.wtiles;
+    const int ht = b % g.htiles; b /= g.htiles;
+    const int tk = b % g.tchunks; const int n = b / g.tchunks;
+    const int h0 = ht * TH, w0 = wt * TW;
+    const int t0 = tk * g.tc, t1 = min(g.T, t0 + g.tc);
+
+    // ---- per-thread staging slots (loop invariant over t) ----
+    int s_off[NLD], s_lds[NLD];
+    bool s_ok[NLD];
+    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};   // (tid + 512 i) & 15 == cl: one channel quad per thread
+    const bool act = (MODE != M_BWD_DATA) && a.sc != nullptr;
+    if (act) {
+        const float4 s = *(const float4*)(a.sc + c), h = *(const float4*)(a.sh + c);
+        sa[0] = s.x; sa[1] = s.y; sa[2] = s.z; sa[3] = s.w; sb[0] = h.x; sb[1] = h.y; sb[2] = h.z; sb[3] = h.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        const int pos = idx >> 4, q = idx & 15;
+        const int pr = pos / PW, pc = pos % PW;
+        const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
+        s_ok[i] = pos < NPOS && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+        s_off[i] = s_ok[i] ? (hi * g.W + wi) * g.C + c0 + q * 4 : 0;
+        s_lds[i] = pos < NPOS ? pos * 64 + q * 4 : -1;
+    }
+    const long plane_elems = (long)g.H * g.W * g.C;
+    const bf16* in_n = a.in + (long)n * g.T * plane_elems;
+    uint2 regs[NLD];
+    auto fetch = [&](int t) {                      // input plane t -> registers (zeros outside the volume)
+        const bool tok = t >= 0 && t < g.T;
+        const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) regs[i] = (tok && s_ok[i]) ? *(const uint2*)(p + s_off[i]) : make_uint2(0, 0);
+    };
+    auto park = [&](int t) {                       // registers -> activated fp32 in ring slot t mod 3
+        const bool tok = t >= 0 && t < g.T;
+        float* dst = smem + ((t + 3) % 3) * PLANE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (s_lds[i] < 0) continue;
+            const bf16x4 v = as_bf16x4(regs[i]);
+            float4 o;
+            if (act) {
+                const bool ok = tok && s_ok[i];
+                o.x = ok ? fmaxf(fmaf(bf2f(v[0]), sa[0], sb[0]), 0.f) : 0.f;
+                o.y = ok ? fmaxf(fmaf(bf2f(v[1]), sa[1], sb[1]), 0.f) : 0.f;
+                o.z = ok ? fmaxf(fmaf(bf2f(v[2]), sa[2], sb[2]), 0.f) : 0.f;
+                o.w = ok ? fmaxf(fmaf(bf2f(v[3]), sa[3], sb[3]), 0.f) : 0.f;
+            } else {
+                o.x = bf2f(v[0]); o.y = bf2f(v[1]); o.z = bf2f(v[2]); o.w = bf2f(v[3]);   // zeros already where outside
+            }
+            *(float4*)(dst + s_lds[i]) = o;
+        }
+    };
+
+    // ---- filter taps of this thread's 4 channels (bwd data: flipped) ----
+    // filter taps [27][64] stay in LDS behind the ring (bwd data: flipped); every lane group reads its quad as a broadcast --
+    // 108 more VGPRs for register-resident taps spill this kernel
+    float* wl = smem + 3 * PLANE;
+    if constexpr (MODE != M_BWD_WEIGHT) {
+        for (int i = tid; i < 27 * 64; i += 512) {
+            const int cc = i / 27, tap = i % 27;
+            wl[(MODE == M_BWD_DATA ? 26 - tap : tap) * 64 + cc] = a.w[(long)c0 * 27 + i];
+        }
+    }
+    f32x2 wacc[MODE == M_BWD_WEIGHT ? 27 : 1][2];
+    if constexpr (MODE == M_BWD_WEIGHT) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) { wacc[t][0] = f32x2{0.f, 0.f}; wacc[t][1] = f32x2{0.f, 0.f}; }
+    }
+    float a4[4] = {1.f, 1.f, 1.f, 1.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};      // bwd data: bn1 scale/shift of the mask
+    if (MODE == M_BWD_DATA) {
+        const float4 s = *(const float4*)(a.sc + c), h = *(const float4*)(a.sh + c);
+        a4[0] = s.x; a4[1] = s.y; a4[2] = s.z; a4[3] = s.w; b4[0] = h.x; b4[1] = h.y; b4[2] = h.z; b4[3] = h.w;
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: planes t0-1 and t0 parked, t0+1 in flight ----
+    fetch(t0 - 1); park(t0 - 1);
+    fetch(t0); park(t0);
+    fetch(t0 + 1);
+    const int ho = h0 + row, wo0 = w0 + cg * 4;
+    const bool row_ok = ho < g.H;
+    for (int t = t0; t < t1; ++t) {
+        park(t + 1);
+        if (t + 1 < t1) fetch(t + 2);
+        // side inputs of this output plane (global, 8 B per column): bwd data: x;  wgrad: gout
+        uint2 side[4];
+        const long obase = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
+        if (MODE != M_FWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                side[j] = (row_ok && wo0 + j < g.W) ? *(const uint2*)(a.aux + obase + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+        }
+        __syncthreads();
+        f32x2 acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j][0] = f32x2{0.f, 0.f}; acc[j][1] = f32x2{0.f, 0.f}; }
+        f32x2 gv[4][2];
+        if constexpr (MODE == M_BWD_WEIGHT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x4 v = as_bf16x4(side[j]);
+                gv[j][0] = f32x2{bf2f(v[0]), bf2f(v[1])};
+                gv[j][1] = f32x2{bf2f(v[2]), bf2f(v[3])};
+            }
+        }
+        auto tap_plane = [&](int dt) {
+            const float* pl = smem + ((t + dt - 1 + 3) % 3) * PLANE;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const float* rp = pl + ((row + dh) * PW + cg * 4) * 64 + cl * 4;
+                f32x2 in[6][2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float4 v = *(const float4*)(rp + i * 64);
+                    in[i][0] = f32x2{v.x, v.y};
+                    in[i][1] = f32x2{v.z, v.w};
+                }
+                f32x2 wt2[3][2];
+                if constexpr (MODE != M_BWD_WEIGHT) {
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const float4 v = *(const float4*)(wl + ((dt * 3 + dh) * 3 + dw) * 64 + cl * 4);
+                        wt2[dw][0] = f32x2{v.x, v.y};
+                        wt2[dw][1] = f32x2{v.z, v.w};
+                    }
+                }
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int tap = (dt * 3 + dh) * 3 + dw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (MODE == M_BWD_WEIGHT) {
+                            wacc[tap][0] = gv[j][0] * in[j + dw][0] + wacc[tap][0];
+                            wacc[tap][1] = gv[j][1] * in[j + dw][1] + wacc[tap][1];
+                        } else {
+                            acc[j][0] = in[j + dw][0] * wt2[dw][0] + acc[j][0];
+                            acc[j][1] = in[j + dw][1] * wt2[dw][1] + acc[j][1];
+                        }
+                    }
+                }
+            }
+                };
+        if constexpr (MODE == M_BWD_WEIGHT) {         // accumulators are indexed by the tap: needs compile-time dt
+            tap_plane(0); tap_plane(1); tap_plane(2);
+        } else {
+#pragma unroll 1                                      // one temporal tap per pass keeps the live LDS reads at 18 vectors (no spills)
+            for (int dt = 0; dt < 3; ++dt) tap_plane(dt);
+        }
+        if constexpr (MODE != M_BWD_WEIGHT) if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (wo0 + j >= g.W) continue;
+                float v[4] = {acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
+                bf16x4 o;
+                if constexpr (MODE == M_FWD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = f2bf(v[e]); s0[e] += v[e]; s1[e] += v[e] * v[e]; }
+                } else {
+                    const bf16x4 xv = as_bf16x4(side[j]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xf = bf2f(xv[e]);
+                        const float d = fmaf(xf, a4[e], b4[e]) > 0.f ? v[e] : 0.f;
+                        o[e] = f2bf(d);
+                        s0[e] += d; s1[e] += d * xf;
+                    }
+                }
+                *(uint2*)(a.out + obase + (long)(wo0 + j) * g.C) = as_uint2(o);
+            }
+        }
+        __syncthreads();                              // ring slot (t-1) mod 3 is overwritten by the next park
+    }
+
+    // ---- workgroup reduction over the 32 position slots ----
+    float* red = smem;                                // the ring is dead now
+    if constexpr (MODE == M_BWD_WEIGHT) {
+        // [27][64] partial: lanes sharing cl within a wave by shuffles (slot bits 0..1 = lane bits 4..5), waves via LDS
+        const int wave = tid >> 6;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = wacc[t][e >> 1][e & 1];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if ((tid & 63) < 16) red[(wave * 27 + t) * 64 + cl * 4 + e] = v;
+            }
+        __syncthreads();
+        for (int i = tid; i < 27 * 64; i += 512) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv8 = 0; wv8 < 8; ++wv8) s += red[wv8 * 27 * 64 + i];
+            const int tap = i >> 6, cc = i & 63;
+            a.P[((long)blockIdx.x * 27 + tap) * g.C + c0 + cc] = s;
+        }
+    } else if (a.st0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[slot * 64 + cl * 4 + e] = s0[e]; red[(32 + slot) * 64 + cl * 4 + e] = s1[e]; }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, cc = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += red[(which * 32 + k) * 64 + cc];
+            (which ? a.st1 : a.st0)[(long)blockIdx.x * g.C + c0 + cc] = s;
+        }
+    }
+}
+
+TileGeom make_geom(int N, int T, int H, int W, int C) {
+    TileGeom g;
+    g.N = N; g.T = T; g.H = H; g.W = W; g.C = C;
+    g.htiles = (H + TH - 1) / TH; g.wtiles = (W + TW - 1) / TW;
+    const long base = (long)N * g.htiles * g.wtiles * (C / 64);
+    long tc = (long)T * base / 512;                 // >= ~512 workgroups when the volume allows; halo re-fetch is cheap
+    if (tc < 1) tc = 1;
+    if (tc > T) tc = T;
+    g.tc = (int)tc;
+    g.tchunks = (T + g.tc - 1) / g.tc;
+    return g;
+}
+
+template <int MODE>
+int launch_tile(TileArgs& a, hipStream_t stream) {
+    const TileGeom& g = a.g;
+    dim3 grid(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), block(512);
+    const size_t lds = (3 * PLANE + 27 * 64) * sizeof(float);       // ring + filter taps (wgrad reuses the ring for its reduction)
+    static bool attr_done[3] = {false, false, false};
+    if (!attr_done[MODE]) {                            // > 64 KB of dynamic LDS needs the opt-in once per kernel
+        hipFuncSetAttribute((const void*)dwconv_tile_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[MODE] = true;
+    }
+    hipLaunchKernelGGL(dwconv_tile_kernel<MODE>, grid, block, lds, stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" {
+
+// rows of partial statistics (forward, data gradient) = workgroups along x = partial blocks of the weight gradient
+int tuber_dwconv_tile_blocks(int N, int T, int H, int W, int C) {
+    const TileGeom g = make_geom(N, T, H, W, C);
+    return g.N * g.tchunks * g.htiles * g.wtiles;
+}
+
+int tuber_dwconv_tile_fwd(const void* x, const float* sc, const float* sh, const float* w, void* out, float* st0, float* st1,
+                          int N, int T, int H, int W, int C, hipStream_t stream) {
+    if (C & 63) return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.w = w; a.out = (bf16*)out; a.st0 = st0; a.st1 = st1;
+    a.g = make_geom(N, T, H, W, C);
+    return launch_tile<M_FWD>(a, stream);
+}
+
+int tuber_dwconv_tile_bwd_data(const void* gout, const float* w, const void* x, const float* sc, const float* sh, void* dz,
+                               float* st0, float* st1, int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || !sc || !sh) return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)gout; a.sc = sc; a.sh = sh; a.w = w; a.out = (bf16*)dz; a.aux = (const bf16*)x; a.st0 = st0; a.st1 = st1;
+    a.g = make_geom(N, T, H, W, C);
+    return launch_tile<M_BWD_DATA>(a, stream);
+}
+
+// partial must hold tuber_dwconv_tile_blocks * 27 * C floats; dw is the [C][27] fp32 weight gradient
+int tuber_dwconv_tile_bwd_weight(const void* gout, const void* x, const float* sc, const float* sh, float* partial, float* dw,
+                                 int accumulate, int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || !sc || !sh) return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.aux = (const bf16*)gout; a.P = partial;
+    a.g = make_geom(N, T, H, W, C);
+    const int rc = launch_tile<M_BWD_WEIGHT>(a, stream);
+    if (rc) return rc;
+    return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
+}
+
+}  // extern "C"
