@@ -123,7 +123,30 @@ def bench_dw():
               % (N, T, H, W, C, mb, *t, R, C // 64), flush=True)
 
 
+def bench_attn():
+    import numpy as np
+    H, E = 8, 256
+    for B, Lq, Lk in [(48, 352, 352), (2, 352, 352), (2, 15, 352), (12, 15, 1408)]:
+        q = torch.randn(Lq, B, E, device=dev).to(BF)
+        k = torch.randn(Lk, B, E, device=dev).to(BF)
+        v = torch.randn(Lk, B, E, device=dev).to(BF)
+        o, do = torch.empty_like(q), torch.randn(Lq, B, E, device=dev).to(BF)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lse, delta = torch.empty(B, H, Lq, device=dev), torch.empty(B, H, Lq, device=dev)
+        mp = np.array([E, B, 1, 0, 1], dtype=np.int64)
+        m = mp.ctypes.data
+        seed = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        tf = time_it(lambda: lib.call("tuber_attn_fwd", q, m, k, m, v, m, o, m, lse, None, B, H, Lq, Lk, 32 ** -0.5, 0.1, seed, 3))
+        tb = time_it(lambda: lib.call("tuber_attn_bwd", q, m, k, m, v, m, o, m, lse, None, do, m, dq, m, dk, m, dv, m, delta, B, H, Lq, Lk,
+                                      32 ** -0.5, 0.1, seed, 3))
+        fl = 4.0 * B * H * Lq * Lk * 32
+        print("attention B%d Lq%d Lk%d: fwd %.1f us (%.1f TF/s), bwd %.1f us (%.1f TF/s)" % (B, Lq, Lk, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        bench_attn()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dw":
         bench_dw()
         sys.exit(0)

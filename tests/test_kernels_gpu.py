@@ -482,6 +482,45 @@ def test_attention_strided_maps_and_dropout(dev):
     assert 0.02 < rel < 0.6
 
 
+@pytest.mark.parametrize("Lq,Lk", [(64, 32), (100, 32), (15, 32)])
+def test_attention_dropout_backward(dev, Lq, Lk):
+    """Dropout on the attention weights, forward AND backward, against autograd: with Lk = 32 and V = I the forward output IS the
+    dropped probability matrix, which exposes the kernel's keep mask; the mask depends on (seed, salt, b, h, q, k) only, so the
+    same mask applies to a second call with random V.  Lq >= 32 takes the MFMA kernels, Lq = 15 the scalar ones."""
+    B, H, E, p = 2, 8, 256, 0.25
+    scale = 32 ** -0.5
+    seed_t = torch.full((1,), 11, dtype=torch.int64, device=dev)
+    q = rnd(Lq, B, E, dev=dev, seed=1).to(BF)
+    k = rnd(Lk, B, E, dev=dev, seed=2).to(BF)
+    v = rnd(Lk, B, E, dev=dev, seed=3).to(BF)
+    eye = torch.eye(32, device=dev).repeat(1, H).view(Lk, 1, E).repeat(1, B, 1).to(BF).contiguous()
+    mp = torch.tensor([E, B, 1, 0, 1], dtype=torch.int64).numpy()
+    mpp = mp.ctypes.data
+    lse = torch.empty(B, H, Lq, device=dev)
+    pd = torch.empty(Lq, B, E, device=dev, dtype=BF)
+    lib.call("tuber_attn_fwd", q, mpp, k, mpp, eye, mpp, pd, mpp, lse, None, B, H, Lq, Lk, scale, p, seed_t, 77)
+    keep = (pd.float().view(Lq, B, H, 32).permute(1, 2, 0, 3) > 0).float() / (1 - p)          # [B,H,Lq,Lk]
+    assert 0.6 < float((keep > 0).float().mean()) < 0.9
+
+    def heads(x, L):
+        return x.float().view(L, B, H, 32).permute(1, 2, 0, 3).requires_grad_(True)
+    qh, kh, vh = heads(q, Lq), heads(k, Lk), heads(v, Lk)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) * keep) @ vh
+    o = torch.empty(Lq, B, E, device=dev, dtype=BF)
+    lib.call("tuber_attn_fwd", q, mpp, k, mpp, v, mpp, o, mpp, lse, None, B, H, Lq, Lk, scale, p, seed_t, 77)
+    close("attention+dropout fwd", o, ref.permute(2, 0, 1, 3).reshape(Lq, B, E).detach())
+    do = rnd(Lq, B, E, dev=dev, seed=4).to(BF)
+    ref.backward(do.float().view(Lq, B, H, 32).permute(1, 2, 0, 3))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Lq, device=dev)
+    lib.call("tuber_attn_bwd", q, mpp, k, mpp, v, mpp, o, mpp, lse, None, do, mpp, dq, mpp, dk, mpp, dv, mpp, delta, B, H, Lq, Lk, scale,
+             p, seed_t, 77)
+    back = lambda t, L: t.grad.permute(2, 0, 1, 3).reshape(L, B, E)
+    close("attention+dropout bwd dq", dq, back(qh, Lq), rel=2 ** -5)
+    close("attention+dropout bwd dk", dk, back(kh, Lk), rel=2 ** -5)
+    close("attention+dropout bwd dv", dv, back(vh, Lk), rel=2 ** -5)
+
+
 @pytest.mark.parametrize("N,T,H,W", [(1, 4, 30, 38), (2, 3, 64, 340)])
 def test_stem(dev, N, T, H, W):
     clip = rnd(N, 3, T, H, W, dev=dev, seed=1)

@@ -14,29 +14,13 @@
 // 16 lanes that each walk a strided subset of the keys (queries) and are merged with wave shuffles.
 // Sequences are <= 1728 tokens.  Backward recomputes P from the saved
 // log-sum-exp (no P tensor in HBM).
-#include "common.h"
+#include <cstdlib>
 
-struct TokMap { long ld; long sL, s1, s2; int B2; };
+#include "attention.h"
+
 __device__ __forceinline__ long tok_row(const TokMap& m, int l, int b) {
     return (long)l * m.sL + (long)(b / m.B2) * m.s1 + (long)(b % m.B2) * m.s2;
 }
-
-struct AttnArgs {
-    const bf16* Q; TokMap mq;
-    const bf16* K; TokMap mk;
-    const bf16* V; TokMap mv;
-    bf16* O; TokMap mo;
-    float* lse;                   // [B][H][Lq]
-    const uint8_t* kpm;           // [B][Lk] (1 = padded key) or null
-    int B, H, Lq, Lk;
-    float scale, pdrop; uint32_t thresh; const uint64_t* seed_ptr; uint64_t salt;
-    // backward
-    const bf16* dO; TokMap mdo;
-    bf16* dQ; TokMap mdq;
-    bf16* dK; TokMap mdk;
-    bf16* dV; TokMap mdv;
-    float* delta;                 // [B][H][Lq]
-};
 
 __device__ __forceinline__ uint64_t eff_seed(const uint64_t* seed_ptr, uint64_t salt) {
     return (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
@@ -467,6 +451,16 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__
     }
 }
 
+// everything but short-query x short-key calls takes the MFMA kernels (attention_mfma.hip); measured on MI355X the tubelet-query
+// cross attentions (Lq = 15 against 352 / 1408 keys) are faster there too even with one active wave per 64-query block
+#define MFMA_MIN_LQ 32
+#define MFMA_MIN_LK 128
+static bool attn_force_scalar() {
+    static int v = -1;
+    if (v < 0) v = getenv("TUBER_ATTN_SCALAR") ? 1 : 0;      // A/B switch for profiling
+    return v == 1;
+}
+
 extern "C" {
 
 // maps: 5 longs each = {ld, sL, s1, s2, B2}
@@ -483,6 +477,8 @@ int tuber_attn_fwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
     if (Lq <= SMALL_L && Lk <= SMALL_L)
         hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(ceil_div((long)B * H * Lq, 256)), dim3(256), 0, stream, a);
+    else if ((Lq >= MFMA_MIN_LQ || Lk >= MFMA_MIN_LK) && !attn_force_scalar())
+        tuber_attn_mfma_fwd_launch(&a, stream);
     else
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
     TUBER_RETURN_LAUNCH();
@@ -502,6 +498,8 @@ int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.dV = (bf16*)dV; a.mdv = mk_map(mdv); a.delta = delta;
     if (Lq <= SMALL_L && Lk <= SMALL_L) {
         hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(ceil_div((long)B * H * (Lq > Lk ? Lq : Lk), 256)), dim3(256), 0, stream, a);
+    } else if ((Lq >= MFMA_MIN_LQ || Lk >= MFMA_MIN_LK) && !attn_force_scalar()) {
+        tuber_attn_mfma_bwd_launch(&a, stream);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(Lk, 16), H, B), dim3(256), 0, stream, a);

@@ -1,0 +1,286 @@
+// MFMA flash attention for 32-wide heads (gfx950, wave64): the Lq >= 32 cases of tuber_attn_fwd / tuber_attn_bwd --
+// the DETR encoder self-attention (352 tokens per clip) and the class branch's factorised spatial attention
+// (48 x 8 (batch, head) pairs of 352 x 352), i.e. ~3/4 of the attention time of the training step.
+// reference: nn.MultiheadAttention, models/transformer/transformer.py:159, transformer_layers.py:81,88.
+//
+// One MFMA 16x16x32 covers the whole head dimension, so QK^T costs one instruction per 16 x 16 score tile.  All products are
+// issued TRANSPOSED (keys / head dim as MFMA rows, queries or keys as MFMA columns) so that the accumulator layout of a score
+// tile (lane = one column, 4 consecutive rows) is already the B-operand layout of the following product -- P never goes
+// through LDS.  The 8 k-slots a lane contributes to that second product are rows {g*4..g*4+3} of two stacked 16-row tiles;
+// the A operand (V^T, K^T, Q^T, dO^T) is read from a transposed LDS image with the same slot order.
+//   forward : S^T = K Q^T, online softmax per query column (cross-lane-group max / sum = 2 shuffles), O^T += V^T P^T
+//   dQ      : S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
+//   dK, dV  : S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+// Dropout regenerates the forward mask from (seed, salt, ((b*H+h)*Lq+q)*Lk+k) like the scalar kernels of attention.hip.
+#include "attention.h"
+
+namespace {
+
+constexpr int TL = 64;      // rows (keys or queries) per staged tile
+constexpr int RP = 40;      // row-major image: 80-byte rows (ds_read_b128 of 16 different rows is conflict-free)
+constexpr int TP = 68;      // transposed image [32][TL + 4]: 136-byte rows (8-byte aligned 4-element groups)
+
+__device__ __forceinline__ long trow(const TokMap& m, int l, int b) {
+    return (long)l * m.sL + (long)(b / m.B2) * m.s1 + (long)(b % m.B2) * m.s2;
+}
+__device__ __forceinline__ uint64_t eseed(const uint64_t* seed_ptr, uint64_t salt) {
+    return (seed_ptr ? *seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + salt;
+}
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// one staged tile: thread t -> row r = t >> 2, 16-byte chunk c = t & 3 (8 head-dim elements)
+__device__ __forceinline__ uint4 tile_fetch(const bf16* base, const TokMap& m, int b, int h, int r0, int L) {
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    return (r0 + r < L) ? *(const uint4*)(base + trow(m, r0 + r, b) * m.ld + h * 32 + c * 8) : make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ void park_rm(bf16 (*dst)[RP], uint4 v) {
+    *(uint4*)&dst[threadIdx.x >> 2][(threadIdx.x & 3) * 8] = v;
+}
+__device__ __forceinline__ void park_tr(bf16 (*dst)[TP], uint4 v) {
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const bf16x8 x = as_bf16x8(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[c * 8 + e][r] = x[e];
+}
+// A operand from a row-major image: MFMA row i = image row (r0 + li), k = head dim g*8 .. g*8+7
+__device__ __forceinline__ bf16x8 frag_rm(const bf16 (*src)[RP], int r0, int li, int g) {
+    return as_bf16x8(*(const uint4*)&src[r0 + li][g * 8]);
+}
+// A operand from a transposed image: MFMA row i = head dim d, k-slots = image columns {c0+g*4..+3, c0+16+g*4..+3}
+__device__ __forceinline__ bf16x8 frag_tr(const bf16 (*src)[TP], int d, int c0, int g) {
+    const uint2 lo = *(const uint2*)&src[d][c0 + g * 4], hi = *(const uint2*)&src[d][c0 + 16 + g * 4];
+    return as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 vt[32][TP];
+    __shared__ uint8_t msk[TL];
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int qi = q0 + wave * 16 + li;
+    const bool qok = qi < a.Lq;
+    const int qc = qok ? qi : a.Lq - 1;
+    const bf16x8 qf = as_bf16x8(*(const uint4*)(a.Q + trow(a.mq, qc, b) * a.mq.ld + h * 32 + g * 8));
+    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
+    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, l = 0.f;
+    uint4 kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk), vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk);
+    for (int k0 = 0; k0 < a.Lk; k0 += TL) {
+        __syncthreads();
+        park_rm(ks, kr);
+        park_tr(vt, vr);
+        if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
+        if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int c0 = sub * 32;
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) s[t] = mfma(frag_rm(ks, c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            float p[8];
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = msk[c0 + t * 16 + g * 4 + r];
+                    p[t * 4 + r] = dead ? -INFINITY : s[t][r] * a.scale;
+                    cmax = fmaxf(cmax, p[t * 4 + r]);
+                }
+            cmax = group_max(cmax);
+            const float mnew = fmaxf(mx, cmax);
+            const float alpha = mnew == -INFINITY ? 1.f : __expf(mx - mnew);
+            float ls = 0.f;
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float pe = mnew == -INFINITY ? 0.f : __expf(p[e] - mnew);
+                ls += pe;
+                if (a.pdrop > 0.f) {
+                    const int kk = k0 + c0 + (e >> 2) * 16 + g * 4 + (e & 3);
+                    pe = dropout_keep(seed, rbase + kk, a.thresh) ? pe * inv_keep : 0.f;
+                }
+                pf[e] = f2bf(pe);
+            }
+            l = l * alpha + group_sum(ls);
+            mx = mnew;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            o0 = mfma(frag_tr(vt, li, c0, g), pf, o0);
+            o1 = mfma(frag_tr(vt, 16 + li, c0, g), pf, o1);
+        }
+    }
+    if (qok) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        bf16* orow = a.O + trow(a.mo, qi, b) * a.mo.ld + h * 32;
+        bf16x4 y0, y1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { y0[r] = f2bf(o0[r] * inv); y1[r] = f2bf(o1[r] * inv); }
+        *(uint2*)(orow + g * 4) = as_uint2(y0);
+        *(uint2*)(orow + 16 + g * 4) = as_uint2(y1);
+        if (a.lse && g == 0) a.lse[((long)b * a.H + h) * a.Lq + qi] = mx + __logf(l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ (and delta = dO . O for the dK/dV kernel): workgroup = 64 queries of one (b, h), loop over key tiles
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 vs[TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 kt[32][TP];
+    __shared__ uint8_t msk[TL];
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int qi = q0 + wave * 16 + li;
+    const bool qok = qi < a.Lq;
+    const int qc = qok ? qi : a.Lq - 1;
+    const bf16x8 qf = as_bf16x8(*(const uint4*)(a.Q + trow(a.mq, qc, b) * a.mq.ld + h * 32 + g * 8));
+    const bf16x8 dof = as_bf16x8(*(const uint4*)(a.dO + trow(a.mdo, qc, b) * a.mdo.ld + h * 32 + g * 8));
+    float delta;
+    {
+        const bf16x8 of = as_bf16x8(*(const uint4*)(a.O + trow(a.mo, qc, b) * a.mo.ld + h * 32 + g * 8));
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(bf2f(dof[e]), bf2f(of[e]), d);
+        delta = group_sum(d);
+    }
+    const float lse = a.lse[((long)b * a.H + h) * a.Lq + qc];
+    if (qok && g == 0) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
+    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
+    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    uint4 kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk), vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk);
+    for (int k0 = 0; k0 < a.Lk; k0 += TL) {
+        __syncthreads();
+        park_rm(ks, kr);
+        park_tr(kt, kr);
+        park_rm(vs, vr);
+        if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
+        if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int c0 = sub * 32;
+            bf16x8 dsf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 s = mfma(frag_rm(ks, c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 dp = mfma(frag_rm(vs, c0 + t * 16, li, g), dof, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kl = c0 + t * 16 + g * 4 + r;
+                    const float p = msk[kl] ? 0.f : __expf(s[r] * a.scale - lse);
+                    float dpv = dp[r];
+                    if (a.pdrop > 0.f) dpv = dropout_keep(seed, rbase + k0 + kl, a.thresh) ? dpv * inv_keep : 0.f;
+                    dsf[t * 4 + r] = f2bf(p * (dpv - delta) * a.scale);
+                }
+            }
+            dq0 = mfma(frag_tr(kt, li, c0, g), dsf, dq0);
+            dq1 = mfma(frag_tr(kt, 16 + li, c0, g), dsf, dq1);
+        }
+    }
+    if (qok) {
+        bf16* orow = a.dQ + trow(a.mdq, qi, b) * a.mdq.ld + h * 32;
+        bf16x4 y0, y1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { y0[r] = f2bf(dq0[r]); y1[r] = f2bf(dq1[r]); }
+        *(uint2*)(orow + g * 4) = as_uint2(y0);
+        *(uint2*)(orow + 16 + g * 4) = as_uint2(y1);
+    }
+}
+
+// dK, dV: workgroup = 64 keys of one (b, h), loop over query tiles
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 qs[TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 dos[TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 qt[32][TP];
+    __shared__ __attribute__((aligned(16))) bf16 dot_[32][TP];
+    __shared__ float lse_s[TL], del_s[TL];
+    const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x * 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int ki = kb + wave * 16 + li;
+    const bool kin = ki < a.Lk;
+    const int kc = kin ? ki : a.Lk - 1;
+    const bool kdead = !kin || (a.kpm && a.kpm[(long)b * a.Lk + kc]);
+    const bf16x8 kf = as_bf16x8(*(const uint4*)(a.K + trow(a.mk, kc, b) * a.mk.ld + h * 32 + g * 8));
+    const bf16x8 vf = as_bf16x8(*(const uint4*)(a.V + trow(a.mv, kc, b) * a.mv.ld + h * 32 + g * 8));
+    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
+    const uint64_t bh = (uint64_t)(b * a.H + h);
+    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
+    uint4 qr = tile_fetch(a.Q, a.mq, b, h, 0, a.Lq), dr = tile_fetch(a.dO, a.mdo, b, h, 0, a.Lq);
+    float lr = 0.f, er = 0.f;
+    if (threadIdx.x < TL && threadIdx.x < a.Lq) { lr = a.lse[bh * a.Lq + threadIdx.x]; er = a.delta[bh * a.Lq + threadIdx.x]; }
+    for (int q0 = 0; q0 < a.Lq; q0 += TL) {
+        __syncthreads();
+        park_rm(qs, qr); park_tr(qt, qr);
+        park_rm(dos, dr); park_tr(dot_, dr);
+        if (threadIdx.x < TL) { lse_s[threadIdx.x] = lr; del_s[threadIdx.x] = er; }
+        if (q0 + TL < a.Lq) {
+            qr = tile_fetch(a.Q, a.mq, b, h, q0 + TL, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, q0 + TL, a.Lq);
+            const int qn = q0 + TL + threadIdx.x;
+            if (threadIdx.x < TL) { lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int c0 = sub * 32;
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 s = mfma(frag_rm(qs, c0 + t * 16, li, g), kf, f32x4{0.f, 0.f, 0.f, 0.f});      // S[q][key li]
+                const f32x4 dp = mfma(frag_rm(dos, c0 + t * 16, li, g), vf, f32x4{0.f, 0.f, 0.f, 0.f});    // dP[q][key li]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = c0 + t * 16 + g * 4 + r, qq = q0 + ql;
+                    const bool live = !kdead && qq < a.Lq;
+                    const float p = live ? __expf(s[r] * a.scale - lse_s[ql]) : 0.f;
+                    float pd = p, dpv = dp[r];
+                    if (a.pdrop > 0.f) {
+                        const bool keep = dropout_keep(seed, (bh * a.Lq + (uint64_t)(live ? qq : 0)) * (uint64_t)a.Lk + kc, a.thresh);
+                        pd = keep ? p * inv_keep : 0.f;
+                        dpv = keep ? dpv * inv_keep : 0.f;
+                    }
+                    pf[t * 4 + r] = f2bf(pd);
+                    dsf[t * 4 + r] = f2bf(p * (dpv - del_s[ql]) * a.scale);
+                }
+            }
+            dv0 = mfma(frag_tr(dot_, li, c0, g), pf, dv0);
+            dv1 = mfma(frag_tr(dot_, 16 + li, c0, g), pf, dv1);
+            dk0 = mfma(frag_tr(qt, li, c0, g), dsf, dk0);
+            dk1 = mfma(frag_tr(qt, 16 + li, c0, g), dsf, dk1);
+        }
+    }
+    if (kin) {
+        bf16* krow = a.dK + trow(a.mdk, ki, b) * a.mdk.ld + h * 32;
+        bf16* vrow = a.dV + trow(a.mdv, ki, b) * a.mdv.ld + h * 32;
+        bf16x4 y0, y1, z0, z1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { y0[r] = f2bf(dk0[r]); y1[r] = f2bf(dk1[r]); z0[r] = f2bf(dv0[r]); z1[r] = f2bf(dv1[r]); }
+        *(uint2*)(krow + g * 4) = as_uint2(y0);
+        *(uint2*)(krow + 16 + g * 4) = as_uint2(y1);
+        *(uint2*)(vrow + g * 4) = as_uint2(z0);
+        *(uint2*)(vrow + 16 + g * 4) = as_uint2(z1);
+    }
+}
+
+}  // namespace
+
+// entry points used by tuber_attn_fwd / tuber_attn_bwd (attention.hip) for Lq >= 32; `args` is an AttnArgs
+extern "C" void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream) {
+    const AttnArgs& a = *(const AttnArgs*)args;
+    hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
+}
+extern "C" void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream) {
+    const AttnArgs& a = *(const AttnArgs*)args;
+    hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel, dim3(ceil_div(a.Lk, 64), a.H, a.B), dim3(256), 0, stream, a);
+}
