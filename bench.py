@@ -33,13 +33,13 @@ def alg_cost(name, a):
     if name == "tuber_gemm_nt":
         M, N, K = a[6], a[7], a[8]
         amode, epi, out_f32 = a[9], a[21], a[26]
-        cfg = lib.query("tuber_gemm_nt_cfg", M, N)
+        cfg = lib.query("tuber_gemm_nt_cfg", M, N, K)
         by = 2 * (M * K + N * K) + (4 if out_f32 else 2) * M * N
         if a[23] is not None:
             by += 2 * M * N          # residual read
         if epi == 2:
             by += 2 * M * N          # mask source read
-        tile = {0: "128,128,2,2", 1: "128,64,4,1", 2: "64,64,2,2"}[cfg]
+        tile = {0: "128,128,2,2,2", 1: "128,64,4,1,2", 2: "64,64,2,2,4", 7: "64,128,1,4,2"}[cfg]
         return "gemm_nt_kernel<%s,%d,%d>" % (tile, amode, epi), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
@@ -54,6 +54,12 @@ def alg_cost(name, a):
         key = {"tuber_dwconv_fwd": "dwconv_fwd_kernel<%d>" % ss, "tuber_dwconv_bwd_data": "dwconv_bwd_data_kernel<%d>" % ss,
                "tuber_dwconv_bwd_weight": "dwconv_bwd_weight_kernel<%d>" % ss}[name]
         return key, by, 2 * 27 * C * N * To * Ho * Wo
+    if name in ("tuber_dwconv_tile_fwd", "tuber_dwconv_tile_bwd_data", "tuber_dwconv_tile_bwd_weight"):
+        off = 8 if name == "tuber_dwconv_tile_bwd_data" else 7
+        N, T, H, W, C = a[off:off + 5]
+        el = C * N * T * H * W
+        mode = {"tuber_dwconv_tile_fwd": 0, "tuber_dwconv_tile_bwd_data": 1, "tuber_dwconv_tile_bwd_weight": 2}[name]
+        return "dwconv_tile_kernel<%d>" % mode, 2 * el * (3 if mode == 1 else 2), 2 * 27 * el
     if name == "tuber_block_out_fwd":
         return "block_out_fwd_kernel", 2 * 3 * a[7] * a[8], 0
     if name == "tuber_block_out_bwd":
@@ -85,6 +91,9 @@ def shape_of(name, a):
     if name in ("tuber_bn_bwd_apply", "tuber_block_out_fwd", "tuber_block_out_bwd", "tuber_bn_finalize", "tuber_bn_bwd_finalize",
                 "tuber_reduce_rows", "tuber_colsum", "tuber_reduce_slabs", "tuber_layernorm_fwd", "tuber_layernorm_bwd", "tuber_dropout"):
         return " ".join(str(x) for x in a if isinstance(x, int) and not isinstance(x, bool))[:44]
+    if name.startswith("tuber_dwconv_tile"):
+        off = 8 if name == "tuber_dwconv_tile_bwd_data" else 7
+        return "N%d %dx%dx%d C%d" % tuple(a[off:off + 5])
     if name.startswith("tuber_dwconv"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
         return "N%d in%dx%dx%d out%dx%dx%d C%d st%d ss%d" % tuple(a[off:off + 10])
@@ -243,8 +252,10 @@ def main():
     if not args.no_roofline:
         timer = LaunchTimer()
         lib.set_launch_hook(timer)
+        os.environ["TUBER_NO_SIDE_STREAM"] = "1"        # per-kernel timing: every launch on one stream, nothing concurrent
         eager_step()
         torch.cuda.synchronize()
+        os.environ.pop("TUBER_NO_SIDE_STREAM", None)
         lib.set_launch_hook(None)
         prepass = timer.summary()
         if os.environ.get("TUBER_BENCH_SHAPES") and rank == 0:
@@ -262,9 +273,11 @@ def main():
     timer = LaunchTimer(only=dominant) if dominant else None
     if timer:
         lib.set_launch_hook(timer)
+        os.environ["TUBER_NO_SIDE_STREAM"] = "1"
         for _ in range(min(args.steps, 3)):
             eager_step()
         torch.cuda.synchronize()
+        os.environ.pop("TUBER_NO_SIDE_STREAM", None)
         lib.set_launch_hook(None)
         timed_steps = min(args.steps, 3)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -281,7 +294,7 @@ def main():
         "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights"
                                % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1]),
                    "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce)" % world, "launch_mode": mode},
-        "final_loss": round(float(loss), 4) if loss is not None else None,
+        "final_loss": round(float(loss.detach()), 4) if loss is not None else None,
         "alg_gflop_per_clip_fwd_bwd": 981.0,
         "readme_implied_gflops": round(total_clips / dt * 120.0, 1),
     }

@@ -321,7 +321,18 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : 0);
     dim3 grid(tiles), block(256);
-#define LNT(AM, EP) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>), grid, block, lds, s, p)
+#define LNT(AM, EP)                                                                                                   \
+    do {                                                                                                              \
+        if (lds > 65536) { /* more than 64 KB of dynamic LDS needs a one-time opt-in per kernel */                    \
+            static bool done = false;                                                                                 \
+            if (!done) {                                                                                              \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>,                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+                done = true;                                                                                          \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>), grid, block, lds, s, p);                      \
+    } while (0)
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
@@ -341,16 +352,17 @@ static int nt_force_cfg() {
     if (g_nt_force == -2) { const char* e = getenv("TUBER_NT_CFG"); g_nt_force = e ? atoi(e) : -1; }
     return g_nt_force;
 }
-static int nt_pick_cfg(int M, int N) {
+static int nt_pick_cfg(int M, int N, int K) {
     if (nt_force_cfg() >= 0) return nt_force_cfg();       // tuning / experiments only
-    // measured on MI355X (profiles/r01_c_*): the 64x64 tile (4-5 workgroups resident per CU) beats 128x128 on every
-    // HBM-bound / small-K shape of the backbone; 128x128 only pays for the big class-branch GEMMs.
-    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    return (N >= 512 && t128 >= 1024) ? 0 : 2;
+    // measured on MI355X in isolation (scripts/gemm_bench.py, profiles/r01_*): every tile here has 64 rows (one partial-statistics
+    // row per 64 output rows); 64x64 (4-5 workgroups resident per CU) wins the small-N and long-K shapes, 64x128 the wide
+    // short-K ones (conv4 / dgrad1 of layer1-3, class-branch projections) where re-reading A per 64 columns is what costs
+    return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 2;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0 || cfg == 3) { *bm = 128; *wm = 2; }
     else if (cfg == 1 || cfg == 5) { *bm = 128; *wm = 4; }
+    else if (cfg == 6 || cfg == 7) { *bm = 64; *wm = 1; }
     else { *bm = 64; *wm = 2; }
 }
 
@@ -359,13 +371,13 @@ extern "C" {
 // number of partial-statistics rows gemm_nt writes for (M, N): the caller sizes stat0/stat1 as
 // [rows][N] floats and hands the same row count to the finalize kernels.
 // tile configuration tuber_gemm_nt picks for (M, N): 0 = 128x128, 1 = 128x64, 2 = 64x64 (profiling / tests)
-int tuber_gemm_nt_cfg(int M, int N) { return nt_pick_cfg(M, N); }
+int tuber_gemm_nt_cfg(int M, int N, int K) { return nt_pick_cfg(M, N, K); }
 
 int tuber_gemm_nt_set_cfg(int cfg) { g_nt_force = cfg < 0 ? -1 : cfg; return 0; }
 
 int tuber_gemm_nt_stat_rows(int M, int N) {
     int bm, wm;
-    nt_cfg_dims(nt_pick_cfg(M, N), &bm, &wm);
+    nt_cfg_dims(nt_pick_cfg(M, N, 64), &bm, &wm);     // every automatic choice has 64-row tiles
     return ceil_div(M, bm);
 }
 
@@ -391,12 +403,14 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
-    switch (nt_pick_cfg(M, N)) {
+    switch (nt_pick_cfg(M, N, K)) {
         case 0: return launch_nt_cfg<128, 128, 2, 2, 2>(p, amode, epi, stream);
         case 1: return launch_nt_cfg<128, 64, 4, 1, 2>(p, amode, epi, stream);
         case 3: return launch_nt_cfg<128, 128, 2, 2, 4>(p, amode, epi, stream);
         case 4: return launch_nt_cfg<64, 64, 2, 2, 8>(p, amode, epi, stream);
         case 5: return launch_nt_cfg<128, 64, 4, 1, 4>(p, amode, epi, stream);
+        case 6: return launch_nt_cfg<64, 256, 1, 4, 2>(p, amode, epi, stream);
+        case 7: return launch_nt_cfg<64, 128, 1, 4, 2>(p, amode, epi, stream);
         default: return launch_nt_cfg<64, 64, 2, 2, 4>(p, amode, epi, stream);
     }
 }
