@@ -58,3 +58,29 @@ def test_criterion_matches_reference(dev, golden_dir, name, yaml_name):
         gw = max(gw, float(np.abs(got - ref).max()))
     print("%s: worst abs gradient error w.r.t. the outputs %.2e" % (name, gw))
     assert gw <= 2e-5
+
+
+@pytest.mark.gpu
+def test_device_assignment_matches_host_lsap():
+    """tuber_lsap_device (one thread per problem) against the host tuber_lsap on random, tie-heavy and rectangular problems."""
+    import numpy as np
+    from tubelet_transformer_amd import lib
+    from tubelet_transformer_amd.criterion import _lsap
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    for (L, B, Q, Tmax) in [(6, 2, 15, 8), (3, 4, 10, 16), (2, 3, 40, 24), (1, 2, 5, 8)]:
+        cost = rng.standard_normal((L, B, Q, Tmax)).astype(np.float32)
+        cost[0] = np.round(cost[0] * 2) / 2                      # many exact ties
+        if L > 1:
+            cost[1, :, :, :] = cost[1, :, :1, :]                 # identical rows: ties between queries
+        sizes = [int(rng.integers(0, Tmax + 1)) for _ in range(B)]
+        sizes[0] = min(Tmax, Q + 1) if Tmax > Q else Tmax        # more targets than queries where possible
+        match = torch.full((L, B, Tmax), -7, dtype=torch.int32, device=dev)
+        lib.call("tuber_lsap_device", torch.from_numpy(cost).to(dev), torch.tensor(sizes, dtype=torch.int32, device=dev), match, L, B, Q, Tmax)
+        got = match.cpu().numpy()
+        for l in range(L):
+            for b, n in enumerate(sizes):
+                want = np.full(Tmax, -1, dtype=np.int32)
+                i, j = _lsap(cost[l, b, :, :n].astype(np.float64))
+                want[j] = i
+                assert np.array_equal(got[l, b], want), (L, B, Q, Tmax, l, b, n, got[l, b], want)

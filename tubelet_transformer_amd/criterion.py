@@ -142,7 +142,45 @@ class _SetCriterionBase(nn.Module):
         self.matcher, self.weight_dict = matcher, weight_dict
         self.eos_coef, self.losses, self.data_file = eos_coef, losses, data_file
         self.ava = data_file == "ava"
-        self.last_indices = None
+        self._indices, self._match_dev = None, None
+
+    # -- assignment ---------------------------------------------------------------------------------------
+    @property
+    def last_indices(self):
+        """reference order (main, aux_0 .. aux_4) list of per-clip (query_idx, target_idx) pairs of the last call; when the
+        assignment ran on the device this is where it is copied to the host (lazily: training never needs it)."""
+        if self._indices is None and self._match_dev is not None:
+            match, sizes = self._match_dev
+            m = match.cpu().numpy()
+            L = m.shape[0]
+            per_layer = []
+            for l in range(L):
+                per = []
+                for b, n in enumerate(sizes):
+                    q = m[l, b, :n]
+                    t = np.nonzero(q >= 0)[0]
+                    order = np.argsort(q[t], kind="stable")
+                    per.append((torch.as_tensor(q[t][order], dtype=torch.int64), torch.as_tensor(t[order], dtype=torch.int64)))
+                per_layer.append(per)
+            self._indices = [per_layer[L - 1]] + per_layer[:L - 1]
+        return self._indices
+
+    @last_indices.setter
+    def last_indices(self, v):
+        self._indices, self._match_dev = v, None
+
+    def assign(self, cost, pt):
+        """cost [L,B,Q,Tmax] (device) -> match int32 [L,B,Tmax] on the device.  tuber_lsap_device when the problems fit its
+        128 x 128 bound (no host round trip), else the host tuber_lsap."""
+        L, B, Q, T = cost.shape
+        if Q <= 128 and T <= 128:
+            match = torch.empty(L, B, T, dtype=torch.int32, device=cost.device)
+            lib.call("tuber_lsap_device", cost, pt.tcount, match, L, B, Q, T)
+            self._indices, self._match_dev = None, (match, list(pt.sizes))
+            return match
+        m, indices = self.matcher.solve(cost.cpu().numpy(), pt.sizes)
+        self.last_indices = [indices[L - 1]] + indices[:L - 1]
+        return torch.from_numpy(m).to(cost.device, non_blocking=True)
 
     # -- pieces (also used one by one by the hipGraph-captured step, training.GraphedStep) ----------------
     def stacked(self, outputs):
@@ -203,10 +241,7 @@ class _SetCriterionBase(nn.Module):
         with torch.no_grad():
             cost = self.matcher.cost(logits_s.detach().contiguous(), (logits_b if self.ava else logits_s).detach().contiguous(),
                                      boxes_s.detach().contiguous(), pt)
-            match, indices = self.matcher.solve(cost.cpu().numpy(), pt.sizes)          # the step's ONE device->host sync
-            match_dev = torch.from_numpy(match).to(logits.device, non_blocking=True)
-        L = logits.shape[0]
-        self.last_indices = [indices[L - 1]] + indices[:L - 1]                          # reference order: main, aux_0 .. aux_4
+            match_dev = self.assign(cost, pt)
         losses = self.losses_from_match(logits_s, logits_b, boxes_s, pt, match_dev, targets)
         losses["class_error"] = self.class_error(logits_s[-1], pt, match_dev[-1])
         return losses

@@ -216,6 +216,89 @@ __global__ __launch_bounds__(256) void criterion_loss_kernel(CritArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hungarian assignment ON THE DEVICE: one thread per (decoder layer, clip) problem -- the same shortest-augmenting-path
+// algorithm with SciPy's tie-breaking as the host tuber_lsap (lsap.cpp; call sites models/detr/matcher.py:80,
+// matcher_ucf.py:82), in double precision on the fp32 costs, so the result is identical.  The problems are tiny
+// (15 queries x <= a few targets), so the point is not speed but removing the step's only device->host round trip:
+// with the assignment on the device the whole training step is ONE hipGraph.
+// ---------------------------------------------------------------------------------------------------------------------
+#define LSAP_MAX 128
+#define LSAP_CACHE 1024
+__global__ void lsap_kernel(const float* __restrict__ cost, const int* __restrict__ tcount, int* __restrict__ match,
+                            int L, int B, int Q, int Tmax) {
+    // one 64-thread block per problem: the lanes stage the costs and clear the output, lane 0 runs the (inherently serial)
+    // augmenting-path search out of LDS (its latency, not private scratch in HBM, is what a serial GPU thread pays per access)
+    const int prob = blockIdx.x;
+    const int b = prob % B;
+    const float* C = cost + (long)prob * Q * Tmax;
+    int* out = match + (long)prob * Tmax;
+    __shared__ double u[LSAP_MAX], v[LSAP_MAX], spc[LSAP_MAX], cs[LSAP_CACHE];
+    __shared__ int path[LSAP_MAX], col4row[LSAP_MAX], row4col[LSAP_MAX], remaining[LSAP_MAX];
+    __shared__ bool SR[LSAP_MAX], SC[LSAP_MAX];
+    for (int t = threadIdx.x; t < Tmax; t += blockDim.x) out[t] = -1;
+    const int T = tcount[b];
+    if (T <= 0 || Q <= 0) return;
+    // rows = the smaller side (SciPy transposes when there are more rows than columns)
+    const bool tr = T < Q;
+    const int nr = tr ? T : Q, nc = tr ? Q : T;
+    const bool cached = nr * nc <= LSAP_CACHE;
+    if (cached)
+        for (int e = threadIdx.x; e < nr * nc; e += blockDim.x) {
+            const int i = e / nc, j = e % nc;
+            cs[e] = tr ? (double)C[(long)j * Tmax + i] : (double)C[(long)i * Tmax + j];
+        }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    auto cst = [&](int i, int j) -> double {
+        return cached ? cs[i * nc + j] : (tr ? (double)C[(long)j * Tmax + i] : (double)C[(long)i * Tmax + j]);
+    };
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    for (int i = 0; i < nr; ++i) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
+    for (int cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        for (int k = 0; k < nr; ++k) SR[k] = false;
+        for (int k = 0; k < nc; ++k) { SC[k] = false; spc[k] = INF; }
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            SR[i] = true;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = min_val + cst(i, j) - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            min_val = lowest;
+            if (min_val == INF) return;                      // infeasible (NaN / inf costs): leave the clip unmatched
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = true;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += min_val;
+        for (int k = 0; k < nr; ++k)
+            if (SR[k] && k != cur) u[k] += min_val - spc[col4row[k]];
+        for (int k = 0; k < nc; ++k)
+            if (SC[k]) v[k] -= min_val - spc[k];
+        int j = sink;
+        while (true) {
+            const int k = path[j];
+            row4col[j] = k;
+            const int tmp = col4row[k]; col4row[k] = j; j = tmp;
+            if (k == cur) break;
+        }
+    }
+    // match[target] = query
+    for (int i = 0; i < nr; ++i) {
+        if (tr) out[i] = col4row[i];          // rows are targets, columns queries
+        else out[col4row[i]] = i;             // rows are queries, columns targets
+    }
+}
+
 extern "C" {
 
 int tuber_criterion_cost(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
@@ -239,6 +322,14 @@ int tuber_criterion_loss(const float* logits, const float* logits_b, const float
     a.match = match; a.L = L; a.B = B; a.Q = Q; a.C = C; a.Tmax = Tmax; a.ava = ava; a.eos = eos; a.pos_weight = pos_weight;
     a.losses = losses; a.g_logits = g_logits; a.g_logits_b = g_logits_b; a.g_bbox = g_bbox; a.g_giou = g_giou;
     hipLaunchKernelGGL(criterion_loss_kernel, dim3(L), dim3(256), (size_t)B * Q * sizeof(int), stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
+// match[l][b][t] = query assigned to target t of clip b by decoder layer l (-1 beyond tcount[b]); cost is the [L,B,Q,Tmax] fp32
+// tensor of tuber_criterion_cost.  Q and Tmax must not exceed 128 (callers fall back to the host tuber_lsap otherwise).
+int tuber_lsap_device(const float* cost, const int* tcount, int* match, int L, int B, int Q, int Tmax, hipStream_t stream) {
+    if (L <= 0 || B <= 0 || Q <= 0 || Tmax <= 0 || Q > LSAP_MAX || Tmax > LSAP_MAX) return TUBER_EINVAL;
+    hipLaunchKernelGGL(lsap_kernel, dim3(L * B), dim3(64), 0, stream, cost, tcount, match, L, B, Q, Tmax);
     TUBER_RETURN_LAUNCH();
 }
 

@@ -77,6 +77,8 @@ DOC = {
     "tuber_attn_wide_bwd": "gradients dq [NQ,2048] and dkv [rows,4096] of tuber_attn_wide_fwd.",
     "tuber_lsap": "rectangular linear sum assignment on HOST doubles; restates scipy.optimize.linear_sum_assignment (call sites "
                   "models/detr/matcher.py:80, matcher_ucf.py:82) incl. its tie-breaking.",
+    "tuber_lsap_device": "the same assignment (scipy.optimize.linear_sum_assignment semantics incl. tie-breaking; matcher.py:80, matcher_ucf.py:82) for all "
+                         "(decoder layer, clip) problems at once ON THE DEVICE, one thread per problem: match[l][b][t] = query of target t.",
     "tuber_grad_norm_clip_coef": "global L2 norm of the flat gradient buffer and the clip coefficient min(1, max_norm/(norm+1e-6)), left on the device: "
                                  "torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1) (utils/video_action_recognition.py:153).",
     "tuber_adamw_segment": "AdamW update (torch.optim.AdamW semantics: decoupled decay, bias correction) of one contiguous flat segment with the "

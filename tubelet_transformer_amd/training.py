@@ -54,14 +54,13 @@ def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0,
 
 
 class GraphedTrainStep:
-    """The same optimisation step replayed from two captured hipGraphs (HIP graphs instead of a tracing compiler):
+    """The same optimisation step replayed from ONE captured hipGraph (HIP graphs instead of a tracing compiler): bf16 weight
+    refresh, forward of the whole model, matching-cost kernel, Hungarian assignment on the device (tuber_lsap_device), fused
+    criterion (losses + output gradients), backward of the whole model, global-norm clip + AdamW.  With >1 rank the optimizer is
+    a second graph behind an eager RCCL all-reduce of the flat gradient buffer; assignment problems beyond the device solver's
+    128 x 128 bound split the graph around the host tuber_lsap.
 
-        graph A : bf16 weight refresh, forward of the whole model, matching-cost kernel
-        host    : ONE device->host copy of the [L,B,Q,Tmax] cost tensor, tuber_lsap, assignment back to a static buffer
-        graph B : fused criterion (losses + output gradients), backward of the whole model, global-norm clip + AdamW
-                  (with >1 rank: B is split around an eager RCCL all-reduce of the flat gradient buffer)
-
-    ~4000 kernel launches per step are issued by the GPU front-end instead of Python, so the step is GPU-bound.
+    ~2000 kernel launches per step are issued by the GPU front-end instead of Python, so the step is GPU-bound.
     Inputs are copied into static device buffers; targets use the padded [B, Tmax] layout, so clips with a different number
     of boxes replay the same graphs (shape changes of the clip batch re-capture).  Dropout masks differ every replay (the seed
     lives in device memory), AdamW reads its step count from device memory.
@@ -93,8 +92,15 @@ class GraphedTrainStep:
             train_step(model, crit, opt, NestedTensor(g.clips, g.mask), targets, self.max_norm)
         torch.cuda.synchronize()
         store.reducer = None
+        # With the assignment on the device (tuber_lsap_device) the whole step is ONE graph: refresh, forward, matching cost,
+        # assignment, fused criterion, backward, clip + AdamW -- no device->host round trip.  (DDP: the optimizer is a second
+        # graph behind the eager RCCL all-reduce.  Problems beyond the device solver's 128 x 128 bound use graph A / host / B.)
+        Q = model.query_embed.num_embeddings
+        g.on_device = Q <= 128 and g.pt.tmax <= 128
         g.A = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g.A):
+        g.B1 = None
+
+        def head():
             outputs = model(NestedTensor(g.clips, g.mask))
             logits, logits_b, boxes = crit.stacked(outputs)
             g.logits_s, g.boxes_s = crit.select(logits, boxes, targets)
@@ -103,12 +109,8 @@ class GraphedTrainStep:
                 g.cost = crit.matcher.cost(g.logits_s.detach().contiguous(),
                                            (logits_b if crit.ava else g.logits_s).detach().contiguous(),
                                            g.boxes_s.detach().contiguous(), g.pt)
-        L, B = g.cost.shape[:2]
-        g.match = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32, device=dev)
-        g.match_host = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32).pin_memory()
-        g.cost_host = torch.empty(g.cost.shape, dtype=torch.float32).pin_memory()
-        g.B1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g.B1, pool=g.A.pool()):
+
+        def tail():
             g.loss_dict = crit.losses_from_match(g.logits_s, g.logits_b, g.boxes_s, g.pt, g.match, targets)
             g.loss_dict["class_error"] = crit.class_error(g.logits_s[-1], g.pt, g.match[-1])
             g.loss = crit.weighted_total(g.loss_dict)
@@ -117,6 +119,22 @@ class GraphedTrainStep:
             store.side_join()
             if world == 1:
                 opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
+
+        if g.on_device:
+            with torch.cuda.graph(g.A):
+                head()
+                g.match = crit.assign(g.cost, g.pt)
+                tail()
+        else:
+            with torch.cuda.graph(g.A):
+                head()
+            L, B = g.cost.shape[:2]
+            g.match = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32, device=dev)
+            g.match_host = torch.full((L, B, g.pt.tmax), -1, dtype=torch.int32).pin_memory()
+            g.cost_host = torch.empty(g.cost.shape, dtype=torch.float32).pin_memory()
+            g.B1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.B1, pool=g.A.pool()):
+                tail()
         g.B2 = None
         if world > 1:
             g.B2 = torch.cuda.CUDAGraph()
@@ -139,14 +157,17 @@ class GraphedTrainStep:
             g.pt.tcount.copy_(torch.tensor(sizes, dtype=torch.int32), non_blocking=True)
             g.pt.fill(targets)
         g.A.replay()
-        g.cost_host.copy_(g.cost, non_blocking=True)
-        torch.cuda.current_stream().synchronize()                 # the step's one host sync: the assignment needs the costs
-        match, indices = self.criterion.matcher.solve(g.cost_host.numpy(), sizes)
-        g.match_host.copy_(torch.from_numpy(match))
-        g.match.copy_(g.match_host, non_blocking=True)
-        L = len(indices)
-        self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
-        g.B1.replay()
+        if g.on_device:
+            self.criterion._indices, self.criterion._match_dev = None, (g.match, sizes)
+        else:
+            g.cost_host.copy_(g.cost, non_blocking=True)
+            torch.cuda.current_stream().synchronize()             # host assignment: the step's one host sync
+            match, indices = self.criterion.matcher.solve(g.cost_host.numpy(), sizes)
+            g.match_host.copy_(torch.from_numpy(match))
+            g.match.copy_(g.match_host, non_blocking=True)
+            L = len(indices)
+            self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
+            g.B1.replay()
         if g.B2 is not None:
             import torch.distributed as dist
             dist.all_reduce(store.gflat, op=dist.ReduceOp.SUM)
