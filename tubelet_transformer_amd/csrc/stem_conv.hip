@@ -120,23 +120,84 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     }
 }
 
-// dW'[k'][n] partials: one [512][64] fp32 slab per workgroup
+// ---- weight gradient ----
+// D[k'][n] += sum_m patch^T[k'][m] G[m][n].  The MFMA A fragment needs 8 consecutive m of one k' = (run, kw), i.e. the pixels
+// P[run][2m + kw]: stride 2.  The patch is therefore staged DE-INTERLEAVED (PE = even, PO = odd pixel columns), which makes
+// the fragment 8 consecutive bf16 of PE/PO[run] starting at m + kw/2; and the 16 rows of an MFMA are 16 RUNS with one common
+// kw, so the sub-dword start offset is wave-uniform: one 16-byte + one 8-byte LDS read and (for odd offsets) 4 v_alignbit.
+#define EOW 72
+#define NQUAD 9          // (run, 4 consecutive pixels): 64 runs x 34 quads = 2176 = 8.5 per thread
+__device__ __forceinline__ void stem_load_patch4(const float* __restrict__ clip, const StemGeom& g, int tile, float4 (&v)[NQUAD]) {
+    const int wt = tile % g.tilesW; int r_ = tile / g.tilesW;
+    const int ho = r_ % g.Ho; r_ /= g.Ho;
+    const int t = r_ % g.T; const int b = r_ / g.T;
+    const int wbase = 2 * wt * SW - 3;
+#pragma unroll
+    for (int i = 0; i < NQUAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx / 34, q = idx % 34;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 63) {
+            const int c = r / 21, kt = (r / 7) % 3, kh = r % 7;
+            const int ti = t + kt - 1, hi = 2 * ho + kh - 3;
+            if (ti >= 0 && ti < g.T && hi >= 0 && hi < g.H) {
+                const float* row = clip + ((((long)b * 3 + c) * g.T + ti) * g.H + hi) * (long)g.W;
+                const int w0 = wbase + 4 * q;
+                if (w0 >= 0 && w0 < g.W) o.x = row[w0];
+                if (w0 + 1 >= 0 && w0 + 1 < g.W) o.y = row[w0 + 1];
+                if (w0 + 2 >= 0 && w0 + 2 < g.W) o.z = row[w0 + 2];
+                if (w0 + 3 >= 0 && w0 + 3 < g.W) o.w = row[w0 + 3];
+            }
+        }
+        v[i] = o;
+    }
+}
+__device__ __forceinline__ void stem_store_patch_eo(bf16 (*PE)[EOW], bf16 (*PO)[EOW], const float4 (&v)[NQUAD]) {
+#pragma unroll
+    for (int i = 0; i < NQUAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx / 34, q = idx % 34;
+        if (r < 64) {
+            *(bf16x2*)&PE[r][2 * q] = bf16x2{f2bf(v[i].x), f2bf(v[i].z)};     // pixels 4q, 4q+2   -> even columns 2q, 2q+1
+            *(bf16x2*)&PO[r][2 * q] = bf16x2{f2bf(v[i].y), f2bf(v[i].w)};     // pixels 4q+1, 4q+3 -> odd columns
+        }
+    }
+}
+// 8 consecutive bf16 of row[] starting at element m0 + s (m0 % 8 == 0, s = 0..3 wave-uniform)
+__device__ __forceinline__ bf16x8 stem_frag_shift(const bf16* row, int m0, int s) {
+    const uint4 a = *(const uint4*)(row + m0);
+    const uint2 b = *(const uint2*)(row + m0 + 8);
+    uint32_t w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+    uint4 o;
+    if (s & 2) { w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; }
+    if (s & 1) {
+        o.x = __builtin_amdgcn_alignbit(w[1], w[0], 16); o.y = __builtin_amdgcn_alignbit(w[2], w[1], 16);
+        o.z = __builtin_amdgcn_alignbit(w[3], w[2], 16); o.w = __builtin_amdgcn_alignbit(w[4], w[3], 16);
+    } else {
+        o = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return as_bf16x8(o);
+}
+
+// dW'[k'][n] partials: one [512][64] fp32 slab per workgroup.  MFMA tile id = wave*7 + kt (28 tiles: kw = id >> 2 in 0..6,
+// run block rb = id & 3); tile row i <-> run = rb*16 + i.
 __global__ __launch_bounds__(256) void stem_conv_bwd_w_kernel(const float* __restrict__ clip, const bf16* __restrict__ G,
                                                               float* __restrict__ partial, StemGeom g) {
-    __shared__ __attribute__((aligned(16))) bf16 P[64][PXW];
+    __shared__ __attribute__((aligned(16))) bf16 PE[64][EOW];
+    __shared__ __attribute__((aligned(16))) bf16 PO[64][EOW];
     __shared__ __attribute__((aligned(16))) bf16 GT[64][72];            // [n][m], m contiguous, 144-byte rows (16 B aligned)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, gq = lane >> 4;
-    f32x4 acc[8][4];
+    f32x4 acc[7][4];
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 7; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // G tile staging: 64 m x 64 n in 4x4 blocks, one block per thread: mi = 0..15 (x4 rows), ci = 0..15 (x4 cols)
     const int ci = (lane & 3) | ((lane >> 4) << 2), mi = ((lane >> 2) & 3) + 4 * wave;
-    float2 pre[NPAIR];
+    float4 pre[NQUAD];
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        stem_load_patch(clip, g, tile, pre);
+        stem_load_patch4(clip, g, tile, pre);
         const int wt = tile % g.tilesW;
         const long row0 = (long)(tile / g.tilesW) * g.Wo + wt * SW;
         uint2 gr[4];
@@ -145,8 +206,8 @@ __global__ __launch_bounds__(256) void stem_conv_bwd_w_kernel(const float* __res
             const int w = wt * SW + mi * 4 + j;
             gr[j] = w < g.Wo ? *(const uint2*)(G + (row0 + mi * 4 + j) * 64 + ci * 4) : make_uint2(0, 0);
         }
-        __syncthreads();                                     // previous tile's MFMAs are done with P / GT
-        stem_store_patch(P, pre);
+        __syncthreads();                                     // previous tile's MFMAs are done with PE / PO / GT
+        stem_store_patch_eo(PE, PO, pre);
         {
             bf16x4 x[4];
 #pragma unroll
@@ -164,27 +225,26 @@ __global__ __launch_bounds__(256) void stem_conv_bwd_w_kernel(const float* __res
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) gb[nt] = as_bf16x8(*(const uint4*)&GT[nt * 16 + li][ms * 32 + gq * 8]);
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                // A operand: row i = k' = (wave*8 + kt)*16 + li -> run = k' >> 3, kw = k' & 7 ; 8 rows m = ms*32 + gq*8 + e
-                const int kp = (wave * 8 + kt) * 16 + li;
-                const bf16* src = &P[kp >> 3][2 * (ms * 32 + gq * 8) + (kp & 7)];
-                bf16x8 pa;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pa[e] = src[2 * e];
+            for (int kt = 0; kt < 7; ++kt) {
+                const int id = wave * 7 + kt, kw = id >> 2, rb = id & 3;
+                const bf16* row = (kw & 1) ? &PO[rb * 16 + li][0] : &PE[rb * 16 + li][0];
+                const bf16x8 pa = stem_frag_shift(row, ms * 32 + gq * 8, kw >> 1);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, gb[nt], acc[kt][nt], 0, 0, 0);
             }
         }
     }
-    // D[i = k'][j = n]: lane holds n = nt*16 + li, k' = (wave*8+kt)*16 + gq*4 + r
+    // D[i = run][j = n]: lane holds n = nt*16 + li, run = rb*16 + gq*4 + r; slab layout [k' = run*8 + kw][n] (kw = 7 rows zero)
     float* o = partial + (long)blockIdx.x * KP * 64;
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
+    for (int kt = 0; kt < 7; ++kt) {
+        const int id = wave * 7 + kt, kw = id >> 2, rb = id & 3;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                o[(long)((wave * 8 + kt) * 16 + gq * 4 + r) * 64 + nt * 16 + li] = acc[kt][nt][r];
+                o[(long)((rb * 16 + gq * 4 + r) * 8 + kw) * 64 + nt * 16 + li] = acc[kt][nt][r];
+    }
 }
 
 // W[64][441] fp32 -> Wp[64][512] bf16 with k' = run*8 + kw (zero padding)
