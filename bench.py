@@ -202,11 +202,13 @@ def main():
                              % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("TUBER_SHARE_GPU"):         # logic test of the N > 1 path on a one-GPU box (ranks share cuda:0; use gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("TUBER_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     cfg = load_cfg(os.path.join(ROOT, "configuration", args.config))
     cfg.DDP_CONFIG.GPU = local
@@ -301,8 +303,19 @@ def main():
     if rank == 0 and timer is not None:
         s = timer.summary()[dominant]
         ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9
+        traffic = None      # measured HBM bytes per launch of this kernel family from the committed PMC passes (profiles/)
+        try:
+            import glob
+            import json as _json
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+            if pm:
+                kk = _json.load(open(pm[-1]))["kernels"]
+                fam = dominant.replace(" ", "")
+                traffic = (kk.get(fam) or kk.get(fam.split("<")[0]) or {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         line["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
                             "alg_bytes_per_launch": int(s["bytes"] / s["launches"]),
                             "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),

@@ -55,7 +55,7 @@ def bench_nt(cfgs):
             def fn():
                 lib.call("tuber_gemm_nt", A, K, B, K, C, N, M, N, K, amode, sc if amode else None, sh if amode else None,
                          0, 0, 0, 0, 0, 0, 0, 0, 0, epi, None, None, 0, 0, 0, st0 if epi else None, st1 if epi else None,
-                         Cm if epi == 2 else None, N, sc if epi == 2 else None, sh if epi == 2 else None, 1.0, 0.0, None, 0)
+                         Cm if epi == 2 else None, N, sc if epi == 2 else None, sh if epi == 2 else None, 1.0, 0.0, None, 0, None, 0, None)
             row += "  %7.1f" % time_it(fn)
         by = 2 * (M * K + N * K + M * N) + (2 * M * N if epi == 2 else 0)
         print(row + "   | alg %.1f MB, %.2f GF" % (by / 1e6, 2 * M * N * K / 1e9), flush=True)
@@ -77,7 +77,7 @@ def bench_tn():
         out = torch.zeros(N, K, device=dev)
 
         def fn():
-            lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
         print("%-28s %8.1f %6d   | %.1f MB %.2f GF" % ("%d %d %d" % (M, N, K), time_it(fn), S, (2 * M * (N + K) + 4 * N * K) / 1e6, 2 * M * N * K / 1e9), flush=True)
 
 

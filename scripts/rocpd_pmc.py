@@ -35,3 +35,17 @@ for tb, k, n, fk, wk, dur in rows[:45]:
     tot += tb
     print("%-100s %7d %14.0f %14.0f %14.1f %12.2f %9.1f" % (k[:98], n, fk, wk, tb / 1e6, tb / 1e6 / n, tb / max(dur, 1)))
 print("# total traffic of listed kernels: %.2f GB" % (tot / 1e9))
+if len(sys.argv) > 3:                 # machine-readable per-launch traffic (bench.py fills roofline.traffic from it)
+    import json
+
+    def family(k):
+        k = re.sub(r"^void ", "", k)
+        k = re.sub(r"\(anonymous namespace\)::", "", k)
+        k = k.split("(")[0].replace(" ", "")
+        m = re.match(r"_Z\d+([a-z_0-9]+?_kernel)", k)
+        return m.group(1) if m else k
+    out = {}
+    for tb, k, n, fk, wk, dur in rows:
+        out[family(k)] = {"launches": n, "hbm_bytes_per_launch": round(tb / n), "avg_us": round(dur / n / 1e3, 2)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "kernels": out},
+              open(sys.argv[3], "w"), indent=1)

@@ -5,7 +5,6 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
@@ -16,7 +15,9 @@ namecol = "display_name" if "display_name" in scol else ("kernel_name" if "kerne
 q = "select s.%s, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s order by 3 desc" % (namecol, kd, ks, namecol)
 rows = list(cur.execute(q))
 tot = sum(r[2] for r in rows)
-print("# rocprofv3 --kernel-trace summary of %s (durations in us; per-step = total / %g steps incl. warm-up)" % (sys.argv[1], steps))
+# one stem-conv forward launch per training step (graph replays, eager warm-up, capture, per-kernel timing passes alike)
+steps = float(sum(r[1] for r in rows if "stem_conv_fwd" in r[0]) or (float(sys.argv[2]) if len(sys.argv) > 2 else 1.0))
+print("# rocprofv3 --kernel-trace summary of %s (durations in us; per-step = total / %g training steps of any kind: replays, eager warm-up, capture, timing passes)" % (sys.argv[1], steps))
 print("%-110s %8s %12s %10s %10s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
 for name, n, t, mn, mx in rows:
     name = re.sub(r"\s+", " ", name)

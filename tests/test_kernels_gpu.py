@@ -41,7 +41,7 @@ def gemm_nt(A, B, M, N, K, amode=0, sc=None, sh=None, gather=None, epi=0, bias=N
     st1 = torch.zeros(rows, N, device=dev) if epi else None
     g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
     lib.call("tuber_gemm_nt", A, lda or K, B, K, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, epi, bias, R, N, relu,
-             out_f32, st0, st1, Cm, N, msc, msh, 1.0, 0.0, None, 0)
+             out_f32, st0, st1, Cm, N, msc, msh, 1.0, 0.0, None, 0, None, 0, None)
     return C, st0, st1
 
 
@@ -119,10 +119,10 @@ def test_gemm_tn(dev, M, N, K, amode):
     part = torch.empty(S, N, K, device=dev)
     out = torch.zeros(N, K, device=dev)
     lib.call("tuber_gemm_tn", G, N, A, K, part, out, 0, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0)
+             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
     close("gemm_tn %dx%dx%d amode %d" % (M, N, K, amode), out, ref, rel=2e-3)
     lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0)
+             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
     close("gemm_tn accumulate", out, 2 * ref, rel=2e-3)
 
 
@@ -137,7 +137,7 @@ def test_gemm_tn_gather(dev):
     S = lib.query("tuber_gemm_tn_slabs", M, N, K)
     part = torch.empty(S, N, K, device=dev)
     out = torch.zeros(N, K, device=dev)
-    lib.call("tuber_gemm_tn", G, N, X, K, part, out, 0, M, N, K, 0, None, None, 1, To, Ho, Wo, Ti, Hi, Wi, st, ss)
+    lib.call("tuber_gemm_tn", G, N, X, K, part, out, 0, M, N, K, 0, None, None, 1, To, Ho, Wo, Ti, Hi, Wi, st, ss, None, 0, None, None, None)
     close("gemm_tn gather", out, G.float().t() @ Xs.float(), rel=2e-3)
 
 
@@ -374,7 +374,7 @@ def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
     bias = 0.1 * rnd(N, dev=dev, seed=3)
     h = torch.empty(M, N, device=dev, dtype=BF)
     lib.call("tuber_gemm_nt", x, K, w, K, h, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-             0, bias, None, 0, 1, 0, None, None, None, 0, None, None, 1.0, p, seed, salt)
+             0, bias, None, 0, 1, 0, None, None, None, 0, None, None, 1.0, p, seed, salt, None, 0, None)
     ones = torch.ones(M, N, device=dev, dtype=BF)
     keep = torch.empty_like(ones)
     lib.call("tuber_dropout", ones, keep, M * N, p, seed, salt)
@@ -387,12 +387,58 @@ def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
     dpre = torch.empty(M, N, device=dev, dtype=BF)
     alpha = 1.0 / (1.0 - p)
     lib.call("tuber_gemm_nt", g, K2, w2t, K2, dpre, N, M, N, K2, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-             2, None, None, 0, 0, 0, None, None, h, N, None, None, alpha, 0.0, None, 0)
+             2, None, None, 0, 0, 0, None, None, h, N, None, None, alpha, 0.0, None, 0, None, 0, None)
     refd = alpha * (g.float() @ w2t.float().t()) * (h.float() > 0)
     close("gemm masked dgrad epilogue", dpre, refd)
     gm = torch.empty_like(dpre)
     lib.call("tuber_relu_mask", g.new_ones(M, N), h, gm, M * N, alpha)
     close("relu_mask alpha", gm, alpha * (h.float() > 0))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(5632, 256, 1024, 2), (700, 512, 128, 0), (130, 64, 256, 2)])
+def test_gemm_nt_bn_backward_prologue(dev, M, N, K, epi):
+    """amode 2: the A operand is the BatchNorm backward apply cA[k]*dz + cB[k]*x + cC[k], formed while loading (the data-gradient
+    GEMMs of conv4 / conv1 / down_sample consume it without dx ever being written)."""
+    dz = rnd(M, K, dev=dev, seed=1).to(BF)
+    x = rnd(M, K, dev=dev, seed=2).to(BF)
+    cA, cB, cC = 1 + 0.2 * rnd(K, dev=dev, seed=3), 0.1 * rnd(K, dev=dev, seed=4), 0.05 * rnd(K, dev=dev, seed=5)
+    w = (rnd(N, K, dev=dev, seed=6) / K ** 0.5).to(BF)
+    res = rnd(M, N, dev=dev, seed=7).to(BF)
+    cm = rnd(M, N, dev=dev, seed=8).to(BF)
+    out = torch.empty(M, N, device=dev, dtype=BF)
+    a_ref = bfr(dz.float() * cA + x.float() * cB + cC)
+    ref = a_ref @ w.float().t()
+    R = lib.query("tuber_gemm_nt_stat_rows", M, N)
+    st0, st1 = torch.zeros(R, N, device=dev), torch.zeros(R, N, device=dev)
+    if epi == 0:
+        lib.call("tuber_gemm_nt", dz, K, w, K, out, N, M, N, K, 2, cA, cB, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 0, None, res, N, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, x, K, cC)
+        close("gemm_nt amode2 (+residual)", out, ref + res.float())
+    else:
+        lib.call("tuber_gemm_nt", dz, K, w, K, out, N, M, N, K, 2, cA, cB, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 2, None, None, 0, 0, 0, st0, st1, cm, N, None, None, 1.0, 0.0, None, 0, x, K, cC)
+        refm = ref * (cm.float() > 0)
+        close("gemm_nt amode2 epi2", out, refm)
+        close("gemm_nt amode2 epi2 sum dz", st0.sum(0), refm.sum(0), abs_=2e-3 * float(refm.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("M,N,K,amode", [(5632, 1024, 256, 1), (700, 64, 192, 0), (44032, 128, 64, 0)])
+def test_gemm_tn_bn_backward_prologue(dev, M, N, K, amode):
+    """G operand = cA[n]*dz + cB[n]*x + cC[n] formed on load (weight gradients of conv4 / conv1 / down_sample)."""
+    dz = rnd(M, N, dev=dev, seed=1).to(BF)
+    x = rnd(M, N, dev=dev, seed=2).to(BF)
+    cA, cB, cC = 1 + 0.2 * rnd(N, dev=dev, seed=3), 0.1 * rnd(N, dev=dev, seed=4), 0.05 * rnd(N, dev=dev, seed=5)
+    A = rnd(M, K, dev=dev, seed=6).to(BF)
+    sc, sh = 1 + 0.1 * rnd(K, dev=dev, seed=7), 0.1 * rnd(K, dev=dev, seed=8)
+    g_ref = bfr(dz.float() * cA + x.float() * cB + cC)
+    a_ref = bfr((A.float() * sc + sh).relu()) if amode else A.float()
+    ref = g_ref.t() @ a_ref
+    S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+    part = torch.empty(S * N * K, device=dev)
+    out = torch.ones(N, K, device=dev)
+    lib.call("tuber_gemm_tn", dz, N, A, K, part, out, 1, M, N, K, amode, sc if amode else None, sh if amode else None,
+             0, 0, 0, 0, 0, 0, 0, 0, 0, x, N, cA, cB, cC)
+    close("gemm_tn G prologue", out - 1, ref, rel=4e-3)
 
 
 @pytest.mark.parametrize("M,C,ld", [(704, 256, 256), (30, 2048, 2048), (180, 3, 64), (24, 3840, 3840), (16896, 512, 512), (5000, 80, 128)])

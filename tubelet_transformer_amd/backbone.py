@@ -204,11 +204,11 @@ class CSNRunner:
             R = lib.query("tuber_gemm_nt_stat_rows", M, N)
             st0, st1 = self.ws("st0", R * N), self.ws("st1", R * N)
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 1, None, None, 0, 0, 0,
-                     st0, st1, None, 0, None, None, 1.0, 0.0, None, 0)
+                     st0, st1, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
             self._bn_train(bn, st0, st1, R, M)
         else:
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 0, None, None, 0, 0, 0,
-                     None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+                     None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
             self._bn_eval(bn)
 
     # -- forward ------------------------------------------------------------------------------------
@@ -279,7 +279,10 @@ class CSNRunner:
 
     # -- backward -------------------------------------------------------------------------------------
     def _bn_bwd(self, bn, st0, st1, R, count, dz, x, M):
-        """finalize coefficients (+ dgamma/dbeta into the flat grads) and apply: returns dx tensor [M, C]."""
+        """finalize coefficients (+ dgamma/dbeta into the flat grads) and apply: returns dx tensor [M, C].
+        (Forming dx inside the consuming GEMMs instead -- tuber_gemm_nt amode 2 / tuber_gemm_tn G2 -- removes this kernel and
+        7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
+        not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
         st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
         lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
                  bn.dgamma, bn.dbeta, 1)
@@ -291,7 +294,7 @@ class CSNRunner:
         S = lib.query("tuber_gemm_tn_slabs", M, N, K)
         part = self.ws("tn", S * N * K)
         g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
-        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g)
+        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None)
 
     def backward(self, saved, dfeat):
         """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients are
@@ -323,7 +326,7 @@ class CSNRunner:
             s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
             dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
             lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0)
+                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
             dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
@@ -359,11 +362,11 @@ class CSNRunner:
                     self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
                 dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
                 lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
-                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
                 if not strided:
                     res = dxd
             lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+                     0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
             if d["ds"] and strided:
                 lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
             dy = dx

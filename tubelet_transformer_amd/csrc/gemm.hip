@@ -23,7 +23,7 @@
 
 #include "common.h"
 
-enum { A_PLAIN = 0, A_BN_RELU = 1 };
+enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2 };     // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply)
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2 };
 
 struct GemmNT {
@@ -31,7 +31,8 @@ struct GemmNT {
     const bf16* B; long ldb;
     void* C; long ldc;
     int M, N, K;
-    const float* a_scale; const float* a_shift;   // A_BN_RELU
+    const float* a_scale; const float* a_shift;   // A_BN_RELU (scale, shift) / A_BN_BWD (cA, cB)
+    const bf16* A2; long lda2; const float* a_coef2;   // A_BN_BWD: second operand (the BN input x) and cC
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss; // row gather (strided 1x1x1 conv)
     const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
@@ -45,7 +46,7 @@ template <int NT>
 __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
 
 template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI>
-__global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gemm_nt_kernel(GemmNT p) {
+__global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4 : 1) void gemm_nt_kernel(GemmNT p) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
     constexpr int STAGE = (BM + BN) * 128;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
     // ---- staging assignment: chunk c = tid + 256*i -> (row = c>>3, q = c&7) ----
     const int q = tid & 7;
     const bf16* a_ptr[CA];
+    const bf16* a2_ptr[AMODE == A_BN_BWD ? CA : 1];
     bool a_ok[CA];
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
             src = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)h * p.ss) * p.Wi + (long)w * p.ss;
         }
         a_ptr[i] = p.A + src * p.lda + q * 8;
+        if (AMODE == A_BN_BWD) a2_ptr[i] = p.A2 + (long)m * p.lda2 + q * 8;
     }
     const bf16* b_ptr[CB];
     bool b_ok[CB];
@@ -91,20 +94,31 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
     // group instead of one per tile -- these GEMMs have K <= 2048, often only 1-4 tiles), then each tile goes
     // registers -> (BN prologue) -> LDS -> MFMA.
     uint4 ra[G][CA], rb[G][CB];
-    float* lsc = (float*)(smem + 2 * STAGE);       // A_BN_RELU: scale[K] | shift[K] staged once
+    uint4 ra2[AMODE == A_BN_BWD ? G : 1][CA];
+    float* lsc = (float*)(smem + 2 * STAGE);       // A_BN_RELU: scale[K] | shift[K] staged once;  A_BN_BWD: cA | cB | cC
     float* lsh = lsc + p.K;
-    auto load_tile = [&](int kt, uint4 (&xa)[CA], uint4 (&xb)[CB]) {
+    float* lsc2 = lsh + p.K;
+    auto load_tile = [&](int kt, uint4 (&xa)[CA], uint4 (&xb)[CB], uint4 (&xa2)[CA]) {
         const int k0 = kt * 64;
 #pragma unroll
         for (int i = 0; i < CA; ++i) xa[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        if (AMODE == A_BN_BWD) {
+#pragma unroll
+            for (int i = 0; i < CA; ++i) xa2[i] = a_ok[i] ? *(const uint4*)(a2_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < CB; ++i) xb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
     };
-    auto store_tile = [&](int kt, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB]) {
+    auto store_tile = [&](int kt, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB], const uint4 (&xa2)[CA]) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + BM * 128;
-        float sc[8], sh[8];
-        if (AMODE == A_BN_RELU) {
+        float sc[8], sh[8], s2[8];
+        if (AMODE == A_BN_BWD) {
+            const float4* c4 = (const float4*)(lsc2 + kt * 64 + q * 8);
+            const float4 c0 = c4[0], c1 = c4[1];
+            s2[0] = c0.x; s2[1] = c0.y; s2[2] = c0.z; s2[3] = c0.w; s2[4] = c1.x; s2[5] = c1.y; s2[6] = c1.z; s2[7] = c1.w;
+        }
+        if (AMODE != A_PLAIN) {
             const float4* s4 = (const float4*)(lsc + kt * 64 + q * 8);
             const float4* h4 = (const float4*)(lsh + kt * 64 + q * 8);
             const float4 s0 = s4[0], s1 = s4[1], h0 = h4[0], h1 = h4[1];
@@ -119,6 +133,13 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
                 bf16x8 x = as_bf16x8(v), y;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sc[e], sh[e]), 0.f));
+                v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
+            }
+            if (AMODE == A_BN_BWD) {
+                const bf16x8 x = as_bf16x8(v), x2 = as_bf16x8(xa2[i]);
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaf(bf2f(x[e]), sc[e], fmaf(bf2f(x2[e]), sh[e], s2[e])));
                 v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
             }
             *(uint4*)(sa + row * 128 + ((q ^ swz_act(row)) << 4)) = v;
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
     const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
 #pragma unroll
     for (int j = 0; j < G; ++j)
-        if (j < nk) load_tile(j, ra[j], rb[j]);
+        if (j < nk) load_tile(j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
     uint4 side[EPI == EPI_BWD ? MT : 1][NC / 8];         // EPI_BWD: the mask source c, fetched behind the k-loop
     const bool side_vec = EPI == EPI_BWD && vec_ok && ((p.ldcm & 7) == 0);
     if (EPI == EPI_BWD && side_vec) {
@@ -181,8 +202,11 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
                 side[EPI == EPI_BWD ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
         }
     }
-    if (AMODE == A_BN_RELU) {
-        for (int i = tid; i < p.K; i += 256) { lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i]; }
+    if (AMODE != A_PLAIN) {
+        for (int i = tid; i < p.K; i += 256) {
+            lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i];
+            if (AMODE == A_BN_BWD) lsc2[i] = p.a_coef2[i];
+        }
         __syncthreads();
     }
     // software pipeline over k-tiles: register set j holds tile g0+j; as soon as it has been written to LDS the same
@@ -192,8 +216,8 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (g0 + j < nk) {
-                store_tile(g0 + j, buf, ra[j], rb[j]);
-                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j]);
+                store_tile(g0 + j, buf, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
+                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
                 __syncthreads();
                 compute(buf);
                 buf ^= 1;
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4) ? 4 : 1) void gem
 template <int BM, int BN, int WM, int WN, int G>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : 0);
+    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
     dim3 grid(tiles), block(256);
 #define LNT(AM, EP)                                                                                                   \
     do {                                                                                                              \
@@ -338,9 +362,14 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
         else LNT(A_PLAIN, EPI_BWD);
     } else {
-        if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
-        else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
-        else LNT(A_BN_RELU, EPI_BWD);
+        if (amode == A_BN_RELU) {
+            if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
+            else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
+            else LNT(A_BN_RELU, EPI_BWD);
+        } else {                                          // data-gradient GEMMs only: plain (+residual) or masked epilogue
+            if (epi == EPI_PLAIN) LNT(A_BN_BWD, EPI_PLAIN);
+            else LNT(A_BN_BWD, EPI_BWD);
+        }
     }
 #undef LNT
     TUBER_RETURN_LAUNCH();
@@ -388,14 +417,18 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
                   float* stat0, float* stat1,
                   const void* Cm, long ldcm, const float* m_scale, const float* m_shift,
                   float alpha, float drop_p, const void* seed_ptr, unsigned long long salt,
+                  const void* A2, long lda2, const float* a_coef2,
                   hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7)) return TUBER_EINVAL;
-    if (amode == A_BN_RELU && (!a_scale || !a_shift)) return TUBER_EINVAL;
+    if (amode != A_PLAIN && (!a_scale || !a_shift)) return TUBER_EINVAL;
+    if (amode == A_BN_BWD && (!A2 || !a_coef2 || (lda2 & 7) || gather || epi == EPI_STATS)) return TUBER_EINVAL;
+    if (amode < 0 || amode > 2) return TUBER_EINVAL;
     if (epi == EPI_BWD && !Cm) return TUBER_EINVAL;
     if (epi != EPI_PLAIN && out_f32) return TUBER_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && epi != EPI_PLAIN)) return TUBER_EINVAL;
     GemmNT p;
     p.alpha = alpha;
+    p.A2 = (const bf16*)A2; p.lda2 = lda2; p.a_coef2 = a_coef2;
     p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_inv_keep = 1.f / (1.f - drop_p);
     p.seed_ptr = (const uint64_t*)seed_ptr; p.salt = (uint64_t)salt;
     p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
@@ -431,6 +464,7 @@ struct GemmTN {
     float* P;                    // partials [S][N][K]
     int M, N, K, S, rows_per_slab, accumulate;
     const float* a_scale; const float* a_shift;   // A_BN_RELU on A (per k column)
+    const bf16* G2; long ldg2; const float* gA; const float* gB; const float* gC;   // GMODE 1: G := gA[n]*G + gB[n]*G2 + gC[n]
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
 };
 
@@ -463,7 +497,7 @@ __device__ __forceinline__ void tn_stage_store(char* dst, const uint2 (&r)[4], i
 }
 
 // T = output tile edge (128: 2x2 waves of 64x64; 64: 2x2 waves of 32x32 -- 4x more workgroups for small N*K)
-template <int AMODE, int T>
+template <int AMODE, int T, int GMODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     constexpr int BN = T, BKo = T, TM = T / 2, TN = T / 2, MT = TM / 16, NT = TN / 16;
     constexpr int NB = T / 64;                 // 4x4 blocks per thread per operand per 64-row step
@@ -506,12 +540,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
         g_col_ok[i] = n0 + ci[i] * 4 < p.N;
         a_col_ok[i] = k0 + ci[i] * 4 < p.K;
     }
+    float gca[GMODE ? NB : 1][4], gcb[GMODE ? NB : 1][4], gcc[GMODE ? NB : 1][4];      // BatchNorm-backward apply on the G operand
+    if (GMODE) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = n0 + ci[i] * 4 + c;
+                gca[i][c] = n < p.N ? p.gA[n] : 0.f; gcb[i][c] = n < p.N ? p.gB[n] : 0.f; gcc[i][c] = n < p.N ? p.gC[n] : 0.f;
+            }
+    }
 
     // 64-row steps are fetched in groups of GS so their global loads overlap (one HBM latency per group)
     constexpr int GS = 4;
     uint2 rgs[GS][NB][4], ravs[GS][NB][4];
+    uint2 rg2s[GMODE ? GS : 1][NB][4];
     bool roks[GS][NB][4];
-    auto load_step = [&](int ms, uint2 (&rg)[NB][4], uint2 (&rav)[NB][4], bool (&rok)[NB][4]) {
+    auto load_step = [&](int ms, uint2 (&rg)[NB][4], uint2 (&rav)[NB][4], bool (&rok)[NB][4], uint2 (&rg2)[NB][4]) {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -527,10 +572,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
                     arow = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)h * p.ss) * p.Wi + (long)w * p.ss;
                 }
                 rg[i][j] = (ok && g_col_ok[i]) ? *(const uint2*)(p.G + (long)m * p.ldg + n0 + ci[i] * 4) : make_uint2(0, 0);
+                if (GMODE) rg2[i][j] = (ok && g_col_ok[i]) ? *(const uint2*)(p.G2 + (long)m * p.ldg2 + n0 + ci[i] * 4) : make_uint2(0, 0);
                 rav[i][j] = (ok && a_col_ok[i]) ? *(const uint2*)(p.A + arow * p.lda + k0 + ci[i] * 4) : make_uint2(0, 0);
             }
     };
-    auto store_step = [&](int buf, const uint2 (&rg)[NB][4], const uint2 (&rav)[NB][4], const bool (&rok)[NB][4]) {
+    auto store_step = [&](int buf, const uint2 (&rg)[NB][4], const uint2 (&rav)[NB][4], const bool (&rok)[NB][4], const uint2 (&rg2)[NB][4]) {
         char* sg = smem + buf * STAGE;       // G^T tile: [n][m]  (MFMA A operand -> "weight" swizzle)
         char* sa = sg + BN * 128;            // A^T tile: [k][m]  (MFMA B operand -> "act" swizzle)
 #pragma unroll
@@ -539,6 +585,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
             bool any_bad = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { g4[j] = rg[i][j]; a4[j] = rav[i][j]; any_bad |= !rok[i][j]; }
+            if (GMODE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x4 x = as_bf16x4(g4[j]), x2 = as_bf16x4(rg2[i][j]);
+                    bf16x4 y;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        y[c] = rok[i][j] ? f2bf(fmaf(bf2f(x[c]), gca[i][c], fmaf(bf2f(x2[c]), gcb[i][c], gcc[i][c]))) : (bf16)0.f;
+                    g4[j] = as_uint2(y);
+                }
+            }
             const float one[4] = {1.f, 1.f, 1.f, 1.f}, zero[4] = {0.f, 0.f, 0.f, 0.f};
             tn_stage_store<A_PLAIN, NT>(sg, g4, mi[i], ci[i], false, true, one, zero);
             if (AMODE == A_BN_RELU && any_bad) {
@@ -571,15 +628,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);  // n index (G^T rows)
 
+    // rolling software pipeline over the 64-row steps (like gemm_nt): register set j is re-armed with step +GS as soon as
+    // it has been written to LDS, so GS steps of global loads stay in flight behind the MFMA work
     int buf = 0;
-    for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
 #pragma unroll
-        for (int j = 0; j < GS; ++j)
-            if (ms + 64 * j < m_end) load_step(ms + 64 * j, rgs[j], ravs[j], roks[j]);
+    for (int j = 0; j < GS; ++j)
+        if (m_begin + 64 * j < m_end) load_step(m_begin + 64 * j, rgs[j], ravs[j], roks[j], rg2s[GMODE ? j : 0]);
+    for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
             if (ms + 64 * j >= m_end) continue;
-            store_step(buf, rgs[j], ravs[j], roks[j]);
+            store_step(buf, rgs[j], ravs[j], roks[j], rg2s[GMODE ? j : 0]);
+            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rgs[j], ravs[j], roks[j], rg2s[GMODE ? j : 0]);
             __syncthreads();
             const char* sg = smem + buf * STAGE;
             const char* sa = sg + BN * 128;
@@ -671,6 +731,7 @@ int tuber_gemm_tn_slabs(int M, int N, int K) {
 int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* partial, float* out, int accumulate,
                   int M, int N, int K, int amode, const float* a_scale, const float* a_shift,
                   int gather, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
+                  const void* G2, long ldg2, const float* gA, const float* gB, const float* gC,
                   hipStream_t stream) {
     // N / K need not be multiples of 4, but G / A must be readable up to ceil4(N) / ceil4(K) columns (padded ld)
     if (M <= 0 || N <= 0 || K <= 0 || (ldg & 3) || (lda & 3) || ldg < ((N + 3) & ~3) || lda < ((K + 3) & ~3)) return TUBER_EINVAL;
@@ -684,18 +745,23 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     p.accumulate = accumulate;
     p.P = p.S == 1 ? out : partial;            // a single slab writes (or accumulates into) the gradient directly
     p.a_scale = a_scale; p.a_shift = a_shift;
+    const int gmode = G2 ? 1 : 0;
+    if (gmode && (!gA || !gB || !gC || (ldg2 & 3) || ldg2 < ((N + 3) & ~3))) return TUBER_EINVAL;
+    p.G2 = (const bf16*)G2; p.ldg2 = ldg2; p.gA = gA; p.gB = gB; p.gC = gC;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     const int T = tn_tile(N, K);
     const int tiles = ceil_div(N, T) * ceil_div(K, T);
     dim3 grid(tiles * p.S), block(256);
     const size_t lds = 2 * 2 * T * 128;
+#define LTN(AM, TT, GM) hipLaunchKernelGGL((gemm_tn_kernel<AM, TT, GM>), grid, block, lds, stream, p)
     if (T == 128) {
-        if (amode == A_BN_RELU) hipLaunchKernelGGL((gemm_tn_kernel<A_BN_RELU, 128>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, 128>), grid, block, lds, stream, p);
+        if (amode == A_BN_RELU) { if (gmode) LTN(A_BN_RELU, 128, 1); else LTN(A_BN_RELU, 128, 0); }
+        else { if (gmode) LTN(A_PLAIN, 128, 1); else LTN(A_PLAIN, 128, 0); }
     } else {
-        if (amode == A_BN_RELU) hipLaunchKernelGGL((gemm_tn_kernel<A_BN_RELU, 64>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, 64>), grid, block, lds, stream, p);
+        if (amode == A_BN_RELU) { if (gmode) LTN(A_BN_RELU, 64, 1); else LTN(A_BN_RELU, 64, 0); }
+        else { if (gmode) LTN(A_PLAIN, 64, 1); else LTN(A_PLAIN, 64, 0); }
     }
+#undef LTN
     if (p.S > 1) {
         const long n = (long)N * K;
         if (p.S <= 16) hipLaunchKernelGGL(reduce_slabs_flat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);

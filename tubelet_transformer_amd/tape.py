@@ -120,7 +120,7 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
     p = float(drop)
     salt = tp.salt() if p > 0.0 else 0
     lib.call("tuber_gemm_nt", x, K, wb, K, y, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-             0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt)
+             0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt, None, 0, None)
     if not tp.train:
         return y
     inv_keep = 1.0 / (1.0 - p)
@@ -154,7 +154,7 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
         gw = st.gflat.data_ptr() + 4 * (st.offsets[wname] + r0 * K)
         with st.side(gb, x):               # weight / bias gradients feed nothing until the optimizer
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
             if bname:
                 gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0)
                 lib.call("tuber_colsum", gb, workspace(dev, "cs", lib.query("tuber_colsum_blocks", M) * N), gbias, 1, M, N, ldg)
@@ -167,7 +167,7 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
         dx = torch.empty(M, K, dtype=BF, device=dev)
         if id(tx) in tp.stack:
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+                     0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
             tp.put(tx, dx)
             return
         r = tp.g.pop(id(tx), None)
@@ -176,11 +176,11 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             r = None
         if id(tx) in tp.mask and r is None and tx is x:
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     2, None, None, 0, 0, 0, None, None, x, K, None, None, tp.mask[id(tx)], 0.0, None, 0)
+                     2, None, None, 0, 0, 0, None, None, x, K, None, None, tp.mask[id(tx)], 0.0, None, 0, None, 0, None)
             tp.premasked.add(id(tx))
         else:
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, r, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0)
+                     0, None, r, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
         tp.put(tx, dx)
     tp.rec(bwd)
     return y
