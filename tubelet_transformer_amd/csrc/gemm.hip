@@ -681,6 +681,154 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_tn via the gfx950 LDS transpose read (ds_read_b64_tr_b16): the 64-row steps of G and A are parked in LDS ROW-MAJOR with
+// plain 16-byte stores (exactly as they arrive from HBM), and the m-contiguous MFMA fragments are read back transposed by the
+// hardware: for a 16-lane group, lane i supplies the address of chunk i (row i/4, 4 columns (i%4)*4..) of a [4 m][16 cols] block
+// and receives column i of it, i.e. 4 consecutive m for its own output column.  Two such reads make one MFMA operand.
+// The register-transposing kernel above issues 17 VALU instructions per MFMA (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA); this one ~4.
+// Used for 64 x 64 output tiles with 8-element aligned N, K, ld; otherwise (heads with N = 3/4/80, GMODE, 128 tiles) the kernel
+// above runs.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define TNP 72               // LDS row pitch in bf16 (144 B): the 4 rows of a transposed block fall on disjoint bank ranges
+
+__device__ __forceinline__ bf16x8 tn2_frag(const bf16* img, int m0, int col0, int li) {
+    // rows m0 .. m0+7 (two [4][16] blocks), columns col0 .. col0+15; lane li of the group gets 8 consecutive m of column col0+li
+    const bf16* p = img + (m0 + (li >> 2)) * TNP + col0 + (li & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * TNP));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
+    constexpr int T = 64, TM = 32, TN = 32, MT = 2, NT = 2;
+    constexpr int IMG = 64 * TNP;                       // one operand image (elements)
+    __shared__ __attribute__((aligned(16))) bf16 smem[2][2][IMG];     // [buf][G | A][64 m][TNP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + T - 1) / T, tiles_k = (p.K + T - 1) / T;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = b / (tiles_n * tiles_k);
+    b -= slab * tiles_n * tiles_k;
+    const int tile_n = b % tiles_n, tile_k = b / tiles_n;
+    const int n0 = tile_n * T, k0 = tile_k * T;
+    const int m_begin = slab * p.rows_per_slab;
+    const int m_end = min(p.M, m_begin + p.rows_per_slab);
+
+    // staging: thread -> 16-byte chunk c (8 columns) of rows r and r + 32 of the 64-row step
+    const int c = tid & 7, r = tid >> 3;
+    const bool g_col_ok = n0 + c * 8 < p.N, a_col_ok = k0 + c * 8 < p.K;
+    float asc[8], ash[8];
+    if (AMODE == A_BN_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + c * 8 + e;
+            asc[e] = k < p.K ? p.a_scale[k] : 1.f;
+            ash[e] = k < p.K ? p.a_shift[k] : 0.f;
+        }
+    }
+    constexpr int GS = 4;
+    uint4 rg[GS][2], ra[GS][2];
+    bool rok[GS][2];
+    auto load_step = [&](int ms, uint4 (&xg)[2], uint4 (&xa)[2], bool (&ok)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ms + r + 32 * h;
+            ok[h] = m < m_end;
+            long arow = m;
+            if (p.gather && ok[h]) {
+                int w = m % p.Wo; int q = m / p.Wo;
+                int hh = q % p.Ho; q /= p.Ho;
+                int t = q % p.To; int n = q / p.To;
+                arow = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)hh * p.ss) * p.Wi + (long)w * p.ss;
+            }
+            xg[h] = (ok[h] && g_col_ok) ? *(const uint4*)(p.G + (long)m * p.ldg + n0 + c * 8) : make_uint4(0, 0, 0, 0);
+            xa[h] = (ok[h] && a_col_ok) ? *(const uint4*)(p.A + arow * p.lda + k0 + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_step = [&](int buf, const uint4 (&xg)[2], const uint4 (&xa)[2], const bool (&ok)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 av = xa[h];
+            if (AMODE == A_BN_RELU) {
+                const bf16x8 x = as_bf16x8(av);
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), asc[e], ash[e]), 0.f));
+                av = (ok[h] && a_col_ok) ? as_uint4(y) : make_uint4(0, 0, 0, 0);      // rows / columns outside contribute zero
+            }
+            *(uint4*)&smem[buf][0][(r + 32 * h) * TNP + c * 8] = xg[h];
+            *(uint4*)&smem[buf][1][(r + 32 * h) * TNP + c * 8] = av;
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int buf = 0;
+#pragma unroll
+    for (int j = 0; j < GS; ++j)
+        if (m_begin + 64 * j < m_end) load_step(m_begin + 64 * j, rg[j], ra[j], rok[j]);
+    for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            if (ms + 64 * j >= m_end) continue;
+            store_step(buf, rg[j], ra[j], rok[j]);
+            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
+            __syncthreads();
+            const bf16* gi = smem[buf][0];
+            const bf16* ai = smem[buf][1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int m0 = ks * 32 + g * 8;
+                bf16x8 fn[NT], fk[MT];
+#pragma unroll
+                for (int j2 = 0; j2 < NT; ++j2) fn[j2] = tn2_frag(gi, m0, wn * TN + j2 * 16, li);      // rows of D: n
+#pragma unroll
+                for (int i2 = 0; i2 < MT; ++i2) fk[i2] = tn2_frag(ai, m0, wm * TM + i2 * 16, li);      // cols of D: k
+#pragma unroll
+                for (int i2 = 0; i2 < MT; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < NT; ++j2)
+                        acc[i2][j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j2], fk[i2], acc[i2][j2], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+    }
+    // D[row n][col k]: lane holds k = wm*TM + i*16 + li, n = wn*TN + j*16 + g*4 + r.  The tile goes through LDS so that
+    // it leaves as 16-byte stores, 256 contiguous bytes per 16 lanes (direct stores would be 64-byte fragments)
+    float* P = p.P + (long)slab * p.N * p.K;
+    __syncthreads();
+    float* ot = (float*)&smem[0][0][0];                 // [64 n][64 k + 4] fp32 = 17 KB of the 36 KB staging area
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                ot[(wn * TN + j * 16 + g * 4 + rr) * 68 + wm * TM + i * 16 + li] = acc[i][j][rr];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        const int n = n0 + (idx >> 4), k = k0 + (idx & 15) * 4;
+        if (n < p.N && k < p.K) {                       // K % 8 == 0: whole float4 inside
+            float4 v = *(const float4*)&ot[(idx >> 4) * 68 + (idx & 15) * 4];
+            float4* o = (float4*)(P + (long)n * p.K + k);
+            if (p.S == 1 && p.accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+            *o = v;
+        }
+    }
+}
+
 // out[j] (+)= sum_s P[s][j], few slabs: one thread per element
 __global__ void reduce_slabs_flat_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -722,7 +870,10 @@ int tuber_gemm_tn_slabs(int M, int N, int K) {
     long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);
     if (cap < 1) cap = 1;
     if (S > cap) S = cap;
-    const long maxS = ceil_div(M, 256);
+    static int mult = -1;
+    if (mult < 0) { const char* e = getenv("TUBER_TN_SLAB_MULT"); mult = e ? atoi(e) : 1; }     // experiments only
+    S *= mult;
+    const long maxS = ceil_div(M, mult > 1 ? 128 : 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     return (int)S;
@@ -754,7 +905,12 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     dim3 grid(tiles * p.S), block(256);
     const size_t lds = 2 * 2 * T * 128;
 #define LTN(AM, TT, GM) hipLaunchKernelGGL((gemm_tn_kernel<AM, TT, GM>), grid, block, lds, stream, p)
-    if (T == 128) {
+    static int use_tr = -1;
+    if (use_tr < 0) use_tr = getenv("TUBER_TN_REGISTER_TRANSPOSE") ? 0 : 1;      // A/B switch for profiling
+    if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7)) {     // LDS transpose-read kernel
+        if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn2_kernel<A_BN_RELU>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(gemm_tn2_kernel<A_PLAIN>, grid, block, 0, stream, p);
+    } else if (T == 128) {
         if (amode == A_BN_RELU) { if (gmode) LTN(A_BN_RELU, 128, 1); else LTN(A_BN_RELU, 128, 0); }
         else { if (gmode) LTN(A_PLAIN, 128, 1); else LTN(A_PLAIN, 128, 0); }
     } else {
