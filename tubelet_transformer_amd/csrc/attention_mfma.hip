@@ -7,7 +7,8 @@
 // issued TRANSPOSED (keys / head dim as MFMA rows, queries or keys as MFMA columns) so that the accumulator layout of a score
 // tile (lane = one column, 4 consecutive rows) is already the B-operand layout of the following product -- P never goes
 // through LDS.  The 8 k-slots a lane contributes to that second product are rows {g*4..g*4+3} of two stacked 16-row tiles;
-// the A operand (V^T, K^T, Q^T, dO^T) is read from a transposed LDS image with the same slot order.
+// the A operand (V^T, K^T, Q^T, dO^T) is read with the same slot order from the ROW-MAJOR LDS image of V / K / Q / dO by the
+// gfx950 hardware transpose read (ds_read_b64_tr_b16) -- no transposed copies are ever written.
 //   forward : S^T = K Q^T, online softmax per query column (cross-lane-group max / sum = 2 shuffles), O^T += V^T P^T
 //   dQ      : S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
 //   dK, dV  : S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
@@ -18,7 +19,6 @@ namespace {
 
 constexpr int TL = 64;      // rows (keys or queries) per staged tile
 constexpr int RP = 40;      // row-major image: 80-byte rows (ds_read_b128 of 16 different rows is conflict-free)
-constexpr int TP = 68;      // transposed image [32][TL + 4]: 136-byte rows (8-byte aligned 4-element groups)
 
 __device__ __forceinline__ long trow(const TokMap& m, int l, int b) {
     return (long)l * m.sL + (long)(b / m.B2) * m.s1 + (long)(b % m.B2) * m.s2;
@@ -36,20 +36,21 @@ __device__ __forceinline__ uint4 tile_fetch(const bf16* base, const TokMap& m, i
 __device__ __forceinline__ void park_rm(bf16 (*dst)[RP], uint4 v) {
     *(uint4*)&dst[threadIdx.x >> 2][(threadIdx.x & 3) * 8] = v;
 }
-__device__ __forceinline__ void park_tr(bf16 (*dst)[TP], uint4 v) {
-    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-    const bf16x8 x = as_bf16x8(v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dst[c * 8 + e][r] = x[e];
-}
 // A operand from a row-major image: MFMA row i = image row (r0 + li), k = head dim g*8 .. g*8+7
 __device__ __forceinline__ bf16x8 frag_rm(const bf16 (*src)[RP], int r0, int li, int g) {
     return as_bf16x8(*(const uint4*)&src[r0 + li][g * 8]);
 }
-// A operand from a transposed image: MFMA row i = head dim d, k-slots = image columns {c0+g*4..+3, c0+16+g*4..+3}
-__device__ __forceinline__ bf16x8 frag_tr(const bf16 (*src)[TP], int d, int c0, int g) {
-    const uint2 lo = *(const uint2*)&src[d][c0 + g * 4], hi = *(const uint2*)&src[d][c0 + 16 + g * 4];
-    return as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+// the same A operand straight from a ROW-MAJOR image via the gfx950 LDS transpose read: the 16-lane group reads the [4 rows][16 d]
+// blocks at rows r0 + g*4 and r0 + 16 + g*4 (lane i supplies the address of chunk i = row i/4, columns (i%4)*4.. and receives
+// column i), i.e. lane (li, g) gets rows {r0+g*4..+3, r0+16+g*4..+3} of column d0 + li -- no transposed copy in LDS
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_tr_rm(const bf16 (*src)[RP], int d0, int r0, int li, int g) {
+    const bf16* p = &src[r0 + g * 4 + (li >> 2)][d0 + (li & 3) * 4];
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * RP));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
@@ -57,7 +58,7 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16); re
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 vt[32][TP];
+    __shared__ __attribute__((aligned(16))) bf16 vs[TL][RP];
     __shared__ uint8_t msk[TL];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
     for (int k0 = 0; k0 < a.Lk; k0 += TL) {
         __syncthreads();
         park_rm(ks, kr);
-        park_tr(vt, vr);
+        park_rm(vs, vr);
         if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
         if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
         __syncthreads();
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
             mx = mnew;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            o0 = mfma(frag_tr(vt, li, c0, g), pf, o0);
-            o1 = mfma(frag_tr(vt, 16 + li, c0, g), pf, o1);
+            o0 = mfma(frag_tr_rm(vs, 0, c0, li, g), pf, o0);
+            o1 = mfma(frag_tr_rm(vs, 16, c0, li, g), pf, o1);
         }
     }
     if (qok) {
@@ -134,7 +135,6 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
 __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
     __shared__ __attribute__((aligned(16))) bf16 vs[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 kt[32][TP];
     __shared__ uint8_t msk[TL];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
     for (int k0 = 0; k0 < a.Lk; k0 += TL) {
         __syncthreads();
         park_rm(ks, kr);
-        park_tr(kt, kr);
         park_rm(vs, vr);
         if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
         if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
@@ -183,8 +182,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
                     dsf[t * 4 + r] = f2bf(p * (dpv - delta) * a.scale);
                 }
             }
-            dq0 = mfma(frag_tr(kt, li, c0, g), dsf, dq0);
-            dq1 = mfma(frag_tr(kt, 16 + li, c0, g), dsf, dq1);
+            dq0 = mfma(frag_tr_rm(ks, 0, c0, li, g), dsf, dq0);
+            dq1 = mfma(frag_tr_rm(ks, 16, c0, li, g), dsf, dq1);
         }
     }
     if (qok) {
@@ -201,8 +200,6 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
 __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 qs[TL][RP];
     __shared__ __attribute__((aligned(16))) bf16 dos[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 qt[32][TP];
-    __shared__ __attribute__((aligned(16))) bf16 dot_[32][TP];
     __shared__ float lse_s[TL], del_s[TL];
     const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x * 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
@@ -221,8 +218,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
     if (threadIdx.x < TL && threadIdx.x < a.Lq) { lr = a.lse[bh * a.Lq + threadIdx.x]; er = a.delta[bh * a.Lq + threadIdx.x]; }
     for (int q0 = 0; q0 < a.Lq; q0 += TL) {
         __syncthreads();
-        park_rm(qs, qr); park_tr(qt, qr);
-        park_rm(dos, dr); park_tr(dot_, dr);
+        park_rm(qs, qr);
+        park_rm(dos, dr);
         if (threadIdx.x < TL) { lse_s[threadIdx.x] = lr; del_s[threadIdx.x] = er; }
         if (q0 + TL < a.Lq) {
             qr = tile_fetch(a.Q, a.mq, b, h, q0 + TL, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, q0 + TL, a.Lq);
@@ -253,10 +250,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
                     dsf[t * 4 + r] = f2bf(p * (dpv - del_s[ql]) * a.scale);
                 }
             }
-            dv0 = mfma(frag_tr(dot_, li, c0, g), pf, dv0);
-            dv1 = mfma(frag_tr(dot_, 16 + li, c0, g), pf, dv1);
-            dk0 = mfma(frag_tr(qt, li, c0, g), dsf, dk0);
-            dk1 = mfma(frag_tr(qt, 16 + li, c0, g), dsf, dk1);
+            dv0 = mfma(frag_tr_rm(dos, 0, c0, li, g), pf, dv0);
+            dv1 = mfma(frag_tr_rm(dos, 16, c0, li, g), pf, dv1);
+            dk0 = mfma(frag_tr_rm(qs, 0, c0, li, g), dsf, dk0);
+            dk1 = mfma(frag_tr_rm(qs, 16, c0, li, g), dsf, dk1);
         }
     }
     if (kin) {
