@@ -300,3 +300,37 @@ def test_csn_mat_loader_maps_caffe2_names_and_freezes(tmp_path):
     # tune_point 4 (build_CSN): stem, layer1, layer2 frozen; layer3, layer4 trainable (ir_CSN_152.py:251-254,301-303)
     assert not body.conv1.weight.requires_grad and not body.layer2[1].bn3.weight.requires_grad
     assert body.layer3[0].conv1.weight.requires_grad and body.layer4[1].bn4.bias.requires_grad
+
+
+def test_frame_map_matches_reference_evaluator_golden(tmp_path):
+    """row N2: the numpy frame-mAP against the reference's own evaluator (evaluates/evaluate_ava.py over the vendored PASCAL
+    evaluator) on synthetic result files with score ties, duplicate detections, invalid boxes, frames without ground truth and
+    classes without ground truth (oracle/gen_eval_golden.py -> tests/golden/frame_map_case.json): identical to the last bit."""
+    import json
+    from tubelet_transformer_amd.evaluation import FrameMAP, write_result_files
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "frame_map_case.json")))
+    (tmp_path / "GT_0.txt").write_text("\n".join(g["gt_lines"]) + "\n")
+    (tmp_path / "0.txt").write_text("\n".join(g["det_lines"]) + "\n")
+    ev = FrameMAP(g["class_num"])
+    ev.load_gt([str(tmp_path / "GT_0.txt")])
+    ev.load_detections([str(tmp_path / "0.txt")])
+    mAP, per_class = ev.evaluate()
+    assert mAP == g["mAP"]
+    for k, v in g["per_class_ap"].items():
+        c = int(k[1:])
+        if v is None:
+            assert c not in per_class                     # classes without ground truth do not enter the mean
+        else:
+            assert per_class[c] == v, (k, per_class[c], v)
+    # the writer produces lines the parser (and the reference's ``line.split(' [')`` parser) reads back unchanged
+    K = g["class_num"]
+    rng = np.random.default_rng(1)
+    det_ids = ["a_1", "a_1", "b_2"]
+    boxes, sc, bn = rng.uniform(0, 100, (3, 4)), rng.uniform(0, 1, (3, K)), rng.uniform(0, 1, (3, 3))
+    gt_b, gt_l = rng.uniform(0, 100, (2, 6)), (rng.uniform(0, 1, (2, K)) > 0.5).astype(np.float64)
+    dp, gp = write_result_files(str(tmp_path), "res", 0, det_ids, boxes, sc, bn, ["a_1", "b_2"], gt_b, gt_l)
+    lines = open(dp).read().splitlines()
+    assert len(lines) == 3 and lines[0].startswith("a_1 [") and lines[0].endswith("]")
+    vals = [float(x) for x in lines[2].split(" [")[1].split("]")[0].split(",")]
+    assert np.array_equal(np.asarray(vals), np.concatenate([boxes[2], sc[2], bn[2]]))
+    assert len(open(gp).read().splitlines()) == 2

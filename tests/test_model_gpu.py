@@ -254,3 +254,49 @@ def test_backward_vs_oracle(dev, yaml_name, hw):
     for ch, cb, eh, eb, nr, n in rows[:10]:
         print("  lowest: %-56s cos hip %.4f  cos bf16-oracle %.4f  relerr %.3f / %.3f  norm ratio %.3f" % (n, ch, cb, eh, eb, nr))
     assert not worse, "gradients worse than 2x a bf16-rounded oracle: %s" % worse[:20]
+
+
+@pytest.mark.gpu
+def test_eval_loop_writes_reference_format_and_scores(tmp_path):
+    """row N2 end to end on the GPU: validate_tuber_detection over a two-batch synthetic loader writes {rank}.txt / GT_{rank}.txt in
+    the reference's format and returns a finite frame-mAP; the epoch training loop runs on the same loader."""
+    from tubelet_transformer_amd.evaluation import validate_tuber_detection
+    from tubelet_transformer_amd.training import build_optimizer, train_tuber_detection
+    dev = torch.device("cuda:0")
+    cfg = load_cfg(os.path.join(ROOT, "configuration", "TubeR_CSN50_AVA21.yaml"))
+    cfg.CONFIG.LOG.BASE_PATH, cfg.CONFIG.LOG.RES_DIR = str(tmp_path), "tmp_res"
+    model, criterion, post = build_model(cfg)
+    synth.load_name_hashed(model)
+    model.to(dev)
+    criterion.to(dev)
+    H, W = 64, 96
+    loader = []
+    for i in range(2):
+        clips = synth.synthetic_clips(2, 32, H, W, seed=10 + i)
+        tg = synth.synthetic_targets(2, "ava", 80, seed=20 + i, device="cpu", hw=(H, W))
+        for b, t in enumerate(tg):
+            n = t["boxes"].shape[0]
+            t["image_id"] = ["vid%d_%04d" % (i, 900 + b), 16]
+            t["size"] = torch.tensor([H, W])
+            raw = torch.zeros(n, 6)
+            raw[:, 0] = b                      # index of the clip inside the batch
+            raw[:, 1] = 16                     # key-frame position
+            raw[:, 2:] = torch.rand(n, 4).sort(dim=1).values[:, [0, 1, 2, 3]] * torch.tensor([W, H, W, H]) / 2 + torch.tensor([0, 0, W / 2, H / 2])
+            t["raw_boxes"] = raw
+        loader.append((clips, tg))
+    mAP = validate_tuber_detection(cfg, model, criterion, post, loader, epoch=0, verbose=False)
+    assert mAP == mAP and 0.0 <= mAP <= 1.0
+    det = open(os.path.join(str(tmp_path), "tmp_res", "0.txt")).read().splitlines()
+    gt = open(os.path.join(str(tmp_path), "tmp_res", "GT_0.txt")).read().splitlines()
+    Q = cfg.CONFIG.MODEL.QUERY_NUM
+    assert len(det) == 2 * 2 * Q
+    key, rest = det[0].split(" [")
+    assert key == "vid0_0900" and len(rest.split("]")[0].split(",")) == 4 + 80 + 1      # box, class scores, actor probability
+    assert len(gt) == sum(t["boxes"].shape[0] for _, tg in loader for t in tg)
+    assert len(gt[0].split(" [")[1].split("]")[0].split(",")) == 6 + 80
+    # one training epoch over the same loader (eager steps)
+    opt = build_optimizer(model, cfg)
+    w0 = model.class_fc.weight.detach().clone()
+    loader2 = [(c, [{k: v for k, v in t.items()} for t in tg]) for c, tg in loader]
+    loss = train_tuber_detection(cfg, model, criterion, loader2, opt, epoch=0, max_norm=cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM, print_freq=100)
+    assert torch.isfinite(loss) and not torch.equal(w0, model.class_fc.weight.detach())

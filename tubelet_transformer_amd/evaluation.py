@@ -1,0 +1,263 @@
+"""Evaluation loop, result files and frame-mAP.
+
+Mirrors ``utils/video_action_recognition.py:222-454`` (``validate_tuber_detection``): eval-mode forward on the HIP path,
+``postprocessors['bbox']``, the per-rank text files ``{BASE_PATH}/{RES_DIR}/{rank}.txt`` / ``GT_{rank}.txt`` in the reference's
+exact format (``"{image_id} [x1, y1, x2, y2, <C scores>, <actor probs>]"`` and ``"{image_id} [<6 raw-box numbers>, <C labels>]"``),
+so the reference's own evaluator can be pointed at them unchanged, and a compact numpy restatement of the metric it computes
+(``evaluates/evaluate_ava.py:17-171`` driving the vendored PASCAL evaluator ``evaluates/utils/object_detection_evaluation.py:309``:
+per-class VOC average precision at IoU >= 0.5, greedy score-ordered matching, one detection per ground-truth box, classes without
+ground truth excluded from the mean).  ``tests/golden/frame_map_case.json`` pins it against the reference evaluator run in the
+build container (``oracle/gen_eval_golden.py``).  Host-side code: runs once per epoch on rank 0 (not throughput relevant).
+"""
+import glob
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# result files
+# ---------------------------------------------------------------------------------------------------------------------
+def write_result_files(base_path, res_dir, rank, det_ids, det_boxes, det_scores, det_binary, gt_ids, gt_boxes, gt_labels):
+    """video_action_recognition.py:397-407: one line per (frame, query) / per ground-truth box."""
+    d = os.path.join(base_path, res_dir)
+    os.makedirs(d, exist_ok=True)
+    det_path = os.path.join(d, "%d.txt" % rank)
+    gt_path = os.path.join(d, "GT_%d.txt" % rank)
+    with open(det_path, "w") as f:
+        for x in range(len(det_ids)):
+            data = np.concatenate([det_boxes[x], det_scores[x], det_binary[x]])
+            f.write("{} {}\n".format(det_ids[x], data.tolist()))
+    with open(gt_path, "w") as f:
+        for x in range(len(gt_ids)):
+            data = np.concatenate([gt_boxes[x], gt_labels[x]])
+            f.write("{} {}\n".format(gt_ids[x], data.tolist()))
+    return det_path, gt_path
+
+
+def _parse(line):
+    key = line.split(" [")[0]
+    vals = [float(v) for v in line.split(" [")[1].split("]")[0].split(",")]
+    return key, vals
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frame-mAP
+# ---------------------------------------------------------------------------------------------------------------------
+def _iou_one_to_many(box, boxes):
+    x1 = np.maximum(box[0], boxes[:, 0]); y1 = np.maximum(box[1], boxes[:, 1])
+    x2 = np.minimum(box[2], boxes[:, 2]); y2 = np.minimum(box[3], boxes[:, 3])
+    inter = np.maximum(x2 - x1, 0.0) * np.maximum(y2 - y1, 0.0)
+    a = (box[2] - box[0]) * (box[3] - box[1])
+    b = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    return inter / (a + b - inter)
+
+
+def _average_precision(precision, recall):
+    """area under the monotone precision envelope (VOC 2010+; object_detection/utils/metrics.py:compute_average_precision)"""
+    if precision is None or len(precision) == 0:
+        return float("nan")
+    r = np.concatenate([[0.0], recall, [1.0]])
+    p = np.concatenate([[0.0], precision, [0.0]])
+    for i in range(len(p) - 2, -1, -1):
+        p[i] = max(p[i], p[i + 1])
+    idx = np.where(r[1:] != r[:-1])[0] + 1
+    return float(np.sum((r[idx] - r[idx - 1]) * p[idx]))
+
+
+class FrameMAP:
+    """Frame-level mean average precision from the result files (STDetectionEvaluater semantics, evaluate_ava.py:17-171)."""
+
+    def __init__(self, class_num, class_whitelist=None, exclude_keys=(), iou_threshold=0.5, gt_min_score=1e-2):
+        self.class_num, self.iou = class_num, iou_threshold
+        self.whitelist = set(class_whitelist) if class_whitelist is not None else None
+        self.exclude = set(exclude_keys)
+        self.gt_min_score = gt_min_score
+        self.gt, self.det = {}, {}
+
+    def _wanted(self, cls):
+        return self.whitelist is None or cls in self.whitelist
+
+    def load_gt(self, paths):
+        for path in paths:
+            for line in open(path):
+                key, v = _parse(line)
+                if key in self.exclude:
+                    continue
+                labels = np.asarray(v[6:])
+                for x in np.nonzero(labels > self.gt_min_score)[0]:
+                    if self._wanted(int(x) + 1):
+                        self.gt.setdefault(key, []).append((int(x) + 1, np.asarray(v[2:6], dtype=float)))
+
+    def load_detections(self, paths):
+        for path in paths:
+            for line in open(path):
+                key, v = _parse(line)
+                if key in self.exclude:
+                    continue
+                box = np.asarray(v[0:4], dtype=float)
+                scores = v[4:self.class_num + 4]
+                for x, s in enumerate(scores):
+                    if self._wanted(x + 1):
+                        self.det.setdefault(key, []).append((x + 1, box, float(s)))
+
+    def evaluate(self):
+        """-> (mAP, {class_id: AP}).  Detections of images without ground truth count as false positives (the PASCAL evaluator
+        scores them against an empty ground-truth list, object_detection_evaluation.py:601-620)."""
+        # The data flow (and therefore the resolution of score ties) follows the reference exactly: per image all (box, class)
+        # entries in file order are ordered by np.argsort(-score) (evaluate_ava.py:150), matched greedily per class in that
+        # order (per_image_evaluation.py:354-366), concatenated per class in image order, and ranked by np.argsort(score)[::-1]
+        # (metrics.py:56-57).  numpy's default sort is deterministic, so equal inputs give the reference's permutation.
+        per_class = {}
+        n_gt = {}
+        for key, items in self.gt.items():
+            for cls, _ in items:
+                n_gt[cls] = n_gt.get(cls, 0) + 1
+        scores, tps = {}, {}
+        for key, dets in self.det.items():
+            gts = self.gt.get(key, [])
+            cls_a = np.asarray([d[0] for d in dets], dtype=int)
+            box_a = np.vstack([d[1] for d in dets])
+            sc_a = np.asarray([d[2] for d in dets], dtype=float)
+            index = np.argsort(-sc_a)
+            cls_a, box_a, sc_a = cls_a[index], box_a[index], sc_a[index]
+            valid = (box_a[:, 0] < box_a[:, 2]) & (box_a[:, 1] < box_a[:, 3])      # per_image_evaluation.py:445-449
+            cls_a, box_a, sc_a = cls_a[valid], box_a[valid], sc_a[valid]
+            for cls in range(1, self.class_num + 1):
+                sel = cls_a == cls
+                if not sel.any():
+                    continue
+                gboxes = np.asarray([b for c, b in gts if c == cls], dtype=float).reshape(-1, 4)
+                taken = np.zeros(len(gboxes), dtype=bool)
+                tp = np.zeros(int(sel.sum()), dtype=bool)
+                if len(gboxes):
+                    for i, box in enumerate(box_a[sel]):
+                        iou = _iou_one_to_many(box, gboxes)
+                        j = int(np.argmax(iou))
+                        if iou[j] >= self.iou and not taken[j]:
+                            taken[j] = True
+                            tp[i] = True
+                scores.setdefault(cls, []).append(sc_a[sel])
+                tps.setdefault(cls, []).append(tp)
+        for cls in range(1, self.class_num + 1):
+            if not self._wanted(cls) or n_gt.get(cls, 0) == 0:
+                continue
+            if cls not in scores:
+                per_class[cls] = 0.0
+                continue
+            s = np.concatenate(scores[cls]); t = np.concatenate(tps[cls])
+            order = np.argsort(s)[::-1]
+            t = t[order]
+            ctp = np.cumsum(t).astype(float); cfp = np.cumsum(~t).astype(float)
+            per_class[cls] = _average_precision(ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps), ctp / n_gt[cls])
+        mAP = float(np.mean(list(per_class.values()))) if per_class else float("nan")
+        return mAP, per_class
+
+
+def read_labelmap(path):
+    """utils/utils.py:10-25: pbtxt label map -> ([{id, name}], {ids})."""
+    labelmap, ids, name = [], set(), ""
+    with open(path) as f:
+        for line in f:
+            if line.startswith("  name:"):
+                name = line.split('"')[1]
+            elif line.startswith("  id:") or line.startswith("  label_id:"):
+                cid = int(line.strip().split(" ")[-1])
+                labelmap.append({"id": cid, "name": name})
+                ids.add(cid)
+    return labelmap, ids
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def validate_tuber_detection(cfg, model, criterion, postprocessors, data_loader, epoch, writer=None, excluded_timestamps=None,
+                             verbose=True):
+    """video_action_recognition.py:222-454.  Differences: no 30 s sleep, no hard-coded /xxx/ path (``excluded_timestamps`` = csv path
+    or None), the distributed barriers are only issued when torch.distributed is initialised, the metric is FrameMAP."""
+    import torch.distributed as dist
+    C = cfg.CONFIG
+    ddp = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if ddp else 0                   # the reference reads cfg.DDP_CONFIG.GPU_WORLD_RANK / _SIZE, which its
+    world = dist.get_world_size() if ddp else 1            # launcher fills from the same process group
+    model.eval()
+    criterion.eval()
+    dev = next(model.parameters()).device
+    res = os.path.join(C.LOG.BASE_PATH, C.LOG.RES_DIR)
+    if rank == 0:
+        os.makedirs(res, exist_ok=True)
+        for p in glob.glob(os.path.join(res, "*.txt")):
+            os.remove(p)
+    det_scores, det_boxes, det_binary, det_ids, gt_labels, gt_boxes, gt_ids = [], [], [], [], [], [], []
+    meters = {k: [0.0, 0] for k in ("loss", "loss_bbox", "loss_giou", "loss_ce", "loss_ce_b", "class_error")}
+    end = time.time()
+    for idx, data in enumerate(data_loader):
+        samples, targets = data[0], data[1]
+        batch_id = [t["image_id"] for t in targets]
+        targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
+        outputs = model(samples)
+        loss_dict = criterion(outputs, targets)
+        sizes = torch.stack([t["size"] for t in targets], dim=0)
+        scores, boxes, output_b = postprocessors["bbox"](outputs, sizes)
+        Q = C.MODEL.QUERY_NUM
+        for b in range(scores.shape[0]):
+            frame_id, key_pos = batch_id[b][0], batch_id[b][1]
+            if not C.MODEL.SINGLE_FRAME:
+                k = key_pos // C.MODEL.DS_RATE
+                sl = slice(k * Q, (k + 1) * Q)
+                det_scores.append(scores[b, sl]); det_boxes.append(boxes[b, sl]); det_binary.append(output_b[b, sl])
+            else:
+                det_scores.append(scores[b]); det_boxes.append(boxes[b]); det_binary.append(output_b[b])
+            det_ids.extend([frame_id] * Q)
+            raw = targets[b]["raw_boxes"]
+            sel = (raw[:, 1] == key_pos).nonzero().reshape(-1)
+            lab = targets[b]["labels"][sel].reshape(len(sel), -1)
+            rb = raw[sel].reshape(len(sel), -1)
+            gt_labels.append(lab.cpu().numpy()); gt_boxes.append(rb.cpu().numpy())
+            first = float(targets[0]["raw_boxes"][0, 0])
+            gt_ids.extend(batch_id[int(float(rb[x, 0]) - first)][0] for x in range(len(rb)))
+        wd = criterion.weight_dict
+        total = float(sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd))
+        if not math.isfinite(total):
+            raise FloatingPointError("loss is %r in evaluation: %r" % (total, {k: float(v) for k, v in loss_dict.items()}))
+        n = len(targets)
+        for k, v in (("loss", total), ("loss_bbox", loss_dict["loss_bbox"]), ("loss_giou", loss_dict["loss_giou"]),
+                     ("loss_ce", loss_dict["loss_ce"]), ("loss_ce_b", loss_dict.get("loss_ce_b", 0.0)),
+                     ("class_error", loss_dict["class_error"])):
+            meters[k][0] += float(v) * n; meters[k][1] += n
+        if verbose and rank == 0:
+            print("Epoch: [%d][%d/%d]  batch time %.3f  " % (epoch, idx + 1, len(data_loader), time.time() - end) +
+                  ", ".join("%s: %.3f" % (k, s / max(c, 1)) for k, (s, c) in meters.items()))
+        end = time.time()
+    cat = lambda xs, w: np.concatenate(xs, axis=0) if xs else np.zeros((0, w))
+    nc = C.DATA.NUM_CLASSES
+    write_result_files(C.LOG.BASE_PATH, C.LOG.RES_DIR, rank, det_ids, cat(det_boxes, 4), cat(det_scores, nc), cat(det_binary, 1),
+                       gt_ids, cat(gt_boxes, 6), cat(gt_labels, nc))
+    if writer is not None and rank == 0:
+        for k, (s, c) in meters.items():
+            writer.add_scalar("val/" + k, s / max(c, 1), epoch)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    mAP = 0.0
+    if rank == 0:
+        white = None
+        if getattr(C.DATA, "LABEL_PATH", None) and os.path.isfile(C.DATA.LABEL_PATH):
+            _, white = read_labelmap(C.DATA.LABEL_PATH)
+        excl = []
+        if excluded_timestamps and os.path.isfile(excluded_timestamps):
+            excl = [l.strip().replace(",", "_") for l in open(excluded_timestamps) if l.strip()]
+        ev = FrameMAP(nc, class_whitelist=white if nc == 80 else None, exclude_keys=excl)
+        ev.load_gt([os.path.join(res, "GT_%d.txt" % r) for r in range(world)])
+        ev.load_detections([os.path.join(res, "%d.txt" % r) for r in range(world)])
+        mAP, per_class = ev.evaluate()
+        if verbose:
+            print("mAP: %.5f" % mAP)
+        if writer is not None:
+            writer.add_scalar("val/val_mAP_epoch", mAP, epoch)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    return mAP

@@ -175,3 +175,40 @@ class GraphedTrainStep:
             lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
             g.B2.replay()
         return g.loss, g.loss_dict
+
+
+def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, max_norm, lr_scheduler=None, writer=None,
+                          graphed=None, print_freq=10):
+    """One training epoch -- the reference's ``train_tuber_detection`` (utils/video_action_recognition.py:64-220) on the HIP path:
+    every batch is one ``train_step`` (or one replay of ``graphed``, a ``GraphedTrainStep``); losses are read back only every
+    ``print_freq`` iterations so the GPU queue stays full.  ``epoch > LOSS_COFS.WEIGHT_CHANGE`` switches ``loss_ce``'s weight
+    like the reference (:145-146)."""
+    import time
+    model.train()
+    criterion.train()
+    dev = next(model.parameters()).device
+    rank = getattr(cfg.DDP_CONFIG, "GPU_WORLD_RANK", 0)
+    if epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:
+        criterion.weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
+    end = time.time()
+    loss = None
+    for idx, data in enumerate(data_loader):
+        samples, targets = data[0], data[1]
+        targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
+        if graphed is not None:
+            clips = (samples.tensors if hasattr(samples, "tensors") else samples).to(dev, torch.float32)
+            loss, loss_dict = graphed(clips, targets)
+        else:
+            loss, loss_dict = train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=epoch, cfg=cfg)
+        if lr_scheduler is not None and cfg.CONFIG.TRAIN.LR_POLICY == "cosine":
+            lr_scheduler.step_update(epoch * len(data_loader) + idx)
+        if rank == 0 and (idx % print_freq == 0 or idx + 1 == len(data_loader)):
+            lv = float(loss.detach())                          # the only host sync, every print_freq iterations
+            if lv != lv or lv in (float("inf"), float("-inf")):
+                raise FloatingPointError("loss is %r at epoch %d iteration %d" % (lv, epoch, idx))
+            print("Epoch: [%d][%d/%d]  %.3f s/iter  loss %.4f  " % (epoch, idx + 1, len(data_loader), (time.time() - end), lv) +
+                  ", ".join("%s %.4f" % (k, float(v.detach() if torch.is_tensor(v) else v)) for k, v in loss_dict.items() if k in ("loss_ce", "loss_bbox", "loss_giou", "loss_ce_b", "class_error")))
+            if writer is not None:
+                writer.add_scalar("train/loss", lv, idx + epoch * len(data_loader))
+        end = time.time()
+    return loss
