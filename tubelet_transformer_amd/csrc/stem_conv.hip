@@ -195,17 +195,22 @@ __global__ __launch_bounds__(256) void stem_conv_bwd_w_kernel(const float* __res
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // G tile staging: 64 m x 64 n in 4x4 blocks, one block per thread: mi = 0..15 (x4 rows), ci = 0..15 (x4 cols)
     const int ci = (lane & 3) | ((lane >> 4) << 2), mi = ((lane >> 2) & 3) + 4 * wave;
+    // software pipeline over the tiles: the patch / gradient loads of tile t+1 are issued right after tile t has been parked
+    // in LDS, so their latency hides behind tile t's 56 MFMAs (one workgroup per CU: nothing else would hide it)
     float4 pre[NQUAD];
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    uint2 gr[4];
+    auto fetch = [&](int tile) {
         stem_load_patch4(clip, g, tile, pre);
         const int wt = tile % g.tilesW;
         const long row0 = (long)(tile / g.tilesW) * g.Wo + wt * SW;
-        uint2 gr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int w = wt * SW + mi * 4 + j;
             gr[j] = w < g.Wo ? *(const uint2*)(G + (row0 + mi * 4 + j) * 64 + ci * 4) : make_uint2(0, 0);
         }
+    };
+    if (blockIdx.x < g.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         __syncthreads();                                     // previous tile's MFMAs are done with PE / PO / GT
         stem_store_patch_eo(PE, PO, pre);
         {
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(256) void stem_conv_bwd_w_kernel(const float* __res
                 *(uint2*)&GT[ci * 4 + c][mi * 4] = as_uint2(y);
             }
         }
+        if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);
         __syncthreads();
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
