@@ -269,7 +269,7 @@ def main():
     if not args.no_roofline:
         timer = LaunchTimer()
         lib.set_launch_hook(timer)
-        os.environ["TUBER_NO_SIDE_STREAM"] = "1"        # per-kernel timing: every launch on one stream, nothing concurrent
+        os.environ["TUBER_NO_SIDE_STREAM"] = "1"        # per-kernel timing: every launch on one stream even if TUBER_SIDE_STREAM is set
         eager_step()
         torch.cuda.synchronize()
         os.environ.pop("TUBER_NO_SIDE_STREAM", None)

@@ -116,7 +116,9 @@ class ParamStore:
     def side(self, *keep):
         """``with store.side(t1, t2, ...):`` -- launches inside run on the side stream after everything enqueued so far;
         the listed tensors (inputs produced on the main stream) are kept alive until ``side_join``."""
-        if os.environ.get("TUBER_NO_SIDE_STREAM"):      # profiling: every launch on one stream, in program order
+        # Measured on MI355X (DESIGN.md section 3): once the step was down to ~2 000 launches a second stream for the weight
+        # gradients COSTS 2 ms/step in a hipGraph (cross-queue dependencies) and 3.5 ms eagerly, so it is opt-in.
+        if not os.environ.get("TUBER_SIDE_STREAM") or os.environ.get("TUBER_NO_SIDE_STREAM"):
             yield
             return
         if self.side_stream is None:
