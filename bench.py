@@ -39,8 +39,8 @@ def alg_cost(name, a):
             by += 2 * M * N          # residual read
         if epi == 2:
             by += 2 * M * N          # mask source read
-        tile = {0: "128,128,2,2,2", 1: "128,64,4,1,2", 2: "64,64,2,2,4", 7: "64,128,1,4,2"}[cfg]
-        return "gemm_nt_kernel<%s,%d,%d>" % (tile, amode, epi), by, 2 * M * N * K
+        tile = {0: "128,128,2,2,2", 1: "128,64,4,1,2", 2: "64,64,2,2,4", 7: "64,128,1,4,2", 8: "64,64,2,2,4", 9: "64,128,1,4,2"}[cfg]
+        return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, 2 if cfg in (8, 9) else 1), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
         T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64

@@ -75,6 +75,37 @@ def test_gemm_nt_bn_prologue_stats(dev, M, N, K):
     close("gemm_nt stats sumsq", st1.sum(0), (ref * ref).sum(0), rel=2e-3)
 
 
+@pytest.mark.parametrize("cfg", [2, 7, 8, 9])
+@pytest.mark.parametrize("M,N,K", [(5632, 256, 1024), (5632, 1024, 256), (700, 128, 192), (130, 64, 64)])
+def test_gemm_nt_forced_tile_configs(dev, cfg, M, N, K):
+    """every shipped tile configuration (2: 64x64, 7: 64x128, 8/9: the same with the k-tiles split over two 4-wave groups, incl. an
+    odd number of k-tiles and a single tile) through all prologue / epilogue variants"""
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    sc, sh = 1.0 + 0.2 * rnd(K, dev=dev, seed=5), 0.3 * rnd(K, dev=dev, seed=6)
+    bias = rnd(N, dev=dev, seed=3)
+    R = rnd(M, N, dev=dev, seed=4).to(BF)
+    Cm = rnd(M, N, dev=dev, seed=7).to(BF)
+    lib.call("tuber_gemm_nt_set_cfg", cfg)
+    try:
+        ref = A.float() @ B.float().t()
+        C, _, _ = gemm_nt(A, B, M, N, K, bias=bias, R=R, relu=1)
+        close("cfg%d plain" % cfg, C, (ref + bias + R.float()).relu())
+        a = bfr((A.float() * sc + sh).relu())
+        ref1 = a @ B.float().t()
+        C, st0, st1 = gemm_nt(A, B, M, N, K, amode=1, sc=sc, sh=sh, epi=1)
+        close("cfg%d bn+stats out" % cfg, C, ref1)
+        close("cfg%d stats sum" % cfg, st0.sum(0), ref1.sum(0), abs_=2e-3 * float(ref1.abs().sum(0).max()))
+        close("cfg%d stats sumsq" % cfg, st1.sum(0), (ref1 * ref1).sum(0), rel=2e-3)
+        C, st0, st1 = gemm_nt(A, B, M, N, K, epi=2, Cm=Cm)
+        refm = ref * (Cm.float() > 0)
+        close("cfg%d masked out" % cfg, C, refm)
+        close("cfg%d masked sum" % cfg, st0.sum(0), refm.sum(0), abs_=2e-3 * float(refm.abs().sum(0).max()))
+        close("cfg%d masked sum dz*c" % cfg, st1.sum(0), (refm * Cm.float()).sum(0), abs_=2e-3 * float((refm * Cm.float()).abs().sum(0).max()))
+    finally:
+        lib.call("tuber_gemm_nt_set_cfg", -1)
+
+
 def test_gemm_nt_gather(dev):
     n, Ti, Hi, Wi, K, N = 2, 8, 15, 21, 256, 512
     st, ss = 2, 2

@@ -45,21 +45,28 @@ __device__ __forceinline__ int swz_act(int row) { return (row >> 1) & 7; }
 template <int NT>
 __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
 
-template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI>
-__global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4 : 1) void gemm_nt_kernel(GemmNT p) {
+// KS = 2: two 4-wave groups per workgroup split the k-tiles (group kg takes tiles kg, kg+2, ..) with their own LDS double
+// buffers and are summed through LDS before the epilogue: half the dependent k-iterations per workgroup and twice the waves
+// per CU for the short-M shapes (layer3/4: M = 5 632 gives only 352 workgroups of 64x64) that are latency- not bandwidth-bound.
+template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4 : 1)) void gemm_nt_kernel(GemmNT p) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = KS == 2 ? (int)(threadIdx.x >> 8) : 0;          // k group of this thread
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // thread / wave id INSIDE the group
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K / 64;
+    const int nkt = p.K / 64;                                   // k-tiles of the whole problem
+    const int nk = (nkt - kg + KS - 1) / KS;                    // ... of this group (local tile j <-> global tile j*KS + kg)
+    const int nk_max = (nkt + KS - 1) / KS;                     // barrier count is uniform over the groups
+    char* const gsm = smem + kg * 2 * STAGE;                    // this group's double buffer
 
     // ---- staging assignment: chunk c = tid + 256*i -> (row = c>>3, q = c&7) ----
     const int q = tid & 7;
@@ -95,11 +102,11 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
     // registers -> (BN prologue) -> LDS -> MFMA.
     uint4 ra[G][CA], rb[G][CB];
     uint4 ra2[AMODE == A_BN_BWD ? G : 1][CA];
-    float* lsc = (float*)(smem + 2 * STAGE);       // A_BN_RELU: scale[K] | shift[K] staged once;  A_BN_BWD: cA | cB | cC
+    float* lsc = (float*)(smem + KS * 2 * STAGE);  // A_BN_RELU: scale[K] | shift[K] staged once;  A_BN_BWD: cA | cB | cC
     float* lsh = lsc + p.K;
     float* lsc2 = lsh + p.K;
-    auto load_tile = [&](int kt, uint4 (&xa)[CA], uint4 (&xb)[CB], uint4 (&xa2)[CA]) {
-        const int k0 = kt * 64;
+    auto load_tile = [&](int kl, uint4 (&xa)[CA], uint4 (&xb)[CB], uint4 (&xa2)[CA]) {
+        const int k0 = (kl * KS + kg) * 64;
 #pragma unroll
         for (int i = 0; i < CA; ++i) xa[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
         if (AMODE == A_BN_BWD) {
@@ -109,8 +116,9 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
 #pragma unroll
         for (int i = 0; i < CB; ++i) xb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
     };
-    auto store_tile = [&](int kt, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB], const uint4 (&xa2)[CA]) {
-        char* sa = smem + buf * STAGE;
+    auto store_tile = [&](int kl, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB], const uint4 (&xa2)[CA]) {
+        const int kt = kl * KS + kg;
+        char* sa = gsm + buf * STAGE;
         char* sb = sa + BM * 128;
         float sc[8], sh[8], s2[8];
         if (AMODE == A_BN_BWD) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
     for (int j = 0; j < NT; ++j) w_row[j] = wn * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);
 
     auto compute = [&](int buf) {
-        const char* sa = smem + buf * STAGE;
+        const char* sa = gsm + buf * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
         }
     }
     if (AMODE != A_PLAIN) {
-        for (int i = tid; i < p.K; i += 256) {
+        for (int i = threadIdx.x; i < p.K; i += 256 * KS) {
             lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i];
             if (AMODE == A_BN_BWD) lsc2[i] = p.a_coef2[i];
         }
@@ -212,18 +220,42 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
     // software pipeline over k-tiles: register set j holds tile g0+j; as soon as it has been written to LDS the same
     // registers are re-armed with tile g0+G+j, so G tiles of global loads stay in flight behind the MFMA work.
     int buf = 0;
-    for (int g0 = 0; g0 < nk; g0 += G) {
+    for (int g0 = 0; g0 < nk_max; g0 += G) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            if (g0 + j < nk) {
-                store_tile(g0 + j, buf, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
+            if (g0 + j < nk_max) {
+                const bool have = g0 + j < nk;           // (odd tile counts: the second group idles through its last barrier)
+                if (have) store_tile(g0 + j, buf, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
                 if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
                 __syncthreads();
-                compute(buf);
+                if (have) compute(buf);
                 buf ^= 1;
             }
         }
     }
+    if (KS == 2) {
+        // sum the two k groups: group 1 parks its accumulators in LDS ([tile][thread] float4: 16-byte accesses), group 0 adds them
+        // and runs the epilogue alone (group 1 only keeps hitting the barriers)
+        __syncthreads();
+        f32x4* xr = (f32x4*)smem;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) xr[(i * NT + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x4 o = xr[(i * NT + j) * 256 + tid];
+                    acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+                }
+        }
+    }
+    const bool epi_on = KS == 1 || kg == 0;
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
     float s0[NC], s1[NC];
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * TM + i * 16 + li;
-        const bool mok = m < p.M;
+        const bool mok = m < p.M && epi_on;
         float v[NC];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -278,8 +310,10 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
                     v[c] = dropout_keep(seed, (uint64_t)m * p.N + nb + c, p.drop_thresh) ? v[c] * p.drop_inv_keep : 0.f;
             }
         } else if (EPI == EPI_STATS) {
+            if (epi_on) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
+                for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
+            }
         } else {  // EPI_BWD: dz = acc * [relu'(bn(c))];  stats: sum dz, sum dz*c
             if (mok) {
 #pragma unroll
@@ -323,14 +357,14 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
         for (int c = 0; c < NC; ++c) {
             const float a = quad16_sum(s0[c]);
             const float b = quad16_sum(s1[c]);
-            if (li == 0) {
+            if (li == 0 && epi_on) {
                 const int col = wn * TN + g * NC + c;
                 red[(wm * BN + col) * 2 + 0] = a;
                 red[(wm * BN + col) * 2 + 1] = b;
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
+        if (epi_on && tid < BN && n0 + tid < p.N) {
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
@@ -340,22 +374,22 @@ __global__ __launch_bounds__(256, (BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4
     }
 }
 
-template <int BM, int BN, int WM, int WN, int G>
+template <int BM, int BN, int WM, int WN, int G, int KS = 1>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
-    dim3 grid(tiles), block(256);
+    const size_t lds = KS * 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
+    dim3 grid(tiles), block(256 * KS);
 #define LNT(AM, EP)                                                                                                   \
     do {                                                                                                              \
         if (lds > 65536) { /* more than 64 KB of dynamic LDS needs a one-time opt-in per kernel */                    \
             static bool done = false;                                                                                 \
             if (!done) {                                                                                              \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>,                     \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, KS>,                     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
                 done = true;                                                                                          \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP>), grid, block, lds, s, p);                      \
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, KS>), grid, block, lds, s, p);                      \
     } while (0)
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
@@ -386,12 +420,14 @@ static int nt_pick_cfg(int M, int N, int K) {
     // measured on MI355X in isolation (scripts/gemm_bench.py, profiles/r01_*): every tile here has 64 rows (one partial-statistics
     // row per 64 output rows); 64x64 (4-5 workgroups resident per CU) wins the small-N and long-K shapes, 64x128 the wide
     // short-K ones (conv4 / dgrad1 of layer1-3, class-branch projections) where re-reading A per 64 columns is what costs
+    // (cfg 8 / 9 = the same tiles with the k-tiles split over two wave groups: -13..-20 % on the long-K short-M shapes in
+    // isolation, nothing measurable on the step -- available through tuber_gemm_nt_set_cfg, not chosen automatically)
     return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 2;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0 || cfg == 3) { *bm = 128; *wm = 2; }
     else if (cfg == 1 || cfg == 5) { *bm = 128; *wm = 4; }
-    else if (cfg == 6 || cfg == 7) { *bm = 64; *wm = 1; }
+    else if (cfg == 6 || cfg == 7 || cfg == 9) { *bm = 64; *wm = 1; }
     else { *bm = 64; *wm = 2; }
 }
 
@@ -444,6 +480,8 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
         case 5: return launch_nt_cfg<128, 64, 4, 1, 4>(p, amode, epi, stream);
         case 6: return launch_nt_cfg<64, 256, 1, 4, 2>(p, amode, epi, stream);
         case 7: return launch_nt_cfg<64, 128, 1, 4, 2>(p, amode, epi, stream);
+        case 8: return launch_nt_cfg<64, 64, 2, 2, 4, 2>(p, amode, epi, stream);
+        case 9: return launch_nt_cfg<64, 128, 1, 4, 2, 2>(p, amode, epi, stream);
         default: return launch_nt_cfg<64, 64, 2, 2, 4>(p, amode, epi, stream);
     }
 }
