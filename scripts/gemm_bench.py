@@ -77,7 +77,7 @@ def bench_tn():
         out = torch.zeros(N, K, device=dev)
 
         def fn():
-            lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
+            lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, None)
         print("%-28s %8.1f %6d   | %.1f MB %.2f GF" % ("%d %d %d" % (M, N, K), time_it(fn), S, (2 * M * (N + K) + 4 * N * K) / 1e6, 2 * M * N * K / 1e9), flush=True)
 
 

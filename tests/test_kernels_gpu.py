@@ -150,10 +150,10 @@ def test_gemm_tn(dev, M, N, K, amode):
     part = torch.empty(S, N, K, device=dev)
     out = torch.zeros(N, K, device=dev)
     lib.call("tuber_gemm_tn", G, N, A, K, part, out, 0, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
+             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, None)
     close("gemm_tn %dx%dx%d amode %d" % (M, N, K, amode), out, ref, rel=2e-3)
     lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
+             0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, None)
     close("gemm_tn accumulate", out, 2 * ref, rel=2e-3)
 
 
@@ -168,7 +168,7 @@ def test_gemm_tn_gather(dev):
     S = lib.query("tuber_gemm_tn_slabs", M, N, K)
     part = torch.empty(S, N, K, device=dev)
     out = torch.zeros(N, K, device=dev)
-    lib.call("tuber_gemm_tn", G, N, X, K, part, out, 0, M, N, K, 0, None, None, 1, To, Ho, Wo, Ti, Hi, Wi, st, ss, None, 0, None, None, None)
+    lib.call("tuber_gemm_tn", G, N, X, K, part, out, 0, M, N, K, 0, None, None, 1, To, Ho, Wo, Ti, Hi, Wi, st, ss, None, 0, None, None, None, None)
     close("gemm_tn gather", out, G.float().t() @ Xs.float(), rel=2e-3)
 
 
@@ -453,6 +453,21 @@ def test_gemm_nt_bn_backward_prologue(dev, M, N, K, epi):
         close("gemm_nt amode2 epi2 sum dz", st0.sum(0), refm.sum(0), abs_=2e-3 * float(refm.abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(704, 2048, 256), (30, 256, 256), (180, 256, 2048), (704, 256, 2048)])
+def test_gemm_tn_fused_bias_gradient(dev, M, N, K):
+    """single-slab weight gradients also produce the bias gradient (column sums of G from the LDS image) in the same launch"""
+    assert lib.query("tuber_gemm_tn_fuses_bias", M, N, K, N, K) == 1
+    G = rnd(M, N, dev=dev, seed=1).to(BF)
+    A = rnd(M, K, dev=dev, seed=2).to(BF)
+    out = torch.ones(N, K, device=dev)
+    db = torch.ones(N, device=dev)
+    part = torch.empty(N * K, device=dev)
+    lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, db)
+    close("gemm_tn (+bias) dW", out - 1, G.float().t() @ A.float(), rel=4e-3)
+    close("gemm_tn fused dbias", db - 1, G.float().sum(0), abs_=2e-3 * float(G.float().abs().sum(0).max()))
+    assert lib.query("tuber_gemm_tn_fuses_bias", 5632, 1024, 256, 1024, 256) == 0        # several slabs: separate colsum
+
+
 @pytest.mark.parametrize("M,N,K,amode", [(5632, 1024, 256, 1), (700, 64, 192, 0), (44032, 128, 64, 0)])
 def test_gemm_tn_bn_backward_prologue(dev, M, N, K, amode):
     """G operand = cA[n]*dz + cB[n]*x + cC[n] formed on load (weight gradients of conv4 / conv1 / down_sample)."""
@@ -468,7 +483,7 @@ def test_gemm_tn_bn_backward_prologue(dev, M, N, K, amode):
     part = torch.empty(S * N * K, device=dev)
     out = torch.ones(N, K, device=dev)
     lib.call("tuber_gemm_tn", dz, N, A, K, part, out, 1, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0, x, N, cA, cB, cC)
+             0, 0, 0, 0, 0, 0, 0, 0, 0, x, N, cA, cB, cC, None)
     close("gemm_tn G prologue", out - 1, ref, rel=4e-3)
 
 

@@ -294,7 +294,7 @@ class CSNRunner:
         S = lib.query("tuber_gemm_tn_slabs", M, N, K)
         part = self.ws("tn", S * N * K)
         g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
-        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None)
+        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None, None)
 
     def backward(self, saved, dfeat):
         """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients are

@@ -503,6 +503,7 @@ struct GemmTN {
     int M, N, K, S, rows_per_slab, accumulate;
     const float* a_scale; const float* a_shift;   // A_BN_RELU on A (per k column)
     const bf16* G2; long ldg2; const float* gA; const float* gB; const float* gC;   // GMODE 1: G := gA[n]*G + gB[n]*G2 + gC[n]
+    float* bias_grad;            // gemm_tn2, single slab: dbias[n] += sum_m G[m][n] from the LDS image (no separate column-sum launch)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
 };
 
@@ -770,6 +771,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
             ash[e] = k < p.K ? p.a_shift[k] : 0.f;
         }
     }
+    const bool do_bias = p.bias_grad != nullptr && tile_k == 0;       // host guarantees S == 1 then
+    float bsum = 0.f;
     constexpr int GS = 4;
     uint4 rg[GS][2], ra[GS][2];
     bool rok[GS][2];
@@ -824,6 +827,11 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
             __syncthreads();
             const bf16* gi = smem[buf][0];
             const bf16* ai = smem[buf][1];
+            if (do_bias) {                          // column sums of this step's G rows: thread = (column, 16-row part)
+                const bf16* col = gi + (tid >> 6) * 16 * TNP + (tid & 63);
+#pragma unroll
+                for (int mm = 0; mm < 16; ++mm) bsum += bf2f(col[mm * TNP]);
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int m0 = ks * 32 + g * 8;
@@ -846,6 +854,12 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
     float* P = p.P + (long)slab * p.N * p.K;
     __syncthreads();
     float* ot = (float*)&smem[0][0][0];                 // [64 n][64 k + 4] fp32 = 17 KB of the 36 KB staging area
+    if (do_bias) {
+        float* br = (float*)&smem[1][1][0];             // far end of the staging area (the tile below uses the first 17 KB)
+        br[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < p.N) p.bias_grad[n0 + tid] += (br[tid] + br[64 + tid]) + (br[128 + tid] + br[192 + tid]);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -917,11 +931,17 @@ int tuber_gemm_tn_slabs(int M, int N, int K) {
     return (int)S;
 }
 
+// 1 when tuber_gemm_tn can also accumulate the bias gradient dbias[n] += sum_m G[m][n] (single slab, transpose-read kernel)
+int tuber_gemm_tn_fuses_bias(int M, int N, int K, long ldg, long lda) {
+    if (getenv("TUBER_TN_REGISTER_TRANSPOSE")) return 0;
+    return tn_tile(N, K) == 64 && !((N | K | ldg | lda) & 7) && tuber_gemm_tn_slabs(M, N, K) == 1;
+}
+
 int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* partial, float* out, int accumulate,
                   int M, int N, int K, int amode, const float* a_scale, const float* a_shift,
                   int gather, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
                   const void* G2, long ldg2, const float* gA, const float* gB, const float* gC,
-                  hipStream_t stream) {
+                  float* bias_grad, hipStream_t stream) {
     // N / K need not be multiples of 4, but G / A must be readable up to ceil4(N) / ceil4(K) columns (padded ld)
     if (M <= 0 || N <= 0 || K <= 0 || (ldg & 3) || (lda & 3) || ldg < ((N + 3) & ~3) || lda < ((K + 3) & ~3)) return TUBER_EINVAL;
     GemmTN p;
@@ -945,7 +965,10 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
 #define LTN(AM, TT, GM) hipLaunchKernelGGL((gemm_tn_kernel<AM, TT, GM>), grid, block, lds, stream, p)
     static int use_tr = -1;
     if (use_tr < 0) use_tr = getenv("TUBER_TN_REGISTER_TRANSPOSE") ? 0 : 1;      // A/B switch for profiling
+    p.bias_grad = nullptr;
+    if (bias_grad && !tuber_gemm_tn_fuses_bias(M, N, K, ldg, lda)) return TUBER_EINVAL;
     if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7)) {     // LDS transpose-read kernel
+        p.bias_grad = bias_grad;
         if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn2_kernel<A_BN_RELU>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(gemm_tn2_kernel<A_PLAIN>, grid, block, 0, stream, p);
     } else if (T == 128) {

@@ -154,9 +154,11 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
         gw = st.gflat.data_ptr() + 4 * (st.offsets[wname] + r0 * K)
         with st.side(gb, x):               # weight / bias gradients feed nothing until the optimizer
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None)
-            if bname:
-                gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0)
+            gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if bname else None
+            fuse_b = bool(bname) and lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) == 1     # bias gradient inside the GEMM
+            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
+                     gbias if fuse_b else None)
+            if bname and not fuse_b:
                 lib.call("tuber_colsum", gb, workspace(dev, "cs", lib.query("tuber_colsum_blocks", M) * N), gbias, 1, M, N, ldg)
         # data gradient; accumulation with an existing gradient of x and the ReLU/Dropout mask of x are GEMM epilogues
         toff, _, _, ldt = st.tinfo[wname]
