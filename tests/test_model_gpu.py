@@ -300,3 +300,37 @@ def test_eval_loop_writes_reference_format_and_scores(tmp_path):
     loader2 = [(c, [{k: v for k, v in t.items()} for t in tg]) for c, tg in loader]
     loss = train_tuber_detection(cfg, model, criterion, loader2, opt, epoch=0, max_norm=cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM, print_freq=100)
     assert torch.isfinite(loss) and not torch.equal(w0, model.class_fc.weight.detach())
+
+
+@pytest.mark.gpu
+def test_split_graph_step_matches_single_graph(monkeypatch):
+    """the DDP form of the captured step (hipGraph cut where layer3's backward ends, so the gradient all-reduce can run under
+    layer2/layer1/stem) replays exactly the same kernels as the single graph: identical parameters after two steps"""
+    from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer
+    dev = torch.device("cuda:0")
+    results = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("TUBER_FORCE_SPLIT_GRAPH", "1")
+        else:
+            monkeypatch.delenv("TUBER_FORCE_SPLIT_GRAPH", raising=False)
+        cfg = load_cfg(os.path.join(ROOT, "configuration", "TubeR_CSN50_AVA21.yaml"))
+        torch.manual_seed(0)
+        model, criterion, _ = build_model(cfg)
+        synth.load_name_hashed(model)
+        model.to(dev).train()
+        criterion.to(dev).train()
+        opt = build_optimizer(model, cfg)
+        clips = synth.synthetic_clips(2, 32, 64, 96, seed=3, device=dev)
+        targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(64, 96))
+        step = GraphedTrainStep(model, criterion, opt, cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM)
+        store, _ = model.engine()
+        store.manual_seed(123)
+        for _ in range(2):
+            loss, _ = step(clips, targets)
+        torch.cuda.synchronize()
+        g = next(iter(step.graphs.values()))
+        assert (g.A2 is not None) == force
+        results.append((float(loss), store.flat.detach().clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])

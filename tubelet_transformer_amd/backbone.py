@@ -156,6 +156,7 @@ class CSNRunner:
                 d = {"cin": blk.conv1.in_channels, "p": blk.conv1.out_channels, "st": blk.temporal_stride, "ss": blk.stride,
                      "ds": blk.down_sample is not None}
                 d["off0"] = store.offsets[p + "conv1.weight"]
+                d["stage"], d["first"] = li, bi == 0
                 d["w1"], _, d["g1"] = wptr(p + "conv1.weight")
                 d["w1t"], d["ld1t"] = tptr(p + "conv1.weight")
                 _, d["w3"], d["g3"] = wptr(p + "conv3.weight")
@@ -171,6 +172,7 @@ class CSNRunner:
         # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
         body = [store.offsets[n] + (q.numel() + 63) // 64 * 64 for n, q in zip(store.names, store.params) if n.startswith(prefix)]
         self.body_end = max(body)
+        self.body_begin = min(store.offsets[n] for n in store.names if n.startswith(prefix))
 
     # -- workspaces (serialised on the stream, so one of each kind suffices) ---------------------
     def ws(self, key, numel, dtype=torch.float32):
@@ -373,6 +375,11 @@ class CSNRunner:
             if red is not None:
                 self.store.side_join()           # the slice handed to RCCL must include the side-stream weight gradients
                 red.notify(d["off0"])
+            hook = getattr(self, "split_hook", None)
+            if hook is not None and d["first"] and d["stage"] == 3:
+                # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
+                # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem
+                hook(d["off0"])
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
         clips, _, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
         M0 = B * T * Ho * Wo

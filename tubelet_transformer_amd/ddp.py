@@ -1,15 +1,18 @@
 """Data-parallel training over the GPUs of one node: one process per GPU, RCCL all-reduce over xGMI.
 
 The reference wraps the model in ``DistributedDataParallel(find_unused_parameters=True)`` (utils/model_utils.py:39-58,
-pipelines/launch.py:20-50).  Here every parameter gradient already lives in ONE flat fp32 buffer that the backward
-kernels fill from its high end (heads, transformer) down to offset 0 (stem), so the reducer is a handful of large
-all-reduces on contiguous slices, issued from the backward pass as soon as a slice is final and overlapped with the
-remaining backward kernels on RCCL's own stream:
+pipelines/launch.py:20-50).  Here every parameter gradient already lives in ONE flat fp32 buffer in ``named_parameters()``
+order -- transformer, embeddings, projections, class-branch encoder, heads, THEN the CSN body (stem, layer1..4) and the pool
+decoder -- so the reducer is a handful of large all-reduces on contiguous slices, issued from the backward pass as soon as a
+slice is final and overlapped with the remaining backward kernels on RCCL's own stream:
 
     backward reaches ...            slice that is final              -> dist.all_reduce(slice, async_op=True)
-    BackboneFn.backward entry       everything above the backbone
-    end of layer4 / 3 / 2 / 1       that stage's parameters
-    end of backward                 stem + "late" parameters (embedding tables)
+    body backward entry             everything laid out behind the body (pool decoder)
+    end of layer4 / 3 / 2 / 1       that stage's parameters (offsets >= the stage's first block)
+    end of backward                 the rest: stem, and the transformer / head slice laid out before the body
+
+(The hipGraph step, training.GraphedTrainStep, does not use these hooks: it cuts its graph once, where layer3's backward ends,
+and reduces [layer3 .. end) and [0 .. body) under the layer2 / layer1 / stem backward.)
 
 No bucket copies, no unused-parameter bitmap (C2), no per-step buffer broadcast (C3): BatchNorm statistics stay local
 like the reference's non-synchronised BatchNorm3d; rank 0's running statistics are what a checkpoint holds.

@@ -8,6 +8,8 @@ The reference additionally copies ``pred_logits`` to the host every step as a Na
 times on rank 0 (:182-193); here the only device->host transfer of a step is the single matcher cost copy, and logging
 reads the (still on-device) loss tensors only when asked to.
 """
+import os
+
 import torch
 
 from .ddp import FlatGradReducer, broadcast_parameters
@@ -120,7 +122,45 @@ class GraphedTrainStep:
             if world == 1:
                 opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
 
-        if g.on_device:
+        g.A2, g.split = None, None
+        # Opt-in (TUBER_SPLIT_GRAPH=1): verified bit-exact on one GPU and run end-to-end with 2 gloo ranks, but this build has never
+        # had a multi-GPU box to validate it under RCCL, so the default DDP step keeps the plain form (graph, all-reduce, graph).
+        split = g.on_device and bool(os.environ.get("TUBER_SPLIT_GRAPH") or os.environ.get("TUBER_FORCE_SPLIT_GRAPH")) \
+            and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
+        if split:
+            # DDP: graph A is cut where layer3's backward ends (~95 % of the gradient bytes are final there), so the RCCL
+            # all-reduce of that slice runs under the layer2 / layer1 / stem backward (graph A2) instead of after it.
+            _, runner = model.engine()
+            cut = {}
+            a2 = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            cs = torch.cuda.Stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            try:
+                with torch.cuda.stream(cs):
+                    g.A.capture_begin(capture_error_mode="relaxed")      # the cut happens on autograd's worker thread
+
+                    def hook(off):
+                        if "off" not in cut:
+                            g.A.capture_end()
+                            cut["off"] = off
+                            a2.capture_begin(pool=g.A.pool(), capture_error_mode="relaxed")
+                    runner.split_hook = hook
+                    try:
+                        head()
+                        g.match = crit.assign(g.cost, g.pt)
+                        tail()
+                    finally:
+                        runner.split_hook = None
+                    if "off" in cut:
+                        a2.capture_end()
+                        g.A2, g.split, g.body_begin = a2, int(cut["off"]), int(runner.body_begin)
+                    else:
+                        g.A.capture_end()
+                torch.cuda.current_stream().wait_stream(cs)
+            except Exception:
+                raise
+        elif g.on_device:
             with torch.cuda.graph(g.A):
                 head()
                 g.match = crit.assign(g.cost, g.pt)
@@ -168,6 +208,39 @@ class GraphedTrainStep:
             L = len(indices)
             self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
             g.B1.replay()
+        if g.A2 is not None:
+            import torch.distributed as dist
+            ddp = g.B2 is not None and dist.is_initialized()
+            dbg = os.environ.get("TUBER_DEBUG_TIMING")
+            if dbg:
+                import time
+                torch.cuda.synchronize(); t0 = time.time()
+            # final at the cut: layer3, layer4 and everything laid out behind the body [split, total) and everything laid out
+            # before it (transformer, heads: [0, body_begin)); pending: stem, layer1, layer2 [body_begin, split)
+            bb = g.body_begin
+            h1 = [dist.all_reduce(store.gflat[g.split:], op=dist.ReduceOp.SUM, async_op=True),
+                  dist.all_reduce(store.gflat[:bb], op=dist.ReduceOp.SUM, async_op=True)] if ddp else None
+            if dbg:
+                t1 = time.time()
+            g.A2.replay()                                     # layer2 / layer1 / stem backward, under the all-reduce
+            if dbg:
+                t2 = time.time()
+            if ddp:
+                h2 = dist.all_reduce(store.gflat[bb:g.split], op=dist.ReduceOp.SUM, async_op=True)
+                for h in h1:
+                    h.wait()
+                if dbg:
+                    t3 = time.time()
+                h2.wait()
+                if dbg:
+                    torch.cuda.synchronize()
+                    print("split step: issue ar1 %.1f ms, replay A2 %.1f ms, wait ar1 %.1f ms, ar2+sync %.1f ms (phase 1: [%d,%d) + [0,%d) of %d floats)"
+                          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.time() - t3) * 1e3, g.split, store.total, bb, store.total), flush=True)
+                from . import lib
+                lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
+            if g.B2 is not None:
+                g.B2.replay()
+            return g.loss, g.loss_dict
         if g.B2 is not None:
             import torch.distributed as dist
             dist.all_reduce(store.gflat, op=dist.ReduceOp.SUM)
