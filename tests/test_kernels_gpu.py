@@ -259,7 +259,7 @@ def test_dwconv_tile(dev, N, T, H, W, C):
     close("dwconv tile bwd data sum dz", s0.sum(0), dz_ref.sum((0, 1, 2, 3)), abs_=2e-3 * float(dz_ref.abs().sum((0, 1, 2, 3)).max()))
     close("dwconv tile bwd data sum dz*x", s1.sum(0), (dz_ref * x.float()).sum((0, 1, 2, 3)),
           abs_=2e-3 * float((dz_ref * x.float()).abs().sum((0, 1, 2, 3)).max()))
-    part = torch.empty(R, 27, C, device=dev)
+    part = torch.empty(lib.query("tuber_dwconv_tile_wgrad_blocks", N, T, H, W, C), 27, C, device=dev)
     dw = torch.ones(C, 27, device=dev)
     lib.call("tuber_dwconv_tile_bwd_weight", g, x, sc, sh, part, dw, 1, N, T, H, W, C)
     close("dwconv tile bwd weight", dw - 1, wp.grad, rel=2e-3)

@@ -332,14 +332,14 @@ class CSNRunner:
             dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
-            nb = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
+            nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
             with self.store.side(dc3, c1):
                 if tile:
                     lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi, P)
                 else:
                     lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
                              To, Hq, Wq, P, st, ss)
-            R1 = nb if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
+            R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
             s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
             dz1 = torch.empty(Min, P, dtype=BF, device=dev)
             if tile:

@@ -12,6 +12,8 @@
 //   * zero padding is applied AFTER the activation (the reference pads relu(bn1(.))).
 // Modes: forward (+ partial statistics of bn3), data gradient (flipped taps; fused with the backward of relu(bn1(.)) and
 // bn1's partial statistics), weight gradient (27 x 4 accumulators per thread, one partial [27][64] per workgroup).
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -261,14 +263,24 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     }
 }
 
-TileGeom make_geom(int N, int T, int H, int W, int C) {
+TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
     TileGeom g;
     g.N = N; g.T = T; g.H = H; g.W = W; g.C = C;
     g.htiles = (H + TH - 1) / TH; g.wtiles = (W + TW - 1) / TW;
     const long base = (long)N * g.htiles * g.wtiles * (C / 64);
-    long tc = (long)T * base / 512;                 // >= ~512 workgroups when the volume allows; halo re-fetch is cheap
-    if (tc < 1) tc = 1;
-    if (tc > T) tc = T;
+    // planes per workgroup: one workgroup is resident per CU (145 KB of LDS), so the kernel runs in ceil(WGs / 256) rounds of
+    // (tc + 2) plane steps (2 = halo planes staged before the first output); pick the tc that minimises rounds x steps
+    // (layer1: tc = 4 -> 768 workgroups = 3 full rounds of 6 steps instead of 576 = 2.25 -> 3 rounds of 8)
+    long best_cost = -1, tc = 1;
+    for (long c = 1; c <= T; ++c) {
+        const long chunks = (T + c - 1) / c;
+        const long rounds = (base * chunks + 255) / 256;
+        const long cost = rounds * (c + 2);
+        // ties: forward / data gradient take the split with more workgroups, the weight gradient the one with fewer (each of
+        // its workgroups ends with a 108-accumulator reduction and a 6.9 KB partial)
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && wgrad)) { best_cost = cost; tc = c; }
+    }
+    { const char* e = getenv("TUBER_DW_TC"); if (e && atoi(e) > 0) tc = atoi(e) > T ? T : atoi(e); }     // experiments only
     g.tc = (int)tc;
     g.tchunks = (T + g.tc - 1) / g.tc;
     return g;
@@ -298,6 +310,12 @@ int tuber_dwconv_tile_blocks(int N, int T, int H, int W, int C) {
     return g.N * g.tchunks * g.htiles * g.wtiles;
 }
 
+// partial blocks of the weight gradient (its own plane chunking)
+int tuber_dwconv_tile_wgrad_blocks(int N, int T, int H, int W, int C) {
+    const TileGeom g = make_geom(N, T, H, W, C, true);
+    return g.N * g.tchunks * g.htiles * g.wtiles;
+}
+
 int tuber_dwconv_tile_fwd(const void* x, const float* sc, const float* sh, const float* w, void* out, float* st0, float* st1,
                           int N, int T, int H, int W, int C, hipStream_t stream) {
     if (C & 63) return TUBER_EINVAL;
@@ -316,13 +334,13 @@ int tuber_dwconv_tile_bwd_data(const void* gout, const float* w, const void* x, 
     return launch_tile<M_BWD_DATA>(a, stream);
 }
 
-// partial must hold tuber_dwconv_tile_blocks * 27 * C floats; dw is the [C][27] fp32 weight gradient
+// partial must hold tuber_dwconv_tile_wgrad_blocks * 27 * C floats; dw is the [C][27] fp32 weight gradient
 int tuber_dwconv_tile_bwd_weight(const void* gout, const void* x, const float* sc, const float* sh, float* partial, float* dw,
                                  int accumulate, int N, int T, int H, int W, int C, hipStream_t stream) {
     if ((C & 63) || !sc || !sh) return TUBER_EINVAL;
     TileArgs a{};
     a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.aux = (const bf16*)gout; a.P = partial;
-    a.g = make_geom(N, T, H, W, C);
+    a.g = make_geom(N, T, H, W, C, true);
     const int rc = launch_tile<M_BWD_WEIGHT>(a, stream);
     if (rc) return rc;
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);

@@ -40,6 +40,7 @@ DOC = {
     "tuber_dwconv_tile_bwd_data": "LDS-staged data gradient of the stride-1 conv3, fused with the backward of relu(bn1(.)) like tuber_dwconv_bwd_data.",
     "tuber_dwconv_tile_bwd_weight": "LDS-staged weight gradient of the stride-1 conv3 (activation recomputed while staging).",
     "tuber_dwconv_tile_blocks": "workgroups along x of the LDS-staged depthwise kernels = partial-stat rows / weight-gradient partial blocks.",
+    "tuber_dwconv_tile_wgrad_blocks": "partial blocks (size of `partial` / (27*C)) of tuber_dwconv_tile_bwd_weight.",
     "tuber_dw_wgrad_reduce": "dw[c][tap] (+)= sum_r partial[r][tap][c]: second stage of the depthwise weight gradient.",
     "tuber_bn_finalize": "training-mode nn.BatchNorm3d(eps=1e-3, momentum=0.1) statistics (ir_CSN_152.py:15-16,46,56,64,119,154): partial rows -> "
                          "mean/invstd, scale=gamma*invstd, shift=beta-mean*scale, running_mean/var (unbiased) and num_batches_tracked update.",
