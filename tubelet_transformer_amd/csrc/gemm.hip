@@ -76,10 +76,13 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
         const int row = (tid >> 3) + 32 * i;
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
+        // rows beyond M / N are loaded from the last valid row instead of being predicated to zero: an exec-masked 16-byte load
+        // costs ~8 instructions (zero fill, saveexec, branch) per k-tile; their products only reach output rows / columns that are
+        // never stored, and the statistics epilogues skip them
+        const int m = min(m0 + row, p.M - 1);
+        a_ok[i] = m0 + row < p.M;
         long src = m;
-        if (p.gather && a_ok[i]) {
+        if (p.gather) {
             int w = m % p.Wo; int r = m / p.Wo;
             int h = r % p.Ho; r /= p.Ho;
             int t = r % p.To; int n = r / p.To;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
     for (int i = 0; i < CB; ++i) {
         const int row = (tid >> 3) + 32 * i;
         b_ok[i] = (n0 + row) < p.N;
-        b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + q * 8;
+        b_ptr[i] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + q * 8;
     }
 
     // k-tiles are fetched in groups of G: all global loads of a group are in flight together (one HBM latency per
@@ -102,19 +105,26 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
     // registers -> (BN prologue) -> LDS -> MFMA.
     uint4 ra[G][CA], rb[G][CB];
     uint4 ra2[AMODE == A_BN_BWD ? G : 1][CA];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {                 // fully defined on every path, so the arrays stay in registers
+#pragma unroll
+        for (int i = 0; i < CA; ++i) { ra[j][i] = make_uint4(0, 0, 0, 0); if (AMODE == A_BN_BWD) ra2[j][i] = make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) rb[j][i] = make_uint4(0, 0, 0, 0);
+    }
     float* lsc = (float*)(smem + KS * 2 * STAGE);  // A_BN_RELU: scale[K] | shift[K] staged once;  A_BN_BWD: cA | cB | cC
     float* lsh = lsc + p.K;
     float* lsc2 = lsh + p.K;
     auto load_tile = [&](int kl, uint4 (&xa)[CA], uint4 (&xb)[CB], uint4 (&xa2)[CA]) {
         const int k0 = (kl * KS + kg) * 64;
 #pragma unroll
-        for (int i = 0; i < CA; ++i) xa[i] = a_ok[i] ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < CA; ++i) xa[i] = *(const uint4*)(a_ptr[i] + k0);
         if (AMODE == A_BN_BWD) {
 #pragma unroll
-            for (int i = 0; i < CA; ++i) xa2[i] = a_ok[i] ? *(const uint4*)(a2_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < CA; ++i) xa2[i] = *(const uint4*)(a2_ptr[i] + k0);
         }
 #pragma unroll
-        for (int i = 0; i < CB; ++i) xb[i] = b_ok[i] ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < CB; ++i) xb[i] = *(const uint4*)(b_ptr[i] + k0);
     };
     auto store_tile = [&](int kl, int buf, const uint4 (&xa)[CA], const uint4 (&xb)[CB], const uint4 (&xa2)[CA]) {
         const int kt = kl * KS + kg;
@@ -141,14 +151,14 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
                 bf16x8 x = as_bf16x8(v), y;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sc[e], sh[e]), 0.f));
-                v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
+                v = as_uint4(y);
             }
             if (AMODE == A_BN_BWD) {
                 const bf16x8 x = as_bf16x8(v), x2 = as_bf16x8(xa2[i]);
                 bf16x8 y;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaf(bf2f(x[e]), sc[e], fmaf(bf2f(x2[e]), sh[e], s2[e])));
-                v = a_ok[i] ? as_uint4(y) : make_uint4(0, 0, 0, 0);
+                v = as_uint4(y);
             }
             *(uint4*)(sa + row * 128 + ((q ^ swz_act(row)) << 4)) = v;
         }
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
                     v[c] = dropout_keep(seed, (uint64_t)m * p.N + nb + c, p.drop_thresh) ? v[c] * p.drop_inv_keep : 0.f;
             }
         } else if (EPI == EPI_STATS) {
-            if (epi_on) {
+            if (mok) {                                   // rows beyond M hold a copy of row M-1
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
             }
