@@ -12,6 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_frames_resize": "PIL.Image.resize((nw, nh)) of every decoded frame (datasets/ava_frame.py:146-150; jhmdb_frame.py alike): Pillow's 8-bit two-pass "
+                           "fixed-point bicubic (libImaging/Resample.c), packed RGB uint8 [nimg][H][W][3] -> [nimg][Ho][Wo][3], bit-exact.",
+    "tuber_clip_prepare": "hflip + crop + ColorJitter + ToTensor/Normalize (datasets/video_transforms.py:69-85,20-66,333-369,308-322; pipeline "
+                          "datasets/ava_frame.py:158-176) and the batch collate of utils/misc.py:279-282,367-425 in one pass: uint8 frames -> "
+                          "fp32 [N][3][T][Hmax][Wmax] zero padded + bool mask [N][Hmax][Wmax]. One TuberClipDesc per clip (56 bytes: long long src_off; "
+                          "int H, W, y1, x1, h, w, flip, jitter, hue, sat, val, pad).",
+    "tuber_clip_desc_bytes": "sizeof(TuberClipDesc) as the library was compiled (host-side layout check).",
     "tuber_gemm_nt": "C[M,N] = f(A)[M,K] . B[N,K]^T on MFMA bf16. Replaces every nn.Conv3d(k=1) of the CSN bottlenecks "
                      "(models/backbones/ir_CSN_152.py:41,58,155-161), input_proj/class_proj (models/tuber_ava.py:57-58) and every "
                      "nn.Linear / packed in-projection (models/transformer/transformer.py:159-165,227-245; transformer_layers.py:81-94; "
@@ -128,6 +135,16 @@ extern "C" {
 #endif
 
 typedef struct ihipStream_t* hipStream_t;
+
+/* one clip of tuber_clip_prepare (device memory, 56 bytes) */
+typedef struct TuberClipDesc {
+    long long src_off;   /* byte offset of the clip's first frame in `frames` (uint8 [T][H][W][3]) */
+    int H, W;            /* frame size */
+    int y1, x1, h, w;    /* crop window in the (flipped) frame: output (y,x) reads (y1+y, x1+x) */
+    int flip, jitter;    /* horizontal flip before the crop; HSV colour jitter on/off */
+    int hue, sat, val;   /* ColorJitter shifts (hue in OpenCV half-degrees) */
+    int pad_;
+} TuberClipDesc;
 
 '''
 FOOTER = '''

@@ -197,6 +197,7 @@ def validate_tuber_detection(cfg, model, criterion, postprocessors, data_loader,
     end = time.time()
     for idx, data in enumerate(data_loader):
         samples, targets = data[0], data[1]
+        samples = samples.to(dev)            # reference :280 / :513; runs the HIP clip pre-pass when the loader yields ClipBatch
         batch_id = [t["image_id"] for t in targets]
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
         outputs = model(samples)

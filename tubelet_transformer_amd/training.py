@@ -267,6 +267,7 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
     loss = None
     for idx, data in enumerate(data_loader):
         samples, targets = data[0], data[1]
+        samples = samples.to(dev)            # reference :121; for an input_pipeline.ClipBatch this IS the HIP pre-pass (uint8 frames -> fp32 batch)
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
         if graphed is not None:
             clips = (samples.tensors if hasattr(samples, "tensors") else samples).to(dev, torch.float32)
