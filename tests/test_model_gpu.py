@@ -334,3 +334,43 @@ def test_split_graph_step_matches_single_graph(monkeypatch):
         results.append((float(loss), store.flat.detach().clone()))
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
+
+
+@pytest.mark.gpu
+def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
+    """one tuber_multi_reduce launch per backward pass instead of ~240 second-stage reductions: same summation order, so the captured
+    step must produce exactly the parameters of the immediate path (TUBER_IMMEDIATE_REDUCE=1), eagerly and from the hipGraph."""
+    from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer
+    dev = torch.device("cuda:0")
+    results = []
+    for immediate in (True, False):
+        if immediate:
+            monkeypatch.setenv("TUBER_IMMEDIATE_REDUCE", "1")
+        else:
+            monkeypatch.delenv("TUBER_IMMEDIATE_REDUCE", raising=False)
+        poison = [torch.full((1 << 28,), float("nan"), device=dev) for _ in range(6)]    # freed blocks the arena will be carved from:
+        del poison                                                                        # a partial read before it is written shows as NaN
+        cfg = load_cfg(os.path.join(ROOT, "configuration", "TubeR_CSN50_AVA21.yaml"))
+        torch.manual_seed(0)
+        model, criterion, _ = build_model(cfg)
+        synth.load_name_hashed(model)
+        model.to(dev).train()
+        criterion.to(dev).train()
+        opt = build_optimizer(model, cfg)
+        clips = synth.synthetic_clips(2, 32, 128, 160, seed=3, device=dev)      # big enough that the dW GEMMs split into slabs
+        targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(128, 160))
+        step = GraphedTrainStep(model, criterion, opt, cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM)
+        store, _ = model.engine()
+        assert store.defer.enabled == (not immediate)
+        store.manual_seed(123)
+        for _ in range(3):
+            loss, _ = step(clips, targets)
+        torch.cuda.synchronize()
+        if not immediate:
+            assert store.defer.cache and not store.defer.entries
+            ntab = sum(int(v[0].numel()) // store.defer._ENTRY.itemsize for v in store.defer.cache.values())
+            assert ntab > 50, "expected many deferred reductions, got %d" % ntab
+        results.append((float(loss), store.flat.detach().clone(), store.gflat.detach().clone()))
+    assert results[0][0] == results[1][0] and results[0][0] == results[0][0]
+    assert torch.equal(results[0][2], results[1][2])
+    assert torch.equal(results[0][1], results[1][1])

@@ -294,9 +294,11 @@ class CSNRunner:
 
     def _wgrad(self, G, ldg, A, lda, out, M, N, K, amode=0, sc=None, sh=None, gather=None):
         S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-        part = self.ws("tn", S * N * K)
+        part, acc = self.store.partial("tn", S * N * K, self.ws) if S > 1 else (None, 1)
         g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
-        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, 1, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None, None)
+        lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, acc, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None, None)
+        if acc == 2:
+            self.store.defer.add(part, out if isinstance(out, int) else out.data_ptr(), N * K, N * K, S, 0 if S <= 16 else 1)
 
     def backward(self, saved, dfeat):
         """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients are
@@ -334,11 +336,15 @@ class CSNRunner:
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
             nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
             with self.store.side(dc3, c1):
+                part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
                 if tile:
-                    lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi, P)
+                    lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B, Ti, Hi, Wi, P)
                 else:
-                    lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, self.ws("tn", nb * 27 * P), d["g3"], 1, B, Ti, Hi, Wi,
+                    lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B, Ti, Hi, Wi,
                              To, Hq, Wq, P, st, ss)
+                if acc == 2:
+                    g3 = d["g3"]
+                    self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
             R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
             s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
             dz1 = torch.empty(Min, P, dtype=BF, device=dev)
@@ -374,8 +380,11 @@ class CSNRunner:
             dy = dx
             if red is not None:
                 self.store.side_join()           # the slice handed to RCCL must include the side-stream weight gradients
+                self.store.defer.flush()         # ... and the deferred second-stage reductions
                 red.notify(d["off0"])
             hook = getattr(self, "split_hook", None)
+            if d["first"] and d["stage"] == 3:
+                self.store.defer.flush()         # always here, so eager warm-up and a split capture build the same reduce tables
             if hook is not None and d["first"] and d["stage"] == 3:
                 # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
                 # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem

@@ -428,7 +428,8 @@ int tuber_dwconv_bwd_weight(const void* gout, const void* x, const float* sc, co
     dim3 grid(nb, C / 64), block(256);
     if (ss == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);
     else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, grid, block, 0, stream, (const bf16*)gout, (const bf16*)x, sc, sh, partial, g, iters);
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div(27 * C, 32)), dim3(1024), 0, stream, partial, dw, nb, C, accumulate);
+    if (accumulate != 2)                       // accumulate == 2: partial blocks reduced later by tuber_multi_reduce
+        hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(ceil_div(27 * C, 32)), dim3(1024), 0, stream, partial, dw, nb, C, accumulate);
     TUBER_RETURN_LAUNCH();
 }
 

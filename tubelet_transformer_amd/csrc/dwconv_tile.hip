@@ -342,7 +342,7 @@ int tuber_dwconv_tile_bwd_weight(const void* gout, const void* x, const float* s
     a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.aux = (const bf16*)gout; a.P = partial;
     a.g = make_geom(N, T, H, W, C, true);
     const int rc = launch_tile<M_BWD_WEIGHT>(a, stream);
-    if (rc) return rc;
+    if (rc || accumulate == 2) return rc;      // accumulate == 2: partial blocks reduced later by tuber_multi_reduce
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
 }
 

@@ -923,7 +923,7 @@ extern "C" {
 // chip to ~256 workgroups but never more than 8 (bounds the fp32 slab traffic to <= the size of the operands) and
 // at least 256 rows each.
 static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
-int tuber_gemm_tn_slabs(int M, int N, int K) {
+static int tn_slabs_wanted(int M, int N, int K) {
     const int T = tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
     long S = (512 + tiles - 1) / tiles;
@@ -940,6 +940,9 @@ int tuber_gemm_tn_slabs(int M, int N, int K) {
     if (S < 1) S = 1;
     return (int)S;
 }
+static int tn_rows_per_slab(int M, int N, int K) { return ceil_div(ceil_div(M, tn_slabs_wanted(M, N, K)), 64) * 64; }
+// slabs actually written (rows per slab are rounded up to 64, so this can be fewer than the split aimed for)
+int tuber_gemm_tn_slabs(int M, int N, int K) { return ceil_div(M, tn_rows_per_slab(M, N, K)); }
 
 // 1 when tuber_gemm_tn can also accumulate the bias gradient dbias[n] += sum_m G[m][n] (single slab, transpose-read kernel)
 int tuber_gemm_tn_fuses_bias(int M, int N, int K, long ldg, long lda) {
@@ -956,11 +959,9 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     if (M <= 0 || N <= 0 || K <= 0 || (ldg & 3) || (lda & 3) || ldg < ((N + 3) & ~3) || lda < ((K + 3) & ~3)) return TUBER_EINVAL;
     GemmTN p;
     p.G = (const bf16*)G; p.ldg = ldg; p.A = (const bf16*)A; p.lda = lda;
-    p.M = M; p.N = N; p.K = K; p.S = tuber_gemm_tn_slabs(M, N, K);
-    int rps = ceil_div(M, p.S);
-    rps = ceil_div(rps, 64) * 64;
-    p.rows_per_slab = rps;
-    p.S = ceil_div(M, rps);
+    p.M = M; p.N = N; p.K = K;
+    p.rows_per_slab = tn_rows_per_slab(M, N, K);
+    p.S = tuber_gemm_tn_slabs(M, N, K);
     p.accumulate = accumulate;
     p.P = p.S == 1 ? out : partial;            // a single slab writes (or accumulates into) the gradient directly
     p.a_scale = a_scale; p.a_shift = a_shift;
@@ -989,7 +990,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
         else { if (gmode) LTN(A_PLAIN, 64, 1); else LTN(A_PLAIN, 64, 0); }
     }
 #undef LTN
-    if (p.S > 1) {
+    if (p.S > 1 && accumulate != 2) {          // accumulate == 2: the caller reduces the slabs later (tuber_multi_reduce)
         const long n = (long)N * K;
         if (p.S <= 16) hipLaunchKernelGGL(reduce_slabs_flat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);
         else hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 32)), dim3(1024), 0, stream, partial, out, n, p.S, accumulate);

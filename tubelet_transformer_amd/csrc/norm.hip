@@ -415,6 +415,42 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
     }
 }
 
+// one entry of tuber_multi_reduce: out[j] += sum_{s<S} P[s*stride + j], j < n.
+//   mode 0: one thread per element, s ascending (few slabs);  mode 1: 32 slab groups x 32 elements per block, LDS tree;
+//   C > 0 (mode 1): P is [S][27][C] and the result goes to out[c*27 + tap] (depthwise weight gradient).
+struct MultiReduceEntry {
+    const float* P;
+    float* out;
+    long n, stride;
+    int S, mode, C, pad_;
+};
+__global__ __launch_bounds__(1024) void multi_reduce_kernel(const MultiReduceEntry* __restrict__ table, const int2* __restrict__ blk) {
+    __shared__ float red[32][33];
+    const int2 be = blk[blockIdx.x];
+    const MultiReduceEntry e = table[be.x];
+    if (e.mode == 0) {
+        const long i = (long)be.y * 1024 + threadIdx.x;
+        if (i >= e.n) return;
+        float a = 0.f;
+        for (int s = 0; s < e.S; ++s) a += e.P[(long)s * e.stride + i];
+        e.out[i] += a;
+    } else {
+        const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const long j = (long)be.y * 32 + cl;
+        float a = 0.f;
+        if (j < e.n) for (int s = rg; s < e.S; s += 32) a += e.P[(long)s * e.stride + j];
+        red[rg][cl] = a;
+        __syncthreads();
+        if (rg == 0 && j < e.n) {
+            a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) a += red[i][cl];
+            float* o = e.C > 0 ? e.out + (j % e.C) * 27 + j / e.C : e.out + j;
+            *o += a;
+        }
+    }
+}
+
 // partial column sums of a bf16 [M, ld] matrix (bias gradient): block (bx, by) sums rows [bx*rpb, (bx+1)*rpb) of the
 // 64 columns by*64.. ; thread = (row lane of 32, 8-column group of 8): 128-byte row segments, 4 rows in flight.
 // With one row block the result goes straight to out (+= when accumulate); otherwise to P[bx][C].
@@ -616,7 +652,8 @@ int tuber_layernorm_bwd(const void* dy, long lddy, const void* xhat, const float
     else if (E == 2048) LNB(32);
     else return TUBER_EINVAL;
 #undef LNB
-    if (dbeta == dgamma + E) {        // weight and bias adjacent in the flat gradient buffer: one reduction over [nb][2E]
+    if (accumulate == 2) {            // the caller reduces partial [nb][2E] later (tuber_multi_reduce)
+    } else if (dbeta == dgamma + E) { // weight and bias adjacent in the flat gradient buffer: one reduction over [nb][2E]
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(2 * E, 32)), dim3(1024), 0, stream, partial, dgamma, nb, 2 * E, accumulate, (long)2 * E);
     } else {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(E, 32)), dim3(1024), 0, stream, partial, dgamma, nb, E, accumulate, (long)2 * E);
@@ -645,9 +682,21 @@ int tuber_colsum(const void* g, float* partial, float* out, int accumulate, long
     const int groups = (C + 7) / 8;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (groups + 7) / 8), dim3(256), 0, stream, (const bf16*)g, partial, out, accumulate,
                        M, C, ld, rpb);
-    if (nb > 1)
+    if (nb > 1 && accumulate != 2)             // accumulate == 2: partial [nb][C] reduced later by tuber_multi_reduce
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, partial, out, nb, C, accumulate, (long)C);
     TUBER_RETURN_LAUNCH();
 }
+
+// All deferred second-stage reductions of one backward pass in ONE launch.  The weight-gradient GEMMs, depthwise weight gradients,
+// LayerNorm and bias gradients each leave per-workgroup fp32 partials (accumulate == 2 in their launchers); ~240 five-microsecond
+// reduce launches per step collapse into this one.  table[e] = MultiReduceEntry, blk[b] = (entry, block index inside the entry).
+// Summation orders are those of reduce_slabs_flat_kernel (mode 0) and reduce_rows / reduce_slabs / dw_wgrad_reduce (mode 1), so the
+// result is bit-identical to the immediate path.
+int tuber_multi_reduce(const void* table, const void* blk, int nblocks, hipStream_t stream) {
+    if (nblocks <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(nblocks), dim3(1024), 0, stream, (const MultiReduceEntry*)table, (const int2*)blk);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_multi_reduce_entry_bytes() { return (int)sizeof(MultiReduceEntry); }
 
 }  // extern "C"

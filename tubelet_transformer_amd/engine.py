@@ -25,6 +25,76 @@ def _ceil(x, m):
     return (x + m - 1) // m * m
 
 
+class DeferredReduce:
+    """Second-stage reductions of the weight-gradient kernels, batched into ONE launch per backward pass.
+
+    The dW GEMMs, depthwise weight gradients, LayerNorm and bias gradients leave per-workgroup fp32 partials; reducing each right
+    away costs ~240 five-microsecond launches per step.  With ``accumulate = 2`` their launchers skip that stage; the partials stay
+    in this arena (bump-allocated, same addresses every step, so it is hipGraph-safe) and ``flush()`` reduces all of them with
+    ``tuber_multi_reduce`` -- same summation order as the immediate kernels, bit-identical gradients.  ``TUBER_IMMEDIATE_REDUCE=1``
+    restores the per-call reductions."""
+    CHUNK = 64 << 20             # floats per arena chunk (256 MB)
+    _ENTRY = np.dtype([("P", "<u8"), ("out", "<u8"), ("n", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("mode", "<i4"), ("C", "<i4"), ("pad", "<i4")])
+
+    def __init__(self, device):
+        self.device = device
+        self.enabled = not os.environ.get("TUBER_IMMEDIATE_REDUCE")
+        self.chunks, self.ci, self.off = [], 0, 0
+        self.entries, self.outs, self.cache = [], set(), {}
+
+    def reset(self):
+        """start of a step: the arena is reused from its first byte (nothing may be pending)."""
+        if self.entries:
+            self.flush()
+        self.ci, self.off = 0, 0
+
+    def alloc(self, n):
+        """device address of n fp32 of scratch that stays untouched until the next ``reset``."""
+        n = _ceil(int(n), ALIGN)
+        while True:
+            if self.ci < len(self.chunks):
+                c = self.chunks[self.ci]
+                if self.off + n <= c.numel():
+                    ptr = c.data_ptr() + 4 * self.off
+                    self.off += n
+                    return ptr
+                self.ci, self.off = self.ci + 1, 0
+                continue
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("deferred-reduce arena would grow during hipGraph capture (run an eager warm-up step first)")
+            self.chunks.append(torch.empty(max(self.CHUNK, n), dtype=torch.float32, device=self.device))
+
+    def add(self, part, out, n, stride, S, mode, C=0):
+        """out[j] += sum_{s<S} part[s*stride + j], j < n  (mode 0: element-wise, S ascending; mode 1: 32-way tree; C: depthwise layout)."""
+        if out in self.outs:             # a second contribution to the same gradient: keep the order of the immediate path
+            self.flush()
+        self.outs.add(out)
+        self.entries.append((int(part), int(out), int(n), int(stride), int(S), int(mode), int(C), 0))
+
+    def flush(self):
+        if not self.entries:
+            return
+        key = tuple(self.entries)
+        hit = self.cache.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("deferred-reduce table changed during hipGraph capture (the warm-up step ran a different sequence)")
+            if lib.query("tuber_multi_reduce_entry_bytes") != self._ENTRY.itemsize:
+                raise RuntimeError("MultiReduceEntry layout drift between engine.py and libtuber_hip.so")
+            tab = np.array(self.entries, dtype=self._ENTRY)
+            per = np.where(tab["mode"] == 0, (tab["n"] + 1023) // 1024, (tab["n"] + 31) // 32).astype(np.int64)
+            blk = np.empty((int(per.sum()), 2), np.int32)
+            blk[:, 0] = np.repeat(np.arange(len(tab), dtype=np.int32), per)
+            starts = np.concatenate([[0], np.cumsum(per)[:-1]])
+            blk[:, 1] = np.arange(len(blk), dtype=np.int64) - np.repeat(starts, per)
+            if len(self.cache) >= 512:       # eager DDP flushes once per bottleneck: ~60 tables per step, all reused
+                self.cache.clear()
+            hit = (torch.from_numpy(tab.view(np.uint8).copy()).to(self.device), torch.from_numpy(blk).to(self.device), len(blk))
+            self.cache[key] = hit
+        lib.call("tuber_multi_reduce", hit[0], hit[1], hit[2])
+        self.entries, self.outs = [], set()
+
+
 class ParamStore:
     def __init__(self, module, device):
         self.module = module
@@ -80,6 +150,7 @@ class ParamStore:
         self.side_stream, self._side_keep, self._side_dirty = None, [], False
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.defer = DeferredReduce(self.device)
 
     @staticmethod
     def _is_gemm_weight(name, p):
@@ -102,6 +173,13 @@ class ParamStore:
                 if p.grad is not None:
                     want.copy_(p.grad)
                 p.grad = want
+
+    def partial(self, key, numel, fallback):
+        """scratch for a weight-gradient kernel's partials -> (pointer or tensor, accumulate flag): arena + 2 when the second stage is
+        deferred to ``defer.flush()``, else ``fallback(key, numel)`` (the shared workspace) + 1."""
+        if self.defer.enabled:
+            return self.defer.alloc(numel), 2
+        return fallback(key, numel), 1
 
     def zero_grad(self):
         self.side_join()
@@ -138,6 +216,7 @@ class ParamStore:
     def begin_step(self, train):
         """new forward: call-site salts restart at 0; in training the device seed advances (captured in graphs)."""
         self.side_join()
+        self.defer.reset()
         self.step_seed = 0
         if train:
             self.seed.add_(1)

@@ -156,10 +156,17 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
             gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if bname else None
             fuse_b = bool(bname) and lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) == 1     # bias gradient inside the GEMM
-            lib.call("tuber_gemm_tn", gb, ldg, x, K, workspace(dev, "tn", S * N * K), gw, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
+            part, acc = st.partial("tn", S * N * K, lambda k, n: workspace(dev, k, n)) if S > 1 else (None, 1)
+            lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, acc, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
                      gbias if fuse_b else None)
+            if acc == 2:
+                st.defer.add(part, gw, N * K, N * K, S, 0 if S <= 16 else 1)
             if bname and not fuse_b:
-                lib.call("tuber_colsum", gb, workspace(dev, "cs", lib.query("tuber_colsum_blocks", M) * N), gbias, 1, M, N, ldg)
+                nbc = lib.query("tuber_colsum_blocks", M)
+                part, acc = st.partial("cs", nbc * N, lambda k, n: workspace(dev, k, n)) if nbc > 1 else (None, 1)
+                lib.call("tuber_colsum", gb, part, gbias, acc, M, N, ldg)
+                if acc == 2:
+                    st.defer.add(part, gbias, N, N, nbc, 1)
         # data gradient; accumulation with an existing gradient of x and the ReLU/Dropout mask of x are GEMM epilogues
         toff, _, _, ldt = st.tinfo[wname]
         wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
@@ -230,8 +237,14 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
         need_res = res is not None or p == 0.0
         dx = torch.empty(M, E, dtype=BF, device=dev) if need_res else None
         dxd = torch.empty(M, E, dtype=BF, device=dev) if p > 0.0 else None
-        lib.call("tuber_layernorm_bwd", gptr, ldg, xhat, rstd, gamma, dx, dxd, workspace(dev, "ln", 2 * nb * E), dgamma, dbeta, 1, M, E,
-                 p, st.seed, salt)
+        part, acc = st.partial("ln", 2 * nb * E, lambda k, n: workspace(dev, k, n))
+        lib.call("tuber_layernorm_bwd", gptr, ldg, xhat, rstd, gamma, dx, dxd, part, dgamma, dbeta, acc, M, E, p, st.seed, salt)
+        if acc == 2:
+            if dbeta == dgamma + 4 * E:
+                st.defer.add(part, dgamma, 2 * E, 2 * E, nb, 1)
+            else:
+                st.defer.add(part, dgamma, E, 2 * E, nb, 1)
+                st.defer.add(part + 4 * E, dbeta, E, 2 * E, nb, 1)
         tp.put(x, dxd if p > 0.0 else dx)
         if res is not None:
             tp.put(res, dx)
@@ -368,7 +381,10 @@ def param_rows(tp, name, B):
             else:
                 allg = gs[0]
             R = lib.query("tuber_colsum_blocks", n * B)
-            lib.call("tuber_colsum", allg, workspace(st.device, "cs", R * Q * E), gp, 1, n * B, Q * E, Q * E)
+            part, acc = st.partial("cs", R * Q * E, lambda k, m: workspace(st.device, k, m)) if R > 1 else (None, 1)
+            lib.call("tuber_colsum", allg, part, gp, acc, n * B, Q * E, Q * E)
+            if acc == 2:
+                st.defer.add(part, gp, Q * E, Q * E, R, 1)
         tp.rec(bwd)
     return out
 

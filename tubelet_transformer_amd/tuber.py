@@ -388,6 +388,7 @@ class _ModelFn(torch.autograd.Function):
         tp, outs = ctx.tp, ctx.outs
         seeds = [(o, g.contiguous().view(o.shape) if g is not None else None) for o, g in zip(outs, grads)]
         tp.backward(seeds)
+        tp.store.defer.flush()             # every deferred weight-gradient reduction of this pass, one launch
         ctx.tp = ctx.outs = None
         return None, None, None, None, None
 
