@@ -21,9 +21,9 @@ DOC = {
     "tuber_clip_desc_bytes": "sizeof(TuberClipDesc) as the library was compiled (host-side layout check).",
     "tuber_multi_reduce": "every deferred second-stage reduction of one backward pass in one launch: the weight-gradient launchers called with "
                           "accumulate = 2 (tuber_gemm_tn, tuber_dwconv_*_bwd_weight, tuber_colsum, tuber_layernorm_bwd) leave their partials in place; "
-                          "table = MultiReduceEntry[] {const float* P; float* out; long n, stride; int S, mode, C, pad}: out[j] += sum_s P[s*stride+j] "
-                          "(mode 0: per element, s ascending; mode 1: 32-way tree; C > 0: depthwise [S][27][C] -> [C][27]); blk = int2[] (entry, block in entry), "
-                          "1024 elements per block in mode 0, 32 in mode 1. Same summation order as the immediate kernels.",
+                          "table = MultiReduceEntry[] {const float* P; float* out; long n, stride; int S, mode, C, next}: out[j] += sum_s P[s*stride+j] "
+                          "(mode 0 / 2: per element / per float4, s ascending; mode 1: 32-way tree; C > 0: depthwise [S][27][C] -> [C][27]; next: chained contribution to the same out); blk = int2[] (head entry, block in entry), "
+                          "1024 / 4096 / 32 elements per block in mode 0 / 2 / 1. Same summation order as the immediate kernels.",
     "tuber_multi_reduce_entry_bytes": "sizeof(MultiReduceEntry) as compiled (host-side layout check).",
     "tuber_gemm_nt": "C[M,N] = f(A)[M,K] . B[N,K]^T on MFMA bf16. Replaces every nn.Conv3d(k=1) of the CSN bottlenecks "
                      "(models/backbones/ir_CSN_152.py:41,58,155-161), input_proj/class_proj (models/tuber_ava.py:57-58) and every "

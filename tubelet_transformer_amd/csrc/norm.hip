@@ -416,38 +416,70 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
 }
 
 // one entry of tuber_multi_reduce: out[j] += sum_{s<S} P[s*stride + j], j < n.
-//   mode 0: one thread per element, s ascending (few slabs);  mode 1: 32 slab groups x 32 elements per block, LDS tree;
-//   C > 0 (mode 1): P is [S][27][C] and the result goes to out[c*27 + tap] (depthwise weight gradient).
+//   mode 0: one thread per element (four when vec: n, stride % 4 == 0 and 16-byte aligned bases), s ascending (few slabs);
+//   mode 1: 32 slab groups x 32 elements per block, LDS tree;  C > 0 (mode 1): P is [S][27][C] and the result goes to out[c*27 + tap]
+//   (depthwise weight gradient).  next >= 0 chains a further contribution to the SAME out (a parameter used several times, e.g. the
+//   shared decoder norm): the chain is added in order by the same thread, so the result equals the sequence of immediate reductions.
 struct MultiReduceEntry {
     const float* P;
     float* out;
     long n, stride;
-    int S, mode, C, pad_;
+    int S, mode, C, next;
 };
 __global__ __launch_bounds__(1024) void multi_reduce_kernel(const MultiReduceEntry* __restrict__ table, const int2* __restrict__ blk) {
     __shared__ float red[32][33];
     const int2 be = blk[blockIdx.x];
-    const MultiReduceEntry e = table[be.x];
-    if (e.mode == 0) {
+    MultiReduceEntry e = table[be.x];
+    if (e.mode == 0) {                       // scalar: 1024 elements per block
         const long i = (long)be.y * 1024 + threadIdx.x;
         if (i >= e.n) return;
-        float a = 0.f;
-        for (int s = 0; s < e.S; ++s) a += e.P[(long)s * e.stride + i];
-        e.out[i] += a;
+        float o = e.out[i];
+        for (;;) {
+            float a = 0.f;
+            for (int s = 0; s < e.S; ++s) a += e.P[(long)s * e.stride + i];
+            o += a;
+            if (e.next < 0) break;
+            e = table[e.next];
+        }
+        e.out[i] = o;
+    } else if (e.mode == 2) {                // the same sums, four elements per thread: 4096 elements per block
+        const long i = ((long)be.y * 1024 + threadIdx.x) * 4;
+        if (i >= e.n) return;
+        float4 o = *(const float4*)(e.out + i);
+        for (;;) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int s = 0; s < e.S; ++s) {
+                const float4 v = *(const float4*)(e.P + (long)s * e.stride + i);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            if (e.next < 0) break;
+            e = table[e.next];
+        }
+        *(float4*)(e.out + i) = o;
     } else {
         const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
         const long j = (long)be.y * 32 + cl;
-        float a = 0.f;
-        if (j < e.n) for (int s = rg; s < e.S; s += 32) a += e.P[(long)s * e.stride + j];
-        red[rg][cl] = a;
-        __syncthreads();
-        if (rg == 0 && j < e.n) {
-            a = 0.f;
+        float o = 0.f;
+        float* op = nullptr;
+        if (rg == 0 && j < e.n) { op = e.C > 0 ? e.out + (j % e.C) * 27 + j / e.C : e.out + j; o = *op; }
+        for (;;) {
+            float a = 0.f;
+            if (j < e.n) for (int s = rg; s < e.S; s += 32) a += e.P[(long)s * e.stride + j];
+            red[rg][cl] = a;
+            __syncthreads();
+            if (rg == 0 && j < e.n) {
+                a = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) a += red[i][cl];
-            float* o = e.C > 0 ? e.out + (j % e.C) * 27 + j / e.C : e.out + j;
-            *o += a;
+                for (int i = 0; i < 32; ++i) a += red[i][cl];
+                o += a;
+            }
+            if (e.next < 0) break;
+            e = table[e.next];
+            __syncthreads();
         }
+        if (op) *op = o;
     }
 }
 

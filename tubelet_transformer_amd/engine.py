@@ -34,13 +34,13 @@ class DeferredReduce:
     ``tuber_multi_reduce`` -- same summation order as the immediate kernels, bit-identical gradients.  ``TUBER_IMMEDIATE_REDUCE=1``
     restores the per-call reductions."""
     CHUNK = 64 << 20             # floats per arena chunk (256 MB)
-    _ENTRY = np.dtype([("P", "<u8"), ("out", "<u8"), ("n", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("mode", "<i4"), ("C", "<i4"), ("pad", "<i4")])
+    _ENTRY = np.dtype([("P", "<u8"), ("out", "<u8"), ("n", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("mode", "<i4"), ("C", "<i4"), ("next", "<i4")])
 
     def __init__(self, device):
         self.device = device
         self.enabled = not os.environ.get("TUBER_IMMEDIATE_REDUCE")
         self.chunks, self.ci, self.off = [], 0, 0
-        self.entries, self.outs, self.cache = [], set(), {}
+        self.entries, self.outs, self.heads, self.cache = [], {}, [], {}
 
     def reset(self):
         """start of a step: the arena is reused from its first byte (nothing may be pending)."""
@@ -66,25 +66,42 @@ class DeferredReduce:
 
     def add(self, part, out, n, stride, S, mode, C=0):
         """out[j] += sum_{s<S} part[s*stride + j], j < n  (mode 0: element-wise, S ascending; mode 1: 32-way tree; C: depthwise layout)."""
-        if out in self.outs:             # a second contribution to the same gradient: keep the order of the immediate path
-            self.flush()
-        self.outs.add(out)
-        self.entries.append((int(part), int(out), int(n), int(stride), int(S), int(mode), int(C), 0))
+        part, out, n, stride = int(part), int(out), int(n), int(stride)
+        if mode == 0 and not ((n | stride) & 3) and not ((part | out) & 15):
+            mode = 2                     # same sums, float4 per thread
+        ent = [part, out, n, stride, int(S), int(mode), int(C), -1]
+        head = self.outs.get(out)
+        if head is not None:             # a further contribution to the same gradient (shared parameter): chain it, order preserved
+            h = self.entries[head]
+            if (h[2], h[5], h[6]) != (n, mode, int(C)):
+                self.flush()
+                head = None
+            else:
+                tail = head
+                while self.entries[tail][7] >= 0:
+                    tail = self.entries[tail][7]
+                self.entries[tail][7] = len(self.entries)
+        if head is None:
+            self.outs[out] = len(self.entries)
+            self.heads.append(len(self.entries))
+        self.entries.append(ent)
 
     def flush(self):
         if not self.entries:
             return
-        key = tuple(self.entries)
+        key = tuple(tuple(e) for e in self.entries)
         hit = self.cache.get(key)
         if hit is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("deferred-reduce table changed during hipGraph capture (the warm-up step ran a different sequence)")
             if lib.query("tuber_multi_reduce_entry_bytes") != self._ENTRY.itemsize:
                 raise RuntimeError("MultiReduceEntry layout drift between engine.py and libtuber_hip.so")
-            tab = np.array(self.entries, dtype=self._ENTRY)
-            per = np.where(tab["mode"] == 0, (tab["n"] + 1023) // 1024, (tab["n"] + 31) // 32).astype(np.int64)
+            tab = np.array(list(key), dtype=self._ENTRY)
+            heads = np.array(self.heads, dtype=np.int32)
+            ht = tab[heads]
+            per = np.where(ht["mode"] == 0, (ht["n"] + 1023) // 1024, np.where(ht["mode"] == 2, (ht["n"] + 4095) // 4096, (ht["n"] + 31) // 32)).astype(np.int64)
             blk = np.empty((int(per.sum()), 2), np.int32)
-            blk[:, 0] = np.repeat(np.arange(len(tab), dtype=np.int32), per)
+            blk[:, 0] = np.repeat(heads, per)
             starts = np.concatenate([[0], np.cumsum(per)[:-1]])
             blk[:, 1] = np.arange(len(blk), dtype=np.int64) - np.repeat(starts, per)
             if len(self.cache) >= 512:       # eager DDP flushes once per bottleneck: ~60 tables per step, all reused
@@ -92,7 +109,7 @@ class DeferredReduce:
             hit = (torch.from_numpy(tab.view(np.uint8).copy()).to(self.device), torch.from_numpy(blk).to(self.device), len(blk))
             self.cache[key] = hit
         lib.call("tuber_multi_reduce", hit[0], hit[1], hit[2])
-        self.entries, self.outs = [], set()
+        self.entries, self.outs, self.heads = [], {}, []
 
 
 class ParamStore:
