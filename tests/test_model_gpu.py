@@ -374,3 +374,69 @@ def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
     assert results[0][0] == results[1][0] and results[0][0] == results[0][0]
     assert torch.equal(results[0][2], results[1][2])
     assert torch.equal(results[0][1], results[1][1])
+
+
+# ------------------------------------------------------------------ BASELINE.json full size (CSN-152, 3x32x256x340) ----------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("yaml_name", ["TubeR_CSN152_AVA21.yaml", "TubeR_CSN152_AVA22.yaml"])
+def test_full_size_eval_forward_matches_oracle(dev, yaml_name):
+    """configs[1..3] of BASELINE.json at their real size: eval forward of one 3x32x256x340 clip through the HIP path against the fp32
+    CPU oracle run live on the box's host cores (a few seconds).  Same tolerances as the reference-golden cases: boxes 1e-2, logits 5e-2."""
+    from oracle import tuber_oracle as O
+    cfg, model, _, _ = build(yaml_name, dev)
+    clips = synth.synthetic_clips(1, 32, 256, 340, seed=1234)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        want = O.tuber_forward(state, cfg, clips, train=False)
+        got = model(clips.to(dev))
+    worst = {}
+    for k, v in flat_outputs(want).items():
+        g = flat_outputs(got)[k]
+        assert g.shape == v.shape and np.isfinite(g).all(), k
+        kind = k.split(".")[-1]
+        worst[kind] = max(worst.get(kind, 0.0), float(np.abs(g - v).max()))
+    print("%s full size: max abs err vs oracle %s" % (yaml_name, {k: "%.2e" % v for k, v in worst.items()}))
+    assert worst["pred_boxes"] <= 1e-2 and worst["pred_logits"] <= 5e-2 and worst["pred_logits_b"] <= 5e-2
+
+
+@pytest.mark.gpu
+def test_full_size_training_step_properties(dev):
+    """size-independent properties of the whole fwd+bwd at BASELINE size (2 clips of 3x32x256x340, CSN-152, dropout on):
+    (1) determinism: the same seed reproduces every gradient bit for bit;
+    (2) linearity of the backward pass: doubling every loss weight doubles every gradient EXACTLY (powers of two commute with bf16 /
+        fp32 rounding), which would break if any gradient buffer were read before being written or accumulated twice;
+    (3) batch equivariance in eval mode: swapping the two clips swaps the outputs bit for bit (no cross-sample leakage)."""
+    cfg, model, crit, _ = build("TubeR_CSN152_AVA21.yaml", dev, train=True)
+    for m in model.modules():                                   # dropout back on (build() zeroes it for the parity cases)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.1
+    store, _ = model.engine()
+    clips = synth.synthetic_clips(2, 32, 256, 340, seed=1234, device=dev)
+    targets = synth.synthetic_targets(2, "ava", 80, seed=4321, device=dev, hw=(256, 340))
+    bn_state = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def grads(scale):
+        model.load_state_dict(bn_state, strict=False)           # same BatchNorm buffers for every run
+        store.manual_seed(77)
+        store.zero_grad()
+        out = model(clips)
+        ld = crit(out, targets)
+        loss = sum(ld[k] * crit.weight_dict[k] * scale for k in ld if k in crit.weight_dict)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), store.gflat.detach().clone()
+
+    l1, g1 = grads(1.0)
+    l1b, g1b = grads(1.0)
+    l2, g2 = grads(2.0)
+    assert math.isfinite(l1) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    assert l1 == l1b and torch.equal(g1, g1b), "training step is not deterministic"
+    assert l2 == 2 * l1
+    assert torch.equal(g2, 2 * g1), "backward is not linear in the loss scale: %d elements differ" % int((g2 != 2 * g1).sum())
+    model.eval()
+    with torch.no_grad():
+        a = flat_outputs(model(clips))
+        b = flat_outputs(model(clips.flip(0)))
+    for k in a:
+        assert np.array_equal(a[k], b[k][::-1] if a[k].shape[0] == 2 else b[k]), k
