@@ -465,7 +465,37 @@ def test_gemm_tn_fused_bias_gradient(dev, M, N, K):
     lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, db)
     close("gemm_tn (+bias) dW", out - 1, G.float().t() @ A.float(), rel=4e-3)
     close("gemm_tn fused dbias", db - 1, G.float().sum(0), abs_=2e-3 * float(G.float().abs().sum(0).max()))
-    assert lib.query("tuber_gemm_tn_fuses_bias", 5632, 1024, 256, 1024, 256) == 0        # several slabs: separate colsum
+
+
+@pytest.mark.parametrize("M,N,K", [(5632, 1024, 256), (16896, 256, 256), (2816, 2048, 512)])
+def test_gemm_tn_fused_bias_gradient_multi_slab(dev, M, N, K):
+    """with several slabs the bias gradient leaves as one partial row per slab; reduced immediately (tuber_reduce_rows) or by the
+    deferred tuber_multi_reduce, the weight-gradient slabs likewise"""
+    assert lib.query("tuber_gemm_tn_fuses_bias", M, N, K, N, K) == 2
+    S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+    assert S > 1
+    G = rnd(M, N, dev=dev, seed=1).to(BF)
+    A = rnd(M, K, dev=dev, seed=2).to(BF)
+    ref_w, ref_b = G.float().t() @ A.float(), G.float().sum(0)
+    tol_b = 2e-3 * float(G.float().abs().sum(0).max())
+    # immediate
+    out, db = torch.ones(N, K, device=dev), torch.ones(N, device=dev)
+    part = torch.full((S * N * K,), float("nan"), device=dev)
+    bpart = torch.full((S * N,), float("nan"), device=dev)
+    lib.call("tuber_gemm_tn", G, N, A, K, part, out, 1, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, bpart)
+    lib.call("tuber_reduce_rows", bpart, db, S, N, 1)
+    close("gemm_tn multi-slab dW", out - 1, ref_w, rel=4e-3)
+    close("gemm_tn multi-slab fused dbias", db - 1, ref_b, abs_=tol_b)
+    # deferred: accumulate = 2 leaves the slabs, one tuber_multi_reduce launch finishes both gradients, bit-identically
+    from tubelet_transformer_amd.engine import DeferredReduce
+    d = DeferredReduce(dev)
+    out2, db2 = torch.ones(N, K, device=dev), torch.ones(N, device=dev)
+    p2, b2 = d.alloc(S * N * K), d.alloc(S * N)
+    lib.call("tuber_gemm_tn", G, N, A, K, p2, out2, 2, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, b2)
+    d.add(p2, out2.data_ptr(), N * K, N * K, S, 0 if S <= 16 else 1)
+    d.add(b2, db2.data_ptr(), N, N, S, 1)
+    d.flush()
+    assert torch.equal(out2, out) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("M,N,K,amode", [(5632, 1024, 256, 1), (700, 64, 192, 0), (44032, 128, 64, 0)])

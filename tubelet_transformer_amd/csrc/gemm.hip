@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
             ash[e] = k < p.K ? p.a_shift[k] : 0.f;
         }
     }
-    const bool do_bias = p.bias_grad != nullptr && tile_k == 0;       // host guarantees S == 1 then
+    const bool do_bias = p.bias_grad != nullptr && tile_k == 0;
     float bsum = 0.f;
     constexpr int GS = 4;
     uint4 rg[GS][2], ra[GS][2];
@@ -868,7 +868,11 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
         float* br = (float*)&smem[1][1][0];             // far end of the staging area (the tile below uses the first 17 KB)
         br[tid] = bsum;
         __syncthreads();
-        if (tid < 64 && n0 + tid < p.N) p.bias_grad[n0 + tid] += (br[tid] + br[64 + tid]) + (br[128 + tid] + br[192 + tid]);
+        if (tid < 64 && n0 + tid < p.N) {
+            const float v = (br[tid] + br[64 + tid]) + (br[128 + tid] + br[192 + tid]);
+            if (p.S == 1) p.bias_grad[n0 + tid] += v;                       // single slab: straight into the gradient
+            else p.bias_grad[(long)slab * p.N + n0 + tid] = v;              // bias_grad is a [S][N] partial, reduced by the caller
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -944,10 +948,14 @@ static int tn_rows_per_slab(int M, int N, int K) { return ceil_div(ceil_div(M, t
 // slabs actually written (rows per slab are rounded up to 64, so this can be fewer than the split aimed for)
 int tuber_gemm_tn_slabs(int M, int N, int K) { return ceil_div(M, tn_rows_per_slab(M, N, K)); }
 
-// 1 when tuber_gemm_tn can also accumulate the bias gradient dbias[n] += sum_m G[m][n] (single slab, transpose-read kernel)
+// Can tuber_gemm_tn also produce the bias gradient sum_m G[m][n] (transpose-read kernel, from the LDS image of G)?
+//   0: no;  1: yes, single slab: bias_grad[n] is accumulated directly;
+//   2: yes, S = tuber_gemm_tn_slabs > 1: bias_grad must point to S*N floats and receives one partial row per slab (reduce them with
+//      tuber_reduce_rows(bias_grad, dbias, S, N, 1) or a tuber_multi_reduce entry).
 int tuber_gemm_tn_fuses_bias(int M, int N, int K, long ldg, long lda) {
     if (getenv("TUBER_TN_REGISTER_TRANSPOSE")) return 0;
-    return tn_tile(N, K) == 64 && !((N | K | ldg | lda) & 7) && tuber_gemm_tn_slabs(M, N, K) == 1;
+    if (!(tn_tile(N, K) == 64 && !((N | K | ldg | lda) & 7))) return 0;
+    return tuber_gemm_tn_slabs(M, N, K) == 1 ? 1 : 2;
 }
 
 int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* partial, float* out, int accumulate,

@@ -39,7 +39,7 @@ DOC = {
     "tuber_gemm_nt_stat_rows": "rows of partial statistics tuber_gemm_nt(epi 1|2) writes for (M,N).",
     "tuber_gemm_tn": "dW[N,K] (+)= sum_m G[m,N]^T . f(A)[m,K]: weight gradient of the same convs / linears (autograd of the ops above); "
                      "split over M into fp32 slabs `partial` [tuber_gemm_tn_slabs][N][K], then reduced deterministically.",
-    "tuber_gemm_tn_fuses_bias": "1 when tuber_gemm_tn can also accumulate the bias gradient (its bias_grad argument) for this shape.",
+    "tuber_gemm_tn_fuses_bias": "can tuber_gemm_tn also produce the bias gradient for this shape: 0 no; 1 yes, accumulated into bias_grad[N] directly (single slab); 2 yes, bias_grad receives one partial row per slab ([tuber_gemm_tn_slabs][N], reduced by the caller).",
     "tuber_gemm_tn_slabs": "number of slabs (size of `partial` / (N*K)) tuber_gemm_tn uses.",
     "tuber_dwconv_fwd": "depthwise Conv3d(C,C,3,groups=C,stride=(st,ss,ss),padding=1) on NDHWC bf16, ResNeXtBottleneck.conv3 "
                         "(ir_CSN_152.py:48-51) with relu(bn1(.)) fused on load (sc/sh may be NULL) and bn3 partial statistics on store.",

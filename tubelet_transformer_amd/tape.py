@@ -155,15 +155,23 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
         with st.side(gb, x):               # weight / bias gradients feed nothing until the optimizer
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
             gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if bname else None
-            fuse_b = bool(bname) and lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) == 1     # bias gradient inside the GEMM
-            part, acc = st.partial("tn", S * N * K, lambda k, n: workspace(dev, k, n)) if S > 1 else (None, 1)
+            # bias gradient inside the GEMM: 1 = accumulated directly (single slab), 2 = one partial row per slab
+            fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) if bname else 0
+            ws = lambda k, n: workspace(dev, k, n)
+            part, acc = st.partial("tn", S * N * K, ws) if S > 1 else (None, 1)
+            bpart = st.partial("cs", S * N, ws)[0] if fuse_b == 2 else None
             lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, acc, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
-                     gbias if fuse_b else None)
+                     gbias if fuse_b == 1 else bpart)
             if acc == 2:
                 st.defer.add(part, gw, N * K, N * K, S, 0 if S <= 16 else 1)
-            if bname and not fuse_b:
+            if fuse_b == 2:
+                if acc == 2:
+                    st.defer.add(bpart, gbias, N, N, S, 1)
+                else:
+                    lib.call("tuber_reduce_rows", bpart, gbias, S, N, 1)
+            elif bname and not fuse_b:
                 nbc = lib.query("tuber_colsum_blocks", M)
-                part, acc = st.partial("cs", nbc * N, lambda k, n: workspace(dev, k, n)) if nbc > 1 else (None, 1)
+                part, acc = st.partial("cs", nbc * N, ws) if nbc > 1 else (None, 1)
                 lib.call("tuber_colsum", gb, part, gbias, acc, M, N, ldg)
                 if acc == 2:
                     st.defer.add(part, gbias, N, N, nbc, 1)
