@@ -301,6 +301,17 @@ def test_bn_finalize_and_bwd(dev):
     dx = torch.empty(M, C, device=dev, dtype=BF)
     lib.call("tuber_bn_bwd_apply", dzb, xb, cA, cB, cC, dx, M, C)
     close("bn bwd apply kernel", dx, cA * dzb.float() + cB * xb.float() + cC)
+    if C % 32 == 0:      # finalize + apply in one launch (short partial lists): bit-identical to the pair, also when accumulating
+        for accumulate in (0, 1):
+            ref = [torch.full((C,), 0.5, device=dev) for _ in range(5)]
+            lib.call("tuber_bn_bwd_finalize", b0, b1, R, C, float(M), gamma, mean, invstd, *ref, accumulate)
+            dx_ref = torch.empty(M, C, device=dev, dtype=BF)
+            lib.call("tuber_bn_bwd_apply", dzb, xb, ref[0], ref[1], ref[2], dx_ref, M, C)
+            got = [torch.full((C,), 0.5, device=dev) for _ in range(5)]
+            dx2 = torch.full((M, C), float("nan"), device=dev, dtype=BF)
+            lib.call("tuber_bn_bwd_fused", b0, b1, R, C, float(M), gamma, mean, invstd, *got, accumulate, dzb, xb, dx2, M)
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), "fused BN backward coefficients differ"
+            assert torch.equal(dx2, dx_ref), "fused BN backward apply differs"
     sc2, sh2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
     lib.call("tuber_bn_eval_affine", gamma, beta, rm, rv, 1e-3, sc2, sh2, C)
     close("bn eval affine", x * sc2 + sh2, F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-3), rel=1e-5)

@@ -21,6 +21,9 @@ from torch import nn
 from . import lib
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
+# measured on MI355X: one fused finalize+apply launch per layer3/4 BatchNorm (R <= 128) is 0.5 ms/step SLOWER than the two launches
+# (1024-thread workgroups on 64-byte row segments, coefficients re-derived by every row chunk) -- off; A/B with the env variable
+BN_FUSED_MAX_ROWS = int(os.environ.get("TUBER_BN_FUSED_MAX_ROWS", "0"))
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -286,9 +289,14 @@ class CSNRunner:
         7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
         not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
         st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
+        dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
+        if R <= BN_FUSED_MAX_ROWS and bn.C % 32 == 0:
+            # short statistics lists (layer3 / layer4): every workgroup of the apply re-derives its channels' coefficients -- one launch
+            lib.call("tuber_bn_bwd_fused", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
+                     bn.dgamma, bn.dbeta, 1, dz, x, dx, M)
+            return dx
         lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
                  bn.dgamma, bn.dbeta, 1)
-        dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
         lib.call("tuber_bn_bwd_apply", dz, x, bn.cA, bn.cB, bn.cC, dx, M, bn.C)
         return dx
 

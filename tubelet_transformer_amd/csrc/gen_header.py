@@ -61,6 +61,7 @@ DOC = {
     "tuber_stat_rows_reduced": "rows left by tuber_stat_rows_reduce (R itself when no first stage is needed).",
     "tuber_bn_eval_affine": "eval-mode BatchNorm3d folded to scale/shift from the running statistics.",
     "tuber_bn_bwd_finalize": "BatchNorm backward coefficients: dx = cA*dz + cB*x + cC, dgamma = sum dz*xhat, dbeta = sum dz.",
+    "tuber_bn_bwd_fused": "tuber_bn_bwd_finalize + tuber_bn_bwd_apply in one launch for short partial lists (R <= 128: layer3 / layer4), bit-identical to the pair.",
     "tuber_bn_bwd_apply": "dx = cA*dz + cB*x + cC (BatchNorm backward apply), bf16 [M,C].",
     "tuber_block_out_fwd": "bottleneck join y = relu(bn4(c4) + shortcut) (ir_CSN_152.py:81-90); shortcut = res or bn_ds(res) when rs/rh given.",
     "tuber_block_out_bwd": "backward of the join: dz = dy*[y>0] and the partial statistics of bn4 (and of the down_sample BN).",
