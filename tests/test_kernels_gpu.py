@@ -746,3 +746,26 @@ def test_elementwise(dev):
     from oracle import tuber_oracle as O
     ref = O.position_embedding_sine_3d(mask.cpu(), 256).permute(0, 2, 3, 4, 1).reshape(-1, 256).to(dev)
     close("posenc", pos, ref, abs_=1e-2)
+
+
+@pytest.mark.parametrize("B,T,hw,E", [(2, 4, 352, 2048), (3, 5, 7, 64)])
+def test_temporal_max_pool(dev, B, T, hw, E):
+    """TEMPORAL_DS_STRATEGY 'max' (backbone_builder.py:45-47,73): forward = nn.MaxPool3d((T,1,1)) exactly (bf16 values, ties are frequent
+    and must go to the earliest frame like torch), backward routes the gradient to that frame"""
+    x = (rnd(B, T, hw, E, dev=dev, seed=1) * 2).to(BF)
+    x[0, :, 0, :8] = 1.0                                        # a full tie
+    out = torch.empty(B * hw, E, device=dev, dtype=BF)
+    arg = torch.empty(B * hw, E, device=dev, dtype=torch.uint8)
+    lib.call("tuber_temporal_max_fwd", x, out, arg, B, T, hw, E)
+    xr = x.float().permute(0, 3, 1, 2).reshape(B, E, T, hw, 1).requires_grad_(True)
+    ref, idx = F.max_pool3d(xr, (T, 1, 1), return_indices=True)
+    assert torch.equal(out.view(B, hw, E).float(), ref.reshape(B, E, hw).permute(0, 2, 1))
+    assert torch.equal(arg.view(B, hw, E).long(), (idx.reshape(B, E, hw) // hw).permute(0, 2, 1))
+    g = rnd(B * hw, E, dev=dev, seed=2).to(BF)
+    dx = torch.full((B, T, hw, E), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_temporal_max_bwd", g, arg, dx, B, T, hw, E)
+    ref.backward(g.float().view(B, hw, E).permute(0, 2, 1).reshape(B, E, 1, hw, 1))
+    assert torch.equal(dx.float(), xr.grad.reshape(B, E, T, hw).permute(0, 2, 3, 1))
+    out2 = torch.empty_like(out)
+    lib.call("tuber_temporal_max_fwd", x, out2, None, B, T, hw, E)     # eval: no argmax
+    assert torch.equal(out2, out)

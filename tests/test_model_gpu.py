@@ -440,3 +440,35 @@ def test_full_size_training_step_properties(dev):
         b = flat_outputs(model(clips.flip(0)))
     for k in a:
         assert np.array_equal(a[k], b[k][::-1] if a[k].shape[0] == 2 else b[k]), k
+
+
+@pytest.mark.gpu
+def test_temporal_ds_strategy_max_matches_oracle(dev):
+    """the fourth branch of Backbone.forward (backbone_builder.py:45-47,73; no published config uses it): eval forward against the
+    oracle, and a training step whose stem gradient arrives through the max-pool routing"""
+    from oracle import tuber_oracle as O
+    cfg = load_cfg(os.path.join(ROOT, "configuration", "TubeR_CSN152_AVA21.yaml"))
+    cfg.CONFIG.MODEL.TEMPORAL_DS_STRATEGY = "max"
+    cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+    model, crit, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    synth.zero_dropout(model)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    crit.to(dev)
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=5)
+    with torch.no_grad():
+        want = flat_outputs(O.tuber_forward(state, cfg, clips, train=False))
+        got = flat_outputs(model(clips.to(dev)))
+    for k, v in want.items():
+        tol = 1e-2 if k.endswith("pred_boxes") else 5e-2
+        assert np.abs(got[k] - v).max() <= tol, (k, float(np.abs(got[k] - v).max()))
+    model.train()
+    crit.train()
+    store, _ = model.engine()
+    store.zero_grad()
+    targets = synth.synthetic_targets(2, "ava", 80, seed=6, device=dev, hw=(64, 96))
+    ld = crit(model(clips.to(dev)), targets)
+    sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict).backward()
+    g = model.backbone.body.conv1.weight.grad
+    assert bool(torch.isfinite(store.gflat).all()) and float(g.abs().max()) > 0

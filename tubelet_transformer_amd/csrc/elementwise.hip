@@ -53,6 +53,63 @@ __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16* __rest
     }
 }
 
+// temporal max pool over all T frames: out[(b,p)][e] = max_t x[(b,t,p)][e], arg = first t that attains it (nn.MaxPool3d((T,1,1)),
+// models/backbone_builder.py:45-47,73); backward routes the gradient to that frame only.  8 channels per thread.
+__global__ __launch_bounds__(256) void temporal_max_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, uint8_t* __restrict__ arg,
+                                                               int B, int T, long hw, int E) {
+    const int epr = E >> 3;
+    const long total = (long)B * hw * epr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % epr);
+        const long r = i / epr;
+        const long pos = r % hw, b = r / hw;
+        float best[8];
+        uint8_t at[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; at[e] = 0; }
+        for (int t = 0; t < T; ++t) {
+            const bf16x8 v = as_bf16x8(*(const uint4*)(x + (((long)b * T + t) * hw + pos) * E + ch * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[e]);
+                if (f > best[e] || (t == 0)) { best[e] = f; at[e] = (uint8_t)t; }      // strict >: ties keep the earliest frame (NaN-free data)
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(best[e]);
+        *(uint4*)(out + r * E + ch * 8) = as_uint4(o);
+        if (arg) {
+            uint2 a;
+            a.x = at[0] | (at[1] << 8) | (at[2] << 16) | ((uint32_t)at[3] << 24);
+            a.y = at[4] | (at[5] << 8) | (at[6] << 16) | ((uint32_t)at[7] << 24);
+            *(uint2*)(arg + r * E + ch * 8) = a;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void temporal_max_bwd_kernel(const bf16* __restrict__ g, const uint8_t* __restrict__ arg, bf16* __restrict__ dx,
+                                                               int B, int T, long hw, int E) {
+    const int epr = E >> 3;
+    const long total = (long)B * T * hw * epr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % epr);
+        long r = i / epr;
+        const long pos = r % hw; r /= hw;
+        const int t = (int)(r % T);
+        const long b = r / T;
+        const long orow = b * hw + pos;
+        const bf16x8 gv = as_bf16x8(*(const uint4*)(g + orow * E + ch * 8));
+        const uint2 a = *(const uint2*)(arg + orow * E + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t at = ((e < 4 ? a.x : a.y) >> (8 * (e & 3))) & 255u;
+            o[e] = at == (uint32_t)t ? gv[e] : f2bf(0.f);
+        }
+        *(uint4*)(dx + ((b * T + t) * hw + pos) * E + ch * 8) = as_uint4(o);
+    }
+}
+
 // out = alpha*a + beta*b   (bf16, n % 8 == 0)
 __global__ void axpby_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, long n8, float alpha, float beta) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -200,6 +257,18 @@ int tuber_rows_gather_sum(const void* in, void* out, int A, int B, int C, int D,
     if (E & 7) return TUBER_EINVAL;
     hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(grid1((long)A * B * C * (E / 8))), dim3(256), 0, stream, (const bf16*)in, (bf16*)out,
                        A, B, C, D, sa, sb, sc, sd, E, mul);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_temporal_max_fwd(const void* x, void* out, void* arg, int B, int T, long hw, int E, hipStream_t stream) {
+    if ((E & 7) || T <= 0 || T > 255) return TUBER_EINVAL;
+    hipLaunchKernelGGL(temporal_max_fwd_kernel, dim3(grid1((long)B * hw * (E / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)out,
+                       (uint8_t*)arg, B, T, hw, E);
+    TUBER_RETURN_LAUNCH();
+}
+int tuber_temporal_max_bwd(const void* g, const void* arg, void* dx, int B, int T, long hw, int E, hipStream_t stream) {
+    if ((E & 7) || T <= 0 || T > 255) return TUBER_EINVAL;
+    hipLaunchKernelGGL(temporal_max_bwd_kernel, dim3(grid1((long)B * T * hw * (E / 8))), dim3(256), 0, stream, (const bf16*)g,
+                       (const uint8_t*)arg, (bf16*)dx, B, T, hw, E);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_axpby(const void* a, const void* b, void* out, long n, float alpha, float beta, hipStream_t stream) {

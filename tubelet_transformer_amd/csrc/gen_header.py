@@ -25,6 +25,9 @@ DOC = {
                           "(mode 0 / 2: per element / per float4, s ascending; mode 1: 32-way tree; C > 0: depthwise [S][27][C] -> [C][27]; next: chained contribution to the same out); blk = int2[] (head entry, block in entry), "
                           "1024 / 4096 / 32 elements per block in mode 0 / 2 / 1. Same summation order as the immediate kernels.",
     "tuber_multi_reduce_entry_bytes": "sizeof(MultiReduceEntry) as compiled (host-side layout check).",
+    "tuber_temporal_max_fwd": "nn.MaxPool3d((T,1,1)) over the T frames of the backbone features, TEMPORAL_DS_STRATEGY 'max' (models/backbone_builder.py:45-47,73): "
+                              "rows (b,t,p) of E bf16 -> rows (b,p) + the uint8 index of the first maximal frame (arg may be NULL in eval).",
+    "tuber_temporal_max_bwd": "backward of tuber_temporal_max_fwd: the gradient goes to the frame that held the maximum, zeros elsewhere.",
     "tuber_gemm_nt": "C[M,N] = f(A)[M,K] . B[N,K]^T on MFMA bf16. Replaces every nn.Conv3d(k=1) of the CSN bottlenecks "
                      "(models/backbones/ir_CSN_152.py:41,58,155-161), input_proj/class_proj (models/tuber_ava.py:57-58) and every "
                      "nn.Linear / packed in-projection (models/transformer/transformer.py:159-165,227-245; transformer_layers.py:81-94; "

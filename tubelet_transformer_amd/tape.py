@@ -433,6 +433,24 @@ def sigmoid(tp, x):
     return y
 
 
+def temporal_max(tp, feat, B, Tp, hw):
+    """feat rows (b,t,hw) -> rows (b,hw): max over the T' frames, nn.MaxPool3d((T',1,1)) (backbone_builder.py:45-47,73)."""
+    C = feat.shape[1]
+    out = torch.empty(B * hw, C, dtype=BF, device=feat.device)
+    arg = torch.empty(B * hw, C, dtype=torch.uint8, device=feat.device) if tp.train else None
+    lib.call("tuber_temporal_max_fwd", feat, out, arg, B, Tp, hw, C)
+    if tp.train:
+        def bwd():
+            g = tp.take(out)
+            if g is None:
+                return
+            d = torch.empty_like(feat)
+            lib.call("tuber_temporal_max_bwd", g.contiguous(), arg, d, B, Tp, hw, C)
+            tp.put(feat, d)
+        tp.rec(bwd)
+    return out
+
+
 def mid_frame(tp, feat, B, Tp, hw):
     """feat rows (b,t,hw) -> rows (b,hw) of the middle frame (backbone_builder.py:79-80); plain torch indexing (JHMDB only)."""
     C = feat.shape[1]

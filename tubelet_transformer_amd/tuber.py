@@ -269,7 +269,9 @@ class DETR(nn.Module):
         elif strat == "decode":
             xs = self._lstr_pool(tp, feat, B, Tp, hw, on)
         elif strat == "max":
-            raise NotImplementedError("TEMPORAL_DS_STRATEGY 'max' is not used by any published config")
+            if Tp != self.backbone.pool_len:
+                raise ValueError("TEMPORAL_DS_STRATEGY 'max' needs T/8 == TEMP_LEN/DS_RATE (got %d vs %d)" % (Tp, self.backbone.pool_len))
+            xs = T.temporal_max(tp, feat, B, Tp, hw)
         else:                                   # mid-frame slice (backbone_builder.py:79-80)
             xs = T.mid_frame(tp, feat, B, Tp, hw)
         m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]          # [B,h,w] (backbone_builder.py:85)
