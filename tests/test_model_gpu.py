@@ -472,3 +472,24 @@ def test_temporal_ds_strategy_max_matches_oracle(dev):
     sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict).backward()
     g = model.backbone.body.conv1.weight.grad
     assert bool(torch.isfinite(store.gflat).all()) and float(g.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_captures_the_graph_step(tmp_path):
+    """N > 1 launch path of bench.py on a one-GPU box: two ranks share cuda:0 and all-reduce over gloo (TUBER_SHARE_GPU).  Checks the
+    contract line and that the DDP step really runs from the captured hipGraph -- the eager warm-up (reducer hooks attached) and the
+    captured backward order their deferred reductions differently, which once made the capture fall back to eager launches."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, TUBER_SHARE_GPU="1", TUBER_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "64",
+           "--width", "96", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "capture failed" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["launch_mode"] == "hipgraph" and j["config"]["global_batch"] == 4
+    assert j["value"] > 0 and math.isfinite(j["final_loss"])

@@ -94,6 +94,15 @@ class GraphedTrainStep:
             train_step(model, crit, opt, NestedTensor(g.clips, g.mask), targets, self.max_norm)
         torch.cuda.synchronize()
         store.reducer = None
+        if red is not None:
+            # the eager reducer made the backward flush its deferred reductions once per bottleneck; the captured backward flushes
+            # twice.  One forward + backward WITHOUT the reducer (no optimizer step: ranks stay in sync) builds those reduce tables now,
+            # because nothing can be uploaded during the capture.
+            ld = crit(model(NestedTensor(g.clips, g.mask)), targets)
+            opt.zero_grad()
+            crit.weighted_total(ld).backward()
+            store.side_join()
+            torch.cuda.synchronize()
         # With the assignment on the device (tuber_lsap_device) the whole step is ONE graph: refresh, forward, matching cost,
         # assignment, fused criterion, backward, clip + AdamW -- no device->host round trip.  (DDP: the optimizer is a second
         # graph behind the eager RCCL all-reduce.  Problems beyond the device solver's 128 x 128 bound use graph A / host / B.)
