@@ -740,11 +740,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 // above runs.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-#define TNP 72               // LDS row pitch in bf16 (144 B): the 4 rows of a transposed block fall on disjoint bank ranges
+#define TNP 64               // LDS row pitch in bf16: 128 B, no padding; 32-byte units XOR-swizzled by tn2_key(row)
+// Bank map (64 banks x 4 B = 256 B per cycle).  16-byte stores: 16 lanes cover rows 2j, 2j+1 = one full 256 B line for any permutation
+// inside a row.  Transposed reads (ds_read_b64_tr_b16): a 32-lane pass reads rows {r..r+3} and {r+8..r+11} (r % 8 in {0, 4}), one 32-B
+// unit each; rows r, r+1 sit in different halves of a line, and the unit index is XORed with a 2-bit key that differs between the row
+// pairs (r, r+1), (r+2, r+3), (r+8, r+9), (r+10, r+11), so the eight 32-B pieces cover all 64 banks exactly once.
+__device__ __forceinline__ int tn2_key(int row) { return ((row >> 1) & 1) | ((row >> 2) & 2); }
+__device__ __forceinline__ int tn2_off(int row, int col) { return row * TNP + ((((col >> 4) ^ tn2_key(row)) << 4) | (col & 15)); }
 
 __device__ __forceinline__ bf16x8 tn2_frag(const bf16* img, int m0, int col0, int li) {
     // rows m0 .. m0+7 (two [4][16] blocks), columns col0 .. col0+15; lane li of the group gets 8 consecutive m of column col0+li
-    const bf16* p = img + (m0 + (li >> 2)) * TNP + col0 + (li & 3) * 4;
+    const bf16* p = img + tn2_off(m0 + (li >> 2), col0 + (li & 3) * 4);          // row + 4 has the same key (m0 % 8 == 0)
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * TNP));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -813,8 +819,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), asc[e], ash[e]), 0.f));
                 av = (ok[h] && a_col_ok) ? as_uint4(y) : make_uint4(0, 0, 0, 0);      // rows / columns outside contribute zero
             }
-            *(uint4*)&smem[buf][0][(r + 32 * h) * TNP + c * 8] = xg[h];
-            *(uint4*)&smem[buf][1][(r + 32 * h) * TNP + c * 8] = av;
+            *(uint4*)&smem[buf][0][tn2_off(r + 32 * h, c * 8)] = xg[h];
+            *(uint4*)&smem[buf][1][tn2_off(r + 32 * h, c * 8)] = av;
         }
     };
 
@@ -838,9 +844,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
             const bf16* gi = smem[buf][0];
             const bf16* ai = smem[buf][1];
             if (do_bias) {                          // column sums of this step's G rows: thread = (column, 16-row part)
-                const bf16* col = gi + (tid >> 6) * 16 * TNP + (tid & 63);
 #pragma unroll
-                for (int mm = 0; mm < 16; ++mm) bsum += bf2f(col[mm * TNP]);
+                for (int mm = 0; mm < 16; ++mm) bsum += bf2f(gi[tn2_off((tid >> 6) * 16 + mm, tid & 63)]);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
