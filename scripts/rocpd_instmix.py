@@ -19,7 +19,7 @@ def load(path):
          "join %s d on e.event_id = d.event_id join %s s on d.kernel_id = s.id group by s.%s, p.name" % (namecol, pe, ip, kd, ks, namecol))
     out = collections.defaultdict(dict)
     for name, ctr, n, v, dur in cur.execute(q):
-        name = re.sub(r"\s+", " ", name).split("(")[0].replace("void ", "")
+        name = re.sub(r"\s+", " ", name).replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         out[name][ctr] = (n, v, dur)
     return out
 
@@ -42,5 +42,5 @@ for k, d in a.items():
                  valu / mfma if mfma else float("nan"), conf / act if act else float("nan")))
 print("# wave-instructions per launch, averaged over the launches of the run (one warm-up + capture + one replay of the BASELINE step)")
 print("%-58s %6s %10s %9s %9s %9s %9s %9s %9s %8s" % ("kernel", "calls", "VALU", "MFMA", "LDS", "SALU", "VMEM_RD", "VMEM_WR", "VALU/MFMA", "LDSconf"))
-for dur, k, n, valu, mfma, lds, salu, rd, wr, ratio, cf in sorted(rows, reverse=True)[:32]:
+for dur, k, n, valu, mfma, lds, salu, rd, wr, ratio, cf in sorted(rows, reverse=True)[:60]:
     print("%-58s %6d %10.0f %9.0f %9.0f %9.0f %9.0f %9.0f %9.1f %8.3f" % (k[:58], n, valu, mfma, lds, salu, rd, wr, ratio, cf))
