@@ -15,7 +15,7 @@
 #include "common.h"
 
 #define SW 64
-#define PXW 136
+#define PXW 160         // row pitch 80 dwords = 16 mod 32: the four run rows of a fragment read (ds_read_b32: 32 banks, 32-lane groups) fall on disjoint banks (136 pixels used)
 #define KP 512
 
 struct StemGeom { int B, T, H, W, Ho, Wo, tilesW, ntiles; };
