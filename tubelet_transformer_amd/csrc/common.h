@@ -72,7 +72,12 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    // keep iff hash >= thresh, thresh = p * 2^32
-    uint32_t h = hash_u32((uint32_t)idx ^ hash_u32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
+    // keep iff hash >= thresh, thresh = p * 2^32.  The inner hash depends on the seed and the HIGH word of the index only: for the
+    // first 2^32 elements of a tensor (all of them, in this model) it is loop-invariant and hoisted; the branch keeps the stream defined
+    // for larger tensors without paying a second hash per element.
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    uint32_t inner = hash_u32((uint32_t)seed);
+    if (__builtin_expect(hi != 0, 0)) inner = hash_u32(hi + (uint32_t)seed);
+    const uint32_t h = hash_u32((uint32_t)idx ^ inner ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
     return h >= thresh;
 }
