@@ -160,6 +160,7 @@ class CSNRunner:
                      "ds": blk.down_sample is not None}
                 d["off0"] = store.offsets[p + "conv1.weight"]
                 d["stage"], d["first"] = li, bi == 0
+                d["mod"] = blk
                 d["w1"], _, d["g1"] = wptr(p + "conv1.weight")
                 d["w1t"], d["ld1t"] = tptr(p + "conv1.weight")
                 _, d["w3"], d["g3"] = wptr(p + "conv3.weight")
@@ -282,21 +283,58 @@ class CSNRunner:
         feat = x.view(B, Ti, Hi, Wi, 2048)
         return feat, saved
 
+    # -- trainability (requires_grad) ---------------------------------------------------------------------
+    # The reference freezes by ``requires_grad = False`` (pretrained recipe: stem + layer1 + layer2, ir_CSN_152.py:251-254,301-303;
+    # LR_BACKBONE <= 0: the whole body, backbone_builder.py:38-40) and autograd then neither computes those gradients nor walks the
+    # graph below the first trainable tensor.  Same here: weight-gradient kernels and dgamma/dbeta of frozen tensors are not
+    # launched / written (their slices of the flat gradient buffer stay zero, ``p.grad`` is None) and the data-gradient chain stops
+    # at the lowest block that still has a trainable tensor.  BatchNorm keeps using batch statistics and updating its running
+    # buffers in train mode, as the reference's frozen-but-train-mode BatchNorm3d does.
+    def trainable_plan(self):
+        """([per-block flag dicts], stem flags, index of the lowest block whose backward must run (len(blocks) = none),
+        stem backward needed).  Read from ``requires_grad`` on every call: freezing may change between steps."""
+        plans = []
+        for d in self.blocks:
+            m = d["mod"]
+            f = {"w1": m.conv1.weight.requires_grad, "w3": m.conv3.weight.requires_grad, "w4": m.conv4.weight.requires_grad,
+                 "bn1": m.bn1.weight.requires_grad or m.bn1.bias.requires_grad,
+                 "bn3": m.bn3.weight.requires_grad or m.bn3.bias.requires_grad,
+                 "bn4": m.bn4.weight.requires_grad or m.bn4.bias.requires_grad}
+            if d["ds"]:
+                f["wd"] = m.down_sample[0].weight.requires_grad
+                f["bnd"] = m.down_sample[1].weight.requires_grad or m.down_sample[1].bias.requires_grad
+            f["any"] = any(f.values())
+            plans.append(f)
+        b = self.body
+        stem = {"w": b.conv1.weight.requires_grad, "bn": b.bn1.weight.requires_grad or b.bn1.bias.requires_grad}
+        stem["any"] = stem["w"] or stem["bn"]
+        lowest = len(self.blocks)
+        if stem["any"]:
+            lowest = 0
+        else:
+            for i, f in enumerate(plans):
+                if f["any"]:
+                    lowest = i
+                    break
+        return plans, stem, lowest
+
+    def any_trainable(self):
+        plans, stem, lowest = self.trainable_plan()
+        return stem["any"] or lowest < len(self.blocks)
+
     # -- backward -------------------------------------------------------------------------------------
-    def _bn_bwd(self, bn, st0, st1, R, count, dz, x, M):
-        """finalize coefficients (+ dgamma/dbeta into the flat grads) and apply: returns dx tensor [M, C].
+    def _bn_bwd(self, bn, st0, st1, R, count, dz, x, M, train=True, apply=True):
+        """finalize coefficients (+ dgamma/dbeta into the flat grads when the layer is trainable) and apply: returns dx tensor [M, C]
+        (None when ``apply`` is off: only dgamma/dbeta were wanted).
         (Forming dx inside the consuming GEMMs instead -- tuber_gemm_nt amode 2 / tuber_gemm_tn G2 -- removes this kernel and
         7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
         not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
         st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
-        dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
-        if R <= BN_FUSED_MAX_ROWS and bn.C % 32 == 0:
-            # short statistics lists (layer3 / layer4): every workgroup of the apply re-derives its channels' coefficients -- one launch
-            lib.call("tuber_bn_bwd_fused", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
-                     bn.dgamma, bn.dbeta, 1, dz, x, dx, M)
-            return dx
         lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
-                 bn.dgamma, bn.dbeta, 1)
+                 bn.dgamma if train else None, bn.dbeta if train else None, 1)
+        if not apply:
+            return None
+        dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
         lib.call("tuber_bn_bwd_apply", dz, x, bn.cA, bn.cB, bn.cC, dx, M, bn.C)
         return dx
 
@@ -309,41 +347,53 @@ class CSNRunner:
             self.store.defer.add(part, out if isinstance(out, int) else out.data_ptr(), N * K, N * K, S, 0 if S <= 16 else 1)
 
     def backward(self, saved, dfeat):
-        """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients are
-        accumulated into the ParamStore's flat gradient buffer."""
+        """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients of the TRAINABLE tensors are
+        accumulated into the ParamStore's flat gradient buffer; the chain stops at the lowest block with a trainable tensor."""
         dev = self.dev
         dy = dfeat
         B = saved["stem"][4][0]
         red = getattr(self.store, "reducer", None)
+        plans, stem_plan, lowest = self.trainable_plan()
         if red is not None:           # everything behind the body (transformer, heads, pool decoder) is final
-            self.store.side_join()
             red.notify(self.body_end, force=True)
-        for d, sv in zip(reversed(self.blocks), reversed(saved["blocks"])):
+        nblk = len(self.blocks)
+        for bi in range(nblk - 1, lowest - 1, -1):
+            d, sv, f = self.blocks[bi], saved["blocks"][bi], plans[bi]
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             C4 = 4 * P
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
+            need_dx = stem_plan["any"] or bi > lowest
+            # how deep the chain inside this block has to go: 7 = input gradient, 6 = conv1 weight, 5 = bn1, 4 = conv3 weight,
+            # 3 = bn3, 2 = conv4 weight, 1 = bn4 / shortcut only
+            depth = 7 if need_dx else (6 if f["w1"] else 5 if f["bn1"] else 4 if f["w3"] else 3 if f["bn3"] else 2 if f["w4"] else 1)
             # join backward: dz + stats of bn4 (and the shortcut BN)
             R = lib.query("tuber_rowblock_count", Mout, C4)
             sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
             dz = torch.empty(Mout, C4, dtype=BF, device=dev)
             lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
-            dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout)
-            dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout) if d["ds"] else None
+            dc4 = None
+            if depth >= 2 or f["bn4"]:
+                dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2)
+            dcd = None
+            if d["ds"] and (need_dx or f["wd"] or f["bnd"]):
+                dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=need_dx or f["wd"])
             # conv4: weight grad (A = relu(bn3(c3)) recomputed on load) and data grad fused with relu/bn3 backward
-            with self.store.side(dc4, c3):
+            if f["w4"]:
                 self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
-            R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
-            s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
-            dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
-            lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
-            dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout)
+            dc3 = None
+            if depth >= 3:
+                R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
+                s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
+                dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
+                lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                         2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
+                dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
-            nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
-            with self.store.side(dc3, c1):
+            if f["w3"]:
+                nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
                 if tile:
                     lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B, Ti, Hi, Wi, P)
@@ -353,51 +403,50 @@ class CSNRunner:
                 if acc == 2:
                     g3 = d["g3"]
                     self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
-            R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
-            s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
-            dz1 = torch.empty(Min, P, dtype=BF, device=dev)
-            if tile:
-                lib.call("tuber_dwconv_tile_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
-            else:
-                lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
-            dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min)
+            dc1 = None
+            if depth >= 5:
+                R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
+                s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
+                dz1 = torch.empty(Min, P, dtype=BF, device=dev)
+                if tile:
+                    lib.call("tuber_dwconv_tile_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
+                else:
+                    lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
+                dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min, train=f["bn1"], apply=depth >= 6)
             # conv1: weight grad and data grad (+ identity shortcut gradient as residual)
-            with self.store.side(dc1, x):
+            if f["w1"]:
                 self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
-            dx = torch.empty(Min, cin, dtype=BF, device=dev)
             strided = st != 1 or ss != 1
-            if not d["ds"]:
-                res = dz
-            elif not strided:
-                res = None  # filled below: stride-1 projection shortcut adds its dense data gradient
-            else:
-                res = None
-            if d["ds"]:
-                gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
-                with self.store.side(dcd, x):
-                    self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
-                dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
-                lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
-                         0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
-                if not strided:
-                    res = dxd
-            lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                     0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
-            if d["ds"] and strided:
-                lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
-            dy = dx
+            gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if (d["ds"] and strided) else None
+            if d["ds"] and f["wd"]:
+                self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
+            if need_dx:
+                dx = torch.empty(Min, cin, dtype=BF, device=dev)
+                res = dz if not d["ds"] else None
+                if d["ds"]:
+                    dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
+                    lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
+                             0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+                    if not strided:
+                        res = dxd           # stride-1 projection shortcut: its dense data gradient is the residual input
+                lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                         0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+                if d["ds"] and strided:
+                    lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
+                dy = dx
             if red is not None:
-                self.store.side_join()           # the slice handed to RCCL must include the side-stream weight gradients
-                self.store.defer.flush()         # ... and the deferred second-stage reductions
+                self.store.defer.flush()         # the slice handed to RCCL must include the deferred second-stage reductions
                 red.notify(d["off0"])
             hook = getattr(self, "split_hook", None)
             if d["first"] and d["stage"] == 3:
                 self.store.defer.flush()         # always here, so eager warm-up and a split capture build the same reduce tables
-            if hook is not None and d["first"] and d["stage"] == 3:
+            if hook is not None and d["first"] and d["stage"] == 3 and need_dx:
                 # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
                 # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem
                 hook(d["off0"])
-        # stem: pool + relu + bn backward, then the 3->64 conv weight gradient over the saved patch matrix
+        if not stem_plan["any"]:
+            return
+        # stem: pool + relu + bn backward, then the 3->64 conv weight gradient (implicit GEMM over the clip)
         clips, _, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
         M0 = B * T * Ho * Wo
         R = lib.query("tuber_stem_pool_bwd_stat_rows", M0)
@@ -405,9 +454,8 @@ class CSNRunner:
         dz0 = torch.empty(M0, 64, dtype=BF, device=dev)
         bn = self.stem_bn
         lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
-        dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0)
-        H, W = clips.shape[-2:]
-        with self.store.side(dc0, clips):
+        dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0, train=stem_plan["bn"], apply=stem_plan["w"])
+        if stem_plan["w"]:
+            H, W = clips.shape[-2:]
             nwg = min(lib.query("tuber_stem_conv_blocks", B, T, H, W), 256)
             lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
-        self.store.side_join()

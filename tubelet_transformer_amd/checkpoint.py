@@ -20,19 +20,31 @@ def _strip(k):
 
 @torch.no_grad()
 def _copy_into(model, tensors, verbose=True, what="checkpoint"):
-    """copy {name: tensor} into model.state_dict() entries with the same (prefix-stripped) name and shape."""
+    """copy {name: tensor} into model.state_dict() entries with the same (prefix-stripped) name.  Names the model does not have
+    are reported as unused (the reference filters them the same way, utils/model_utils.py:84-85); a name the model HAS with a
+    different shape raises like the reference's ``load_state_dict`` does (:89) -- a wrong-NUM_CLASSES / wrong-backbone file
+    must not load partially.  Copies are in place (the flat parameter store's views stay valid)."""
     sd = model.state_dict()
-    used, unused = [], []
+    used, unused, bad = [], [], []
     for k, v in tensors.items():
         n = _strip(k)
-        if n in sd and tuple(sd[n].shape) == tuple(v.shape):
-            sd[n].copy_(torch.as_tensor(v).to(sd[n].device, sd[n].dtype))
-            used.append(n)
-        else:
+        if n not in sd:
             unused.append(k)
+        elif tuple(sd[n].shape) != tuple(v.shape):
+            bad.append("%s: file %s vs model %s" % (n, tuple(v.shape), tuple(sd[n].shape)))
+        else:
+            used.append((n, v))
+    if bad:
+        raise RuntimeError("%s: size mismatch for %d tensors:\n  %s" % (what, len(bad), "\n  ".join(bad[:20])))
+    for n, v in used:
+        sd[n].copy_(torch.as_tensor(v).to(sd[n].device, sd[n].dtype))
+    used = [n for n, _ in used]
     missing = [k for k in sd if k not in set(used)]
     if verbose:
         print("%s: loaded %d tensors; unused %d; not found in file %d" % (what, len(used), len(unused), len(missing)))
+    store = getattr(model, "_store", None)
+    if store is not None and not store.valid():
+        raise RuntimeError("%s: parameters were re-allocated while loading (flat store invalid)" % what)
     return used, unused, missing
 
 

@@ -49,6 +49,10 @@ class PaddedTargets:
         self.tboxes = torch.zeros(B, self.tmax, 4, dtype=torch.float32, device=device)
         self.tlabels = torch.zeros((B, self.tmax, num_classes) if ava else (B, self.tmax), dtype=torch.float32, device=device)
         self.tcount = torch.tensor(self.sizes, dtype=torch.int32).to(device)
+        # JHMDB / UCF: key-frame position and visibility label per clip (criterion.py:378-380,256-262) -- device buffers too, so a
+        # captured step reads the CURRENT batch's values on every replay
+        self.key_pos = None if ava else torch.zeros(B, dtype=torch.int64, device=device)
+        self.vis = None if ava else torch.zeros(B, dtype=torch.int64, device=device)
         self.fill(targets)
 
     def fill(self, targets):
@@ -57,6 +61,22 @@ class PaddedTargets:
             if n:
                 self.tboxes[b, :n] = t["boxes"][:, 1:].to(self.tboxes)          # column 0 is the key-frame index
                 self.tlabels[b, :n] = t["labels"].to(self.tlabels)
+        if not self.ava:
+            if any(torch.as_tensor(t["vis"]).numel() != 1 for t in targets):
+                raise ValueError("one visibility label per clip expected (datasets/jhmdb_frame.py:170-189)")
+            self.key_pos.copy_(torch.stack([torch.as_tensor(t["key_pos"]).reshape(()) for t in targets]).to(self.key_pos), non_blocking=True)
+            self.vis.copy_(torch.stack([torch.as_tensor(t["vis"]).reshape(()) for t in targets]).to(self.vis), non_blocking=True)
+
+    def refill(self, targets):
+        """new batch into the same device buffers (hipGraph replays read these addresses)."""
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        if len(sizes) != self.B or max(sizes + [0]) > self.tmax:
+            raise ValueError("batch of %d clips with up to %d targets does not fit the captured [%d, %d] layout" % (len(sizes), max(sizes + [0]), self.B, self.tmax))
+        self.sizes = sizes
+        self.tboxes.zero_()
+        self.tlabels.zero_()
+        self.tcount.copy_(torch.tensor(sizes, dtype=torch.int32), non_blocking=True)
+        self.fill(targets)
 
 
 class HungarianMatcher(nn.Module):
@@ -190,15 +210,15 @@ class _SetCriterionBase(nn.Module):
         layers = list(outputs.get("aux_outputs", [])) + [{k: v for k, v in outputs.items() if k != "aux_outputs"}]
         return tuple(torch.stack([o[k].float() for o in layers]) for k in ("pred_logits", "pred_logits_b", "pred_boxes"))
 
-    def select(self, logits, boxes, targets):
+    def select(self, logits, boxes, pt):
         return logits, boxes
 
-    def losses_from_match(self, logits, logits_b, boxes, pt, match_dev, targets):
+    def losses_from_match(self, logits, logits_b, boxes, pt, match_dev, targets=None):
         L = logits.shape[0]
         pos_w = 1.0 if (self.evaluation or not self.ava) else float(self.weight)
         lv = _LossFn.apply(logits.contiguous(), logits_b.contiguous() if self.ava else logits, boxes.contiguous(), pt, match_dev,
                            self.ava, float(self.eos_coef), pos_w)
-        ce_b = lv[:, 1] if self.ava else self.visibility_loss(logits_b, targets)
+        ce_b = lv[:, 1] if self.ava else self.visibility_loss(logits_b, pt)
         out = {}
         for l in range(L):
             sfx = "" if l == L - 1 else "_%d" % l
@@ -221,12 +241,7 @@ class _SetCriterionBase(nn.Module):
         L = lv.shape[0]
         names = ("loss_ce", "loss_ce_b", "loss_bbox", "loss_giou")
         vals = tuple(float(wd.get(n + ("" if l == L - 1 else "_%d" % l), 0.0)) for l in range(L) for n in names)
-        cache = self.__dict__.setdefault("_w_cache", {})
-        key = (vals, str(lv.device))
-        if key not in cache:            # built once (outside any hipGraph capture: the eager warm-up step fills the cache)
-            W = torch.tensor(vals, dtype=torch.float32).view(L, 4)
-            cache[key] = (W.to(lv.device), W[:, 1].contiguous().to(lv.device))
-        W, wb = cache[key]
+        W, wb = self.sync_weights(lv.device, vals)
         if ce_b is None:
             return (lv * W).sum()
         Wm = W.clone()
@@ -234,15 +249,40 @@ class _SetCriterionBase(nn.Module):
         total = (lv * Wm).sum() + (ce_b * wb).sum()
         return total
 
+    def sync_weights(self, device, vals=None):
+        """the [L,4] loss-weight tensor on the device, refreshed IN PLACE from ``weight_dict`` when a value changed (the
+        ``epoch > WEIGHT_CHANGE`` switch of loss_ce, video_action_recognition.py:145-146) -- a captured hipGraph keeps reading the
+        same address, so the change takes effect on the next replay.  Call it before replaying; inside a capture nothing is copied."""
+        bufs = self.__dict__.setdefault("_w_bufs", {})
+        key = str(device)
+        ent = bufs.get(key)
+        if vals is None:
+            if ent is None:
+                return None
+            L = ent[0].shape[0]
+            names = ("loss_ce", "loss_ce_b", "loss_bbox", "loss_giou")
+            vals = tuple(float(self.weight_dict.get(n + ("" if l == L - 1 else "_%d" % l), 0.0)) for l in range(L) for n in names)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("loss-weight buffer must exist before hipGraph capture (run one eager step first)")
+            W = torch.tensor(vals, dtype=torch.float32).view(-1, 4).to(device)
+            ent = bufs[key] = [W, W[:, 1].clone(), vals]
+        elif ent[2] != vals and not torch.cuda.is_current_stream_capturing():
+            W = torch.tensor(vals, dtype=torch.float32).view(-1, 4)
+            ent[0].copy_(W)
+            ent[1].copy_(W[:, 1])
+            ent[2] = vals
+        return ent[0], ent[1]
+
     def forward(self, outputs, targets):
         logits, logits_b, boxes = self.stacked(outputs)
-        logits_s, boxes_s = self.select(logits, boxes, targets)
         pt = PaddedTargets(targets, self.ava, logits.shape[-1], logits.device)
+        logits_s, boxes_s = self.select(logits, boxes, pt)
         with torch.no_grad():
             cost = self.matcher.cost(logits_s.detach().contiguous(), (logits_b if self.ava else logits_s).detach().contiguous(),
                                      boxes_s.detach().contiguous(), pt)
             match_dev = self.assign(cost, pt)
-        losses = self.losses_from_match(logits_s, logits_b, boxes_s, pt, match_dev, targets)
+        losses = self.losses_from_match(logits_s, logits_b, boxes_s, pt, match_dev)
         losses["class_error"] = self.class_error(logits_s[-1], pt, match_dev[-1])
         return losses
 
@@ -280,17 +320,17 @@ class SetCriterion(_SetCriterionBase):
         ew[-1] = self.eos_coef
         self.register_buffer("empty_weight", ew)
 
-    def select(self, logits, boxes, targets):
+    def select(self, logits, boxes, pt):
         nq = self.num_queries
         dev = logits.device
-        kf = torch.stack([nq * t["key_pos"].to(dev) + torch.arange(nq, device=dev) for t in targets])       # [B,nq]
+        kf = nq * pt.key_pos[:, None] + torch.arange(nq, device=dev)[None, :]                                # [B,nq]
         L = logits.shape[0]
         idx = kf[None, :, :, None].expand(L, -1, -1, -1)
         return (torch.gather(logits, 2, idx.expand(-1, -1, -1, logits.shape[-1])),
                 torch.gather(boxes, 2, idx.expand(-1, -1, -1, 4)))
 
-    def visibility_loss(self, logits_b, targets):
-        vis = torch.cat([t["vis"] for t in targets]).view(-1).to(logits_b.device)
+    def visibility_loss(self, logits_b, pt):
+        vis = pt.vis
         L, B = logits_b.shape[:2]
         return F.cross_entropy(logits_b.reshape(L * B, -1).float(), vis.repeat(L), reduction="none").view(L, B).mean(1)
 

@@ -45,7 +45,8 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int np, floa
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, const float* __restrict__ clip, float lr,
                                                     float beta1, float beta2, float eps, float wd, const int* __restrict__ step_ptr,
-                                                    int write_clipped_grad) {
+                                                    int write_clipped_grad, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; wd = hyper[1]; }     // per-group lr / weight decay in DEVICE memory: schedulers act on replayed hipGraphs
     const float c = clip ? clip[1] : 1.f;
     const float tstep = (float)(*step_ptr);
     const float bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
@@ -100,16 +101,17 @@ int tuber_grad_norm_clip_coef(const float* g, long n, float max_norm, float* par
 
 // one AdamW step on a contiguous segment; `clip` = norm_out of tuber_grad_norm_clip_coef (or NULL);
 // the step count t (for the bias corrections 1 - beta^t) is read from DEVICE memory so a captured hipGraph
-// replays with the right value every step.
+// replays with the right value every step; so are lr / weight_decay when `hyper` (device float[2] = {lr, weight_decay}) is given
+// (lr_scheduler.step() between replays), else the by-value arguments are used.
 int tuber_adamw_segment(float* p, float* g, float* exp_avg, float* exp_avg_sq, long n, const float* clip, float lr, float beta1,
                         float beta2, float eps, float weight_decay, const int* step_ptr, int write_clipped_grad,
-                        hipStream_t stream) {
+                        const float* hyper, hipStream_t stream) {
     if (n <= 0) return TUBER_EINVAL;
     long nb = (n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, clip, lr, beta1, beta2, eps,
-                       weight_decay, step_ptr, write_clipped_grad);
+                       weight_decay, step_ptr, write_clipped_grad, hyper);
     TUBER_RETURN_LAUNCH();
 }
 

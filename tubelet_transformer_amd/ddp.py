@@ -22,6 +22,21 @@ import torch
 import torch.distributed as dist
 
 
+def trainable_ranges(store):
+    """merged [begin, end) windows of the flat buffers that belong to parameters with ``requires_grad``."""
+    out = []
+    for n, p in zip(store.names, store.params):
+        if not p.requires_grad:
+            continue
+        o = store.offsets[n]
+        e = o + (p.numel() + 63) // 64 * 64
+        if out and out[-1][1] == o:
+            out[-1][1] = e
+        else:
+            out.append([o, e])
+    return [(a, b) for a, b in out]
+
+
 class FlatGradReducer:
     def __init__(self, store, world_size=None, min_bucket=8 << 20):
         self.store = store
@@ -39,11 +54,15 @@ class FlatGradReducer:
     def begin(self):
         self.handles = []
         self.done_from = self.store.total
+        self.ranges = trainable_ranges(self.store)       # windows of frozen parameters hold no gradient: never sent
 
     def _reduce(self, lo, hi):
         if hi <= lo or self.world <= 1:
             return
-        self.handles.append(dist.all_reduce(self.store.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for a, b in self.ranges:
+            a, b = max(a, lo), min(b, hi)
+            if b > a:
+                self.handles.append(dist.all_reduce(self.store.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def _reduce_excluding_late(self, lo, hi):
         cur = lo

@@ -10,7 +10,6 @@ Layout in HBM (per model, per GPU):
                operands of the data-gradient GEMMs; leading dimension padded to a multiple of 64.
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
-import contextlib
 import os
 
 import numpy as np
@@ -164,7 +163,7 @@ class ParamStore:
         self.ttable = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
         self.nmat = len(entries)
         self.step_seed = 0
-        self.side_stream, self._side_keep, self._side_dirty = None, [], False
+        self._by_name = dict(zip(names, params))
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.defer = DeferredReduce(self.device)
@@ -183,13 +182,30 @@ class ParamStore:
         return all(p.data_ptr() == q for p, q in zip(self.params, self._ptrs))
 
     def ensure_grad_views(self):
+        """``p.grad`` of every trainable parameter is its window of the flat gradient buffer; frozen parameters
+        (``requires_grad = False``) have ``p.grad is None`` like under autograd, and their windows stay zero."""
         for n, p in zip(self.names, self.params):
+            if not p.requires_grad:
+                p.grad = None
+                continue
             o = self.offsets[n]
             want = self.gflat[o:o + p.numel()].view(p.shape)
             if p.grad is None or p.grad.data_ptr() != want.data_ptr():
                 if p.grad is not None:
                     want.copy_(p.grad)
                 p.grad = want
+
+    def trainable(self, name):
+        return self._by_name[name].requires_grad
+
+    def trainable_signature(self):
+        """hashable summary of which parameters are trainable (a captured hipGraph bakes the launch sequence in)."""
+        return tuple(i for i, p in enumerate(self.params) if not p.requires_grad)
+
+    def trainable_ranges(self):
+        """merged [begin, end) ranges of the flat buffers that hold trainable parameters (gradient all-reduce)."""
+        from .ddp import trainable_ranges
+        return trainable_ranges(self)
 
     def partial(self, key, numel, fallback):
         """scratch for a weight-gradient kernel's partials -> (pointer or tensor, accumulate flag): arena + 2 when the second stage is
@@ -199,40 +215,11 @@ class ParamStore:
         return fallback(key, numel), 1
 
     def zero_grad(self):
-        self.side_join()
         self.gflat.zero_()
         self.ensure_grad_views()
 
-    # -- side stream for weight gradients -----------------------------------------------------
-    # dW GEMMs / depthwise weight gradients / bias column sums feed nothing until the optimizer, so they run on a second
-    # HIP stream concurrently with the data-gradient chain (these kernels are too small to fill 256 CUs on their own).
-    # Inside a hipGraph capture this becomes a fork/join in the graph.
-    @contextlib.contextmanager
-    def side(self, *keep):
-        """``with store.side(t1, t2, ...):`` -- launches inside run on the side stream after everything enqueued so far;
-        the listed tensors (inputs produced on the main stream) are kept alive until ``side_join``."""
-        # Measured on MI355X (DESIGN.md section 3): once the step was down to ~2 000 launches a second stream for the weight
-        # gradients COSTS 2 ms/step in a hipGraph (cross-queue dependencies) and 3.5 ms eagerly, so it is opt-in.
-        if not os.environ.get("TUBER_SIDE_STREAM") or os.environ.get("TUBER_NO_SIDE_STREAM"):
-            yield
-            return
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
-        self.side_stream.wait_stream(torch.cuda.current_stream())
-        self._side_keep.extend(keep)
-        self._side_dirty = True
-        with torch.cuda.stream(self.side_stream):
-            yield
-
-    def side_join(self):
-        if self._side_dirty:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-            self._side_dirty = False
-        self._side_keep.clear()
-
     def begin_step(self, train):
         """new forward: call-site salts restart at 0; in training the device seed advances (captured in graphs)."""
-        self.side_join()
         self.defer.reset()
         self.step_seed = 0
         if train:

@@ -52,6 +52,8 @@ class Tape:
         self.mask = {}         # id(h) -> 1/(1-p): h = Dropout(ReLU(.)) whose backward mask the consumer's dgrad GEMM applies
         self.premasked = set()
         self.stack = {}        # id(tensor) -> list of gradient tensors summed lazily by the producer's backward
+        self.req = set()       # ids of tensors whose gradient is needed (they depend on a trainable parameter): the backward pass
+        #                        skips weight gradients of frozen parameters and data gradients nobody consumes, like autograd does
 
     # -- gradient bookkeeping -------------------------------------------------------------------
     def rec(self, fn):
@@ -62,6 +64,12 @@ class Tape:
         while id(t) in self.alias:
             t = self.alias[id(t)]
         return t
+
+    def needs(self, t):
+        return id(self.target(t)) in self.req
+
+    def mark(self, t):
+        self.req.add(id(t))
 
     def take(self, t):
         return self.g.pop(id(self.target(t)), None)
@@ -96,6 +104,7 @@ class Tape:
 
     def clear(self):
         self.ops.clear(); self.g.clear(); self.alias.clear(); self.mask.clear(); self.premasked.clear(); self.stack.clear()
+        self.req.clear()
 
     def salt(self):
         self.store.step_seed += 1
@@ -123,6 +132,12 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
              0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt, None, 0, None)
     if not tp.train:
         return y
+    wreq = st.trainable(wname)
+    breq = bool(bname) and st.trainable(bname)
+    xreq = tp.needs(x)
+    if not (wreq or breq or xreq):
+        return y
+    tp.mark(y)
     inv_keep = 1.0 / (1.0 - p)
     if relu:
         tp.mask[id(y)] = inv_keep
@@ -152,12 +167,13 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             lib.call("tuber_dropout", gb, gm, M * N, p, st.seed, salt)    # same (seed, salt, m*N+n) stream as the epilogue
             gb = gm
         gw = st.gflat.data_ptr() + 4 * (st.offsets[wname] + r0 * K)
-        with st.side(gb, x):               # weight / bias gradients feed nothing until the optimizer
+        ws = lambda k, n: workspace(dev, k, n)
+        gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if breq else None
+        fuse_b = 0
+        if wreq:
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-            gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if bname else None
             # bias gradient inside the GEMM: 1 = accumulated directly (single slab), 2 = one partial row per slab
-            fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) if bname else 0
-            ws = lambda k, n: workspace(dev, k, n)
+            fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) if breq else 0
             part, acc = st.partial("tn", S * N * K, ws) if S > 1 else (None, 1)
             bpart = st.partial("cs", S * N, ws)[0] if fuse_b == 2 else None
             lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, acc, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
@@ -169,12 +185,14 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
                     st.defer.add(bpart, gbias, N, N, S, 1)
                 else:
                     lib.call("tuber_reduce_rows", bpart, gbias, S, N, 1)
-            elif bname and not fuse_b:
-                nbc = lib.query("tuber_colsum_blocks", M)
-                part, acc = st.partial("cs", nbc * N, ws) if nbc > 1 else (None, 1)
-                lib.call("tuber_colsum", gb, part, gbias, acc, M, N, ldg)
-                if acc == 2:
-                    st.defer.add(part, gbias, N, N, nbc, 1)
+        if breq and not fuse_b:
+            nbc = lib.query("tuber_colsum_blocks", M)
+            part, acc = st.partial("cs", nbc * N, ws) if nbc > 1 else (None, 1)
+            lib.call("tuber_colsum", gb, part, gbias, acc, M, N, ldg)
+            if acc == 2:
+                st.defer.add(part, gbias, N, N, nbc, 1)
+        if not xreq:
+            return
         # data gradient; accumulation with an existing gradient of x and the ReLU/Dropout mask of x are GEMM epilogues
         toff, _, _, ldt = st.tinfo[wname]
         wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
@@ -226,6 +244,11 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
     lib.call("tuber_layernorm_fwd", x, res, gamma, beta, yptr, ldy, xhat, rstd, M, E, 1e-5, p, st.seed, salt)
     if not tp.train:
         return y
+    preq = st.trainable(prefix + ".weight") or st.trainable(prefix + ".bias")
+    xreq, rreq = tp.needs(x), res is not None and tp.needs(res)
+    if not (preq or xreq or rreq):
+        return y
+    tp.mark(y)
 
     def bwd():
         if out is None:
@@ -246,15 +269,19 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
         dx = torch.empty(M, E, dtype=BF, device=dev) if need_res else None
         dxd = torch.empty(M, E, dtype=BF, device=dev) if p > 0.0 else None
         part, acc = st.partial("ln", 2 * nb * E, lambda k, n: workspace(dev, k, n))
+        if not preq and acc != 2:          # frozen LayerNorm, immediate reductions: gamma/beta gradients go to scratch
+            dgamma = workspace(dev, "ln_frozen", 2 * E).data_ptr()
+            dbeta = dgamma + 4 * E
         lib.call("tuber_layernorm_bwd", gptr, ldg, xhat, rstd, gamma, dx, dxd, part, dgamma, dbeta, acc, M, E, p, st.seed, salt)
-        if acc == 2:
+        if acc == 2 and preq:
             if dbeta == dgamma + 4 * E:
                 st.defer.add(part, dgamma, 2 * E, 2 * E, nb, 1)
             else:
                 st.defer.add(part, dgamma, E, 2 * E, nb, 1)
                 st.defer.add(part + 4 * E, dbeta, E, 2 * E, nb, 1)
-        tp.put(x, dxd if p > 0.0 else dx)
-        if res is not None:
+        if xreq:
+            tp.put(x, dxd if p > 0.0 else dx)
+        if rreq:
             tp.put(res, dx)
     tp.rec(bwd)
     return y
@@ -280,6 +307,10 @@ def attention(tp, roles, geom, kpm, pdrop, *tensors):
              tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(p), st.seed, salt)
     if not tp.train:
         return o
+    treq = [tp.needs(t) for t in tensors]
+    if not any(treq):
+        return o
+    tp.mark(o)
 
     def bwd():
         g = tp.take(o)
@@ -294,8 +325,9 @@ def attention(tp, roles, geom, kpm, pdrop, *tensors):
                  tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, g, mo.ctypes.data,
                  grads[qi].data_ptr() + 2 * qo, mq.ctypes.data, grads[ki].data_ptr() + 2 * ko, mk.ctypes.data,
                  grads[vi].data_ptr() + 2 * vo, mv.ctypes.data, delta, B, H, Lq, Lk, scale, float(p), st.seed, salt)
-        for t, gt in zip(tensors, grads):
-            tp.put(t, gt)
+        for t, gt, need in zip(tensors, grads, treq):
+            if need:
+                tp.put(t, gt)
     tp.rec(bwd)
     return o
 
@@ -310,6 +342,10 @@ def attention_wide(tp, q, kv, HW, T, pdrop):
     lib.call("tuber_attn_wide_fwd", q, kv, o, NQ, HW, T, float(p), st.seed, salt)
     if not tp.train:
         return o
+    qreq, kreq = tp.needs(q), tp.needs(kv)
+    if not (qreq or kreq):
+        return o
+    tp.mark(o)
 
     def bwd():
         g = tp.take(o)
@@ -317,8 +353,10 @@ def attention_wide(tp, q, kv, HW, T, pdrop):
             return
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         lib.call("tuber_attn_wide_bwd", q, kv, g, dq, dkv, NQ, HW, T, float(p), st.seed, salt)
-        tp.put(q, dq)
-        tp.put(kv, dkv)
+        if qreq:
+            tp.put(q, dq)
+        if kreq:
+            tp.put(kv, dkv)
     tp.rec(bwd)
     return o
 
@@ -337,12 +375,17 @@ def add(tp, a, b):
     """a + b with gradients to both."""
     out = torch.empty_like(a)
     lib.call("tuber_axpby", a, b, out, a.numel(), 1.0, 1.0)
-    if tp.train:
+    areq, breq = tp.needs(a), tp.needs(b)
+    if tp.train and (areq or breq):
+        tp.mark(out)
+
         def bwd():
             g = tp.take(out)
             if g is not None:
-                tp.put(a, g)
-                tp.put(b, g)
+                if areq:
+                    tp.put(a, g)
+                if breq:
+                    tp.put(b, g)
         tp.rec(bwd)
     return out
 
@@ -353,7 +396,9 @@ def gather_sum(tp, x, fwd, bwd_map):
     E = x.shape[1]
     out = torch.empty(A * B * C, E, dtype=BF, device=x.device)
     lib.call("tuber_rows_gather_sum", x, out, A, B, C, D, sa, sb, sc, sd, E, float(mul))
-    if tp.train:
+    if tp.train and tp.needs(x):
+        tp.mark(out)
+
         def bwd():
             g = tp.take(out)
             if g is None:
@@ -375,7 +420,8 @@ def param_rows(tp, name, B):
     src = st.shadow.data_ptr() + 2 * st.offsets[name]
     out = torch.empty(B * Q, E, dtype=BF, device=st.device)
     lib.call("tuber_rows_gather_sum", src, out, B, 1, Q, 1, 0, 0, 1, 0, E, 1.0)
-    if tp.train:
+    if tp.train and st.trainable(name):
+        tp.mark(out)
         tp.stack[id(out)] = []
 
         def bwd(keep=out):
@@ -404,8 +450,9 @@ def dropout(tp, x, p):
     salt = tp.salt()
     y = torch.empty_like(x)
     lib.call("tuber_dropout", x, y, x.numel(), float(p), st.seed, salt)
-    if not tp.train:
+    if not tp.train or not tp.needs(x):
         return y
+    tp.mark(y)
 
     def bwd():
         g = tp.take(y)
@@ -421,7 +468,9 @@ def dropout(tp, x, p):
 def sigmoid(tp, x):
     y = torch.empty_like(x)
     lib.call("tuber_sigmoid_fwd", x, y, x.numel())
-    if tp.train:
+    if tp.train and tp.needs(x):
+        tp.mark(y)
+
         def bwd():
             g = tp.take(y)
             if g is None:
@@ -439,7 +488,9 @@ def temporal_max(tp, feat, B, Tp, hw):
     out = torch.empty(B * hw, C, dtype=BF, device=feat.device)
     arg = torch.empty(B * hw, C, dtype=torch.uint8, device=feat.device) if tp.train else None
     lib.call("tuber_temporal_max_fwd", feat, out, arg, B, Tp, hw, C)
-    if tp.train:
+    if tp.train and tp.needs(feat):
+        tp.mark(out)
+
         def bwd():
             g = tp.take(out)
             if g is None:
@@ -455,7 +506,9 @@ def mid_frame(tp, feat, B, Tp, hw):
     """feat rows (b,t,hw) -> rows (b,hw) of the middle frame (backbone_builder.py:79-80); plain torch indexing (JHMDB only)."""
     C = feat.shape[1]
     out = feat.view(B, Tp, hw, C)[:, Tp // 2].reshape(B * hw, C)
-    if tp.train:
+    if tp.train and tp.needs(feat):
+        tp.mark(out)
+
         def bwd():
             g = tp.take(out)
             if g is None:
@@ -472,7 +525,9 @@ def backbone(tp, runner, clips, bn_train):
     feat, saved = runner.forward(clips, bn_train)
     runner.last_shape = tuple(feat.shape)
     f2 = feat.view(-1, feat.shape[-1])
-    if tp.train:
+    if tp.train and runner.any_trainable():
+        tp.mark(f2)
+
         def bwd():
             g = tp.take(f2)
             if g is not None:

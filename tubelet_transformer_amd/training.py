@@ -5,9 +5,10 @@
     optimizer.zero_grad() ; losses.backward() ; clip_grad_norm_(0.1) ; optimizer.step()
 
 The reference additionally copies ``pred_logits`` to the host every step as a NaN probe (:140) and calls ``.item()`` five
-times on rank 0 (:182-193); here the only device->host transfer of a step is the single matcher cost copy, and logging
-reads the (still on-device) loss tensors only when asked to.
+times on rank 0 (:182-193); here a step has no device->host transfer at all (the Hungarian assignment runs on the device) and
+logging reads the (still on-device) loss tensors only when asked to.
 """
+import collections
 import os
 
 import torch
@@ -16,16 +17,33 @@ from .ddp import FlatGradReducer, broadcast_parameters
 from .optim import FusedClipAdamW, build_param_groups
 
 
-def deploy_model(model, cfg, device=None):
-    """Counterpart of utils/model_utils.py:39-58 for the flat-gradient data-parallel path: moves the model to this rank's
-    GPU, broadcasts rank 0's parameters and attaches the gradient reducer.  Returns the (unwrapped) model."""
+def deploy_model(model, cfg, is_tuber=True, device=None):
+    """Counterpart of utils/model_utils.py:39-63, same call form (``deploy_model(model, cfg, is_tuber=True)``): selects this
+    rank's GPU (``torch.cuda.set_device(cfg.DDP_CONFIG.GPU)``), moves the model there, and -- instead of wrapping it in
+    ``DistributedDataParallel`` -- broadcasts rank 0's parameters / buffers and attaches the flat-gradient reducer (ddp.py)
+    when a process group with more than one rank exists.  Then initialises the transformer from the DETR checkpoint
+    ``CONFIG.MODEL.PRETRAIN_TRANSFORMER_DIR`` like the reference (:60-61); a blank path skips that step (the reference would
+    fail in ``torch.load``; there are no checkpoints in an offline image).  Returns the (unwrapped) model."""
     import torch.distributed as dist
-    dev = torch.device(device if device is not None else "cuda:%d" % cfg.DDP_CONFIG.GPU)
+    gpu = getattr(cfg.DDP_CONFIG, "GPU", None)
+    if device is not None:
+        dev = torch.device(device)
+    elif gpu is not None:
+        dev = torch.device("cuda", int(gpu))
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)        # every launch goes to the CURRENT device's stream with raw pointers: pin it (model_utils.py:45)
     model.to(dev)
     store, _ = model.engine()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         broadcast_parameters(store)
         store.reducer = FlatGradReducer(store)
+    path = getattr(cfg.CONFIG.MODEL, "PRETRAIN_TRANSFORMER_DIR", "")
+    if is_tuber and path:
+        from .checkpoint import load_detr_weights
+        print("loading detr")
+        load_detr_weights(model, path, cfg)
     return model
 
 
@@ -48,96 +66,105 @@ def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0,
     if reducer is not None:
         reducer.begin()
     losses.backward()
-    store.side_join()
     if reducer is not None:
         reducer.finish()
     optimizer.step(max_norm=max_norm if max_norm and max_norm > 0 else None)
     return losses.detach(), loss_dict
 
 
+class _Snapshot:
+    """Everything a training step mutates: parameters, BatchNorm buffers, Adam moments + step count, dropout seed.  The captured
+    step needs eager warm-up passes (workspace sizing, reduce tables); they must not count as optimisation steps."""
+
+    def __init__(self, model, store, opt):
+        self.items = [(store.flat, store.flat.clone()), (store.seed, store.seed.clone()), (opt.exp_avg, opt.exp_avg.clone()),
+                      (opt.exp_avg_sq, opt.exp_avg_sq.clone()), (opt.t_dev, opt.t_dev.clone())]
+        self.items += [(b, b.clone()) for b in model.buffers()]
+
+    def restore(self):
+        with torch.no_grad():
+            for live, saved in self.items:
+                live.copy_(saved)
+
+
 class GraphedTrainStep:
     """The same optimisation step replayed from ONE captured hipGraph (HIP graphs instead of a tracing compiler): bf16 weight
     refresh, forward of the whole model, matching-cost kernel, Hungarian assignment on the device (tuber_lsap_device), fused
-    criterion (losses + output gradients), backward of the whole model, global-norm clip + AdamW.  With >1 rank the optimizer is
-    a second graph behind an eager RCCL all-reduce of the flat gradient buffer; assignment problems beyond the device solver's
-    128 x 128 bound split the graph around the host tuber_lsap.
+    criterion (losses + output gradients), backward of the whole model, global-norm clip + AdamW.
 
-    ~2000 kernel launches per step are issued by the GPU front-end instead of Python, so the step is GPU-bound.
-    Inputs are copied into static device buffers; targets use the padded [B, Tmax] layout, so clips with a different number
-    of boxes replay the same graphs (shape changes of the clip batch re-capture).  Dropout masks differ every replay (the seed
-    lives in device memory), AdamW reads its step count from device memory.
+    ~1600 kernel launches per step are issued by the GPU front-end instead of Python, so the step is GPU-bound.
+
+    Everything that changes from batch to batch or epoch to epoch is read from DEVICE memory by the captured kernels and
+    refreshed in ``__call__`` before the replay: the clips and their padding mask, the padded [B, Tmax] targets (boxes, labels,
+    counts and -- JHMDB/UCF -- key-frame positions and visibility labels), the per-group learning rate / weight decay
+    (``lr_scheduler.step()`` keeps working), the loss weights (the ``epoch > WEIGHT_CHANGE`` switch), the dropout seed and the
+    AdamW step count.  A new clip shape or a changed set of frozen parameters captures a new graph (the eager warm-up passes of
+    a capture are rolled back, so they are not optimisation steps); at most ``max_graphs`` graphs are kept (LRU).
+
+    With >1 rank (ddp.py) the gradient all-reduce runs between / under the graph pieces; see ``_capture``.
     """
 
-    def __init__(self, model, criterion, optimizer, max_norm, tmax=16):
+    def __init__(self, model, criterion, optimizer, max_norm, tmax=16, max_graphs=4):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
-        self.max_norm, self.tmax = max_norm, tmax
-        self.graphs = {}
+        self.max_norm, self.tmax, self.max_graphs = max_norm, tmax, max_graphs
+        self.graphs = collections.OrderedDict()
 
-    def _capture(self, clips, targets):
+    # -- capture -------------------------------------------------------------------------------------------------------------
+    def _capture(self, clips, mask, targets):
         from .criterion import PaddedTargets
         from .misc import NestedTensor
         model, crit, opt = self.model, self.criterion, self.optimizer
         store, _ = model.engine()
         dev = store.device
-        # the hooks of the eager reducer must not fire inside a stream capture: in graph mode the gradient all-reduce is
-        # issued eagerly between graph B1 (backward) and B2 (optimizer), so detach the reducer for good
         red = getattr(store, "reducer", None)
         world = getattr(red, "world", 1) if red is not None else getattr(self, "world", 1)
         self.world = world
         g = type("Captured", (), {})()
         g.clips = clips.clone()
-        g.mask = torch.zeros(clips.shape[0], clips.shape[-2], clips.shape[-1], dtype=torch.bool, device=dev)
+        g.mask = mask.clone()
         g.pt = PaddedTargets(targets, crit.ava, crit.num_classes if crit.ava else crit.num_classes + 1, dev, tmax=self.tmax)
-        g.targets = targets
-        # eager warm-up: sizes every persistent workspace before capture
-        for _ in range(2):
-            train_step(model, crit, opt, NestedTensor(g.clips, g.mask), targets, self.max_norm)
-        torch.cuda.synchronize()
-        store.reducer = None
-        if red is not None:
-            # the eager reducer made the backward flush its deferred reductions once per bottleneck; the captured backward flushes
-            # twice.  One forward + backward WITHOUT the reducer (no optimizer step: ranks stay in sync) builds those reduce tables now,
-            # because nothing can be uploaded during the capture.
-            ld = crit(model(NestedTensor(g.clips, g.mask)), targets)
-            opt.zero_grad()
-            crit.weighted_total(ld).backward()
-            store.side_join()
-            torch.cuda.synchronize()
-        # With the assignment on the device (tuber_lsap_device) the whole step is ONE graph: refresh, forward, matching cost,
-        # assignment, fused criterion, backward, clip + AdamW -- no device->host round trip.  (DDP: the optimizer is a second
-        # graph behind the eager RCCL all-reduce.  Problems beyond the device solver's 128 x 128 bound use graph A / host / B.)
-        Q = model.query_embed.num_embeddings
-        g.on_device = Q <= 128 and g.pt.tmax <= 128
-        g.A = torch.cuda.CUDAGraph()
-        g.B1 = None
+        max_norm = self.max_norm if self.max_norm and self.max_norm > 0 else None
 
         def head():
             outputs = model(NestedTensor(g.clips, g.mask))
             logits, logits_b, boxes = crit.stacked(outputs)
-            g.logits_s, g.boxes_s = crit.select(logits, boxes, targets)
+            g.logits_s, g.boxes_s = crit.select(logits, boxes, g.pt)
             g.logits_b = logits_b
             with torch.no_grad():
                 g.cost = crit.matcher.cost(g.logits_s.detach().contiguous(),
                                            (logits_b if crit.ava else g.logits_s).detach().contiguous(),
                                            g.boxes_s.detach().contiguous(), g.pt)
 
-        def tail():
-            g.loss_dict = crit.losses_from_match(g.logits_s, g.logits_b, g.boxes_s, g.pt, g.match, targets)
+        def tail(step):
+            g.loss_dict = crit.losses_from_match(g.logits_s, g.logits_b, g.boxes_s, g.pt, g.match)
             g.loss_dict["class_error"] = crit.class_error(g.logits_s[-1], g.pt, g.match[-1])
             g.loss = crit.weighted_total(g.loss_dict)
             opt.zero_grad()
             g.loss.backward()
-            store.side_join()
-            if world == 1:
-                opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
+            if step:
+                opt.step(max_norm=max_norm)
 
-        g.A2, g.split = None, None
-        # Opt-in (TUBER_SPLIT_GRAPH=1): verified bit-exact on one GPU and run end-to-end with 2 gloo ranks, but this build has never
-        # had a multi-GPU box to validate it under RCCL, so the default DDP step keeps the plain form (graph, all-reduce, graph).
-        split = g.on_device and bool(os.environ.get("TUBER_SPLIT_GRAPH") or os.environ.get("TUBER_FORCE_SPLIT_GRAPH")) \
-            and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
-        if split:
-            # DDP: graph A is cut where layer3's backward ends (~95 % of the gradient bytes are final there), so the RCCL
+        # eager warm-up with the reducer detached (its hooks must not fire inside a stream capture, and it flushes the deferred
+        # reductions per bottleneck where the captured backward flushes twice): sizes every workspace, builds the reduce tables and
+        # the loss-weight / hyper-parameter device tables.  Rolled back afterwards -- a capture is not an optimisation step.
+        snap = _Snapshot(model, store, opt)
+        store.reducer = None
+        try:
+            for _ in range(2):
+                head()
+                g.on_device = g.cost.shape[2] <= 128 and g.cost.shape[3] <= 128      # the bound of tuber_lsap_device (criterion.assign)
+                g.match = crit.assign(g.cost, g.pt)
+                tail(True)
+            torch.cuda.synchronize()
+        finally:
+            snap.restore()
+        opt.sync_hyper()
+        crit.sync_weights(dev)
+        g.A, g.A2, g.B1, g.B2, g.split = torch.cuda.CUDAGraph(), None, None, None, None
+        split = world > 1 and g.on_device and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
+        split = split or bool(os.environ.get("TUBER_FORCE_SPLIT_GRAPH"))
+        if split and g.on_device:
+            # DDP: graph A is cut where layer3's backward ends (~97 % of the gradient bytes are final there), so the RCCL
             # all-reduce of that slice runs under the layer2 / layer1 / stem backward (graph A2) instead of after it.
             _, runner = model.engine()
             cut = {}
@@ -145,36 +172,34 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
-            try:
-                with torch.cuda.stream(cs):
-                    g.A.capture_begin(capture_error_mode="relaxed")      # the cut happens on autograd's worker thread
+            with torch.cuda.stream(cs):
+                g.A.capture_begin(capture_error_mode="relaxed")      # the cut happens on autograd's worker thread
 
-                    def hook(off):
-                        if "off" not in cut:
-                            g.A.capture_end()
-                            cut["off"] = off
-                            a2.capture_begin(pool=g.A.pool(), capture_error_mode="relaxed")
-                    runner.split_hook = hook
-                    try:
-                        head()
-                        g.match = crit.assign(g.cost, g.pt)
-                        tail()
-                    finally:
-                        runner.split_hook = None
-                    if "off" in cut:
-                        a2.capture_end()
-                        g.A2, g.split, g.body_begin = a2, int(cut["off"]), int(runner.body_begin)
-                    else:
+                def hook(off):
+                    if "off" not in cut:
                         g.A.capture_end()
-                torch.cuda.current_stream().wait_stream(cs)
-            except Exception:
-                raise
+                        cut["off"] = off
+                        a2.capture_begin(pool=g.A.pool(), capture_error_mode="relaxed")
+                runner.split_hook = hook
+                try:
+                    head()
+                    g.match = crit.assign(g.cost, g.pt)
+                    tail(world == 1)
+                finally:
+                    runner.split_hook = None
+                if "off" in cut:
+                    a2.capture_end()
+                    g.A2, g.split, g.body_begin = a2, int(cut["off"]), int(runner.body_begin)
+                else:
+                    g.A.capture_end()
+            torch.cuda.current_stream().wait_stream(cs)
         elif g.on_device:
             with torch.cuda.graph(g.A):
                 head()
                 g.match = crit.assign(g.cost, g.pt)
-                tail()
+                tail(world == 1)
         else:
+            # assignment problems beyond the device solver's 128 x 128 bound: graph A / host tuber_lsap / graph B1
             with torch.cuda.graph(g.A):
                 head()
             L, B = g.cost.shape[:2]
@@ -183,28 +208,38 @@ class GraphedTrainStep:
             g.cost_host = torch.empty(g.cost.shape, dtype=torch.float32).pin_memory()
             g.B1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.B1, pool=g.A.pool()):
-                tail()
-        g.B2 = None
+                tail(world == 1)
         if world > 1:
             g.B2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.B2, pool=g.A.pool()):
-                opt.step(max_norm=self.max_norm if self.max_norm and self.max_norm > 0 else None)
+                opt.step(max_norm=max_norm)
+        g.ranges = store.trainable_ranges()
         return g
 
-    def __call__(self, clips, targets):
-        key = tuple(clips.shape)
+    # -- replay --------------------------------------------------------------------------------------------------------------
+    def __call__(self, samples, targets):
+        """``samples``: NestedTensor (clips + padding mask) or a plain [B,3,T,H,W] tensor (no padding)."""
+        store, _ = self.model.engine()
+        if hasattr(samples, "tensors"):
+            clips, mask = samples.tensors, samples.mask
+        else:
+            clips, mask = samples, None
+        if mask is None:
+            mask = torch.zeros(clips.shape[0], clips.shape[-2], clips.shape[-1], dtype=torch.bool, device=store.device)
+        key = (tuple(clips.shape), store.trainable_signature(), self.criterion.training)
         g = self.graphs.get(key)
         if g is None:
-            g = self.graphs[key] = self._capture(clips, targets)
-        store, _ = self.model.engine()
+            while len(self.graphs) >= self.max_graphs:            # LRU: a graph holds its own memory pool
+                self.graphs.popitem(last=False)
+            g = self.graphs[key] = self._capture(clips.to(store.device, torch.float32), mask.to(store.device), targets)
+        else:
+            self.graphs.move_to_end(key)
         g.clips.copy_(clips, non_blocking=True)
-        sizes = [int(t["boxes"].shape[0]) for t in targets]
-        if targets is not g.targets:
-            g.pt.sizes = sizes
-            g.pt.tboxes.zero_()
-            g.pt.tlabels.zero_()
-            g.pt.tcount.copy_(torch.tensor(sizes, dtype=torch.int32), non_blocking=True)
-            g.pt.fill(targets)
+        g.mask.copy_(mask, non_blocking=True)
+        g.pt.refill(targets)
+        self.optimizer.sync_hyper()
+        self.criterion.sync_weights(store.device)
+        sizes = g.pt.sizes
         g.A.replay()
         if g.on_device:
             self.criterion._indices, self.criterion._match_dev = None, (g.match, sizes)
@@ -217,44 +252,27 @@ class GraphedTrainStep:
             L = len(indices)
             self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
             g.B1.replay()
+        if g.B2 is None and g.A2 is None:
+            return g.loss, g.loss_dict
+        import torch.distributed as dist
+        ddp = g.B2 is not None and dist.is_initialized()
+        from . import lib
         if g.A2 is not None:
-            import torch.distributed as dist
-            ddp = g.B2 is not None and dist.is_initialized()
-            dbg = os.environ.get("TUBER_DEBUG_TIMING")
-            if dbg:
-                import time
-                torch.cuda.synchronize(); t0 = time.time()
             # final at the cut: layer3, layer4 and everything laid out behind the body [split, total) and everything laid out
             # before it (transformer, heads: [0, body_begin)); pending: stem, layer1, layer2 [body_begin, split)
             bb = g.body_begin
             h1 = [dist.all_reduce(store.gflat[g.split:], op=dist.ReduceOp.SUM, async_op=True),
-                  dist.all_reduce(store.gflat[:bb], op=dist.ReduceOp.SUM, async_op=True)] if ddp else None
-            if dbg:
-                t1 = time.time()
+                  dist.all_reduce(store.gflat[:bb], op=dist.ReduceOp.SUM, async_op=True)] if ddp else []
             g.A2.replay()                                     # layer2 / layer1 / stem backward, under the all-reduce
-            if dbg:
-                t2 = time.time()
             if ddp:
-                h2 = dist.all_reduce(store.gflat[bb:g.split], op=dist.ReduceOp.SUM, async_op=True)
+                h1.append(dist.all_reduce(store.gflat[bb:g.split], op=dist.ReduceOp.SUM, async_op=True))
                 for h in h1:
                     h.wait()
-                if dbg:
-                    t3 = time.time()
-                h2.wait()
-                if dbg:
-                    torch.cuda.synchronize()
-                    print("split step: issue ar1 %.1f ms, replay A2 %.1f ms, wait ar1 %.1f ms, ar2+sync %.1f ms (phase 1: [%d,%d) + [0,%d) of %d floats)"
-                          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.time() - t3) * 1e3, g.split, store.total, bb, store.total), flush=True)
-                from . import lib
-                lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
-            if g.B2 is not None:
-                g.B2.replay()
-            return g.loss, g.loss_dict
-        if g.B2 is not None:
-            import torch.distributed as dist
+        elif ddp:
             dist.all_reduce(store.gflat, op=dist.ReduceOp.SUM)
-            from . import lib
+        if ddp:
             lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
+        if g.B2 is not None:
             g.B2.replay()
         return g.loss, g.loss_dict
 
@@ -279,8 +297,7 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
         samples = samples.to(dev)            # reference :121; for an input_pipeline.ClipBatch this IS the HIP pre-pass (uint8 frames -> fp32 batch)
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
         if graphed is not None:
-            clips = (samples.tensors if hasattr(samples, "tensors") else samples).to(dev, torch.float32)
-            loss, loss_dict = graphed(clips, targets)
+            loss, loss_dict = graphed(samples, targets)       # NestedTensor: clips AND padding mask go to the captured buffers
         else:
             loss, loss_dict = train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=epoch, cfg=cfg)
         if lr_scheduler is not None and cfg.CONFIG.TRAIN.LR_POLICY == "cosine":
