@@ -155,9 +155,20 @@ class LaunchTimer:
         return out
 
 
-def cpu_baseline(cfg, hw):
-    """CPU oracle (oracle/tuber_oracle.py: stock PyTorch CPU ops, fp32, identical graph and state dict): one full training
-    step (forward, criterion, backward, clip, AdamW) on ONE clip of the benchmark workload, all host cores."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, hw, dataset, batch=2, warm=1, timed=3):
+    """CPU oracle (oracle/tuber_oracle.py: stock PyTorch CPU ops, fp32, identical graph and state dict): full training steps
+    (forward, criterion, backward, clip, AdamW) on a batch of the benchmark workload, all host cores: ``warm`` untimed + ``timed``
+    timed steps (bounded sample: ~1 minute of CPU work)."""
     from oracle import tuber_oracle as O
     from tubelet_transformer_amd import synth
     from tubelet_transformer_amd.tuber import build_model
@@ -165,25 +176,28 @@ def cpu_baseline(cfg, hw):
     torch.set_num_threads(cores)
     model, _, _ = build_model(cfg)
     synth.load_name_hashed(model)
-    pn = [n for n, _ in model.named_parameters()]
+    pn = [n for n, p in model.named_parameters() if p.requires_grad]
     state = {k: (v.clone().requires_grad_(True) if k in pn else v.clone()) for k, v in model.state_dict().items()}
     del model
-    clips = synth.synthetic_clips(1, 32, hw[0], hw[1], seed=1234)
-    targets = synth.synthetic_targets(1, "ava", cfg.CONFIG.DATA.NUM_CLASSES, seed=4321, hw=hw)
+    clips = synth.synthetic_clips(batch, 32, hw[0], hw[1], seed=1234)
+    targets = synth.synthetic_targets(batch, dataset, cfg.CONFIG.DATA.NUM_CLASSES, seed=4321, hw=hw)
     params = [state[n] for n in pn]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
-    t0 = time.time()
-    out = O.tuber_forward(state, cfg, clips, train=True)
-    ld, _ = O.set_criterion(cfg, out, targets)
-    loss = O.total_loss(cfg, ld)
-    opt.zero_grad()
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(params, 0.1)
-    opt.step()
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "1 full training step (fwd+criterion+bwd+clip+AdamW), batch 1 of the same 3x32x%dx%d workload, fp32, "
-                      "dropout off, cold (no warm-up), %.1f s" % (hw[0], hw[1], dt)}
+    times = []
+    for i in range(warm + timed):
+        t0 = time.time()
+        out = O.tuber_forward(state, cfg, clips, train=True)
+        ld, _ = O.set_criterion(cfg, out, targets)
+        loss = O.total_loss(cfg, ld)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        times.append(time.time() - t0)
+    dt = sum(times[warm:]) / timed
+    return {"value": round(batch / dt, 5), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+            "sample": "%d warm-up + %d timed full training steps (fwd+criterion+bwd+clip+AdamW), batch %d of the same 3x32x%dx%d workload, "
+                      "fp32, dropout off; %.1f s/step (steps: %s)" % (warm, timed, batch, hw[0], hw[1], dt, " ".join("%.1f" % t for t in times))}
 
 
 def main():
@@ -192,9 +206,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (reference: TRAIN.BATCH_SIZE 2)")
-    ap.add_argument("--config", default="TubeR_CSN152_AVA21.yaml")
+    ap.add_argument("--config", default="TubeR_CSN152_AVA21.yaml", help="BASELINE.json configs: TubeR_CSN50_AVA21.yaml (2), "
+                    "TubeR_CSN152_AVA21.yaml (3, the headline), Tuber_CSN152_JHMDB.yaml (5: use --height 288 --width 384)")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=340)
+    ap.add_argument("--pretrained-freeze", action="store_true", help="freeze stem + layer1 + layer2 like the pretrained recipe "
+                    "(load_csn_mat, ir_CSN_152.py:251-254,301-303): the 704-GFLOP/clip workload of every real training run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraphs")
@@ -230,14 +247,20 @@ def main():
     torch.manual_seed(0)
     model, criterion, _ = build_model(cfg)
     synth.load_name_hashed(model)                 # random-init weights of the named architecture (no checkpoints offline)
-    model = deploy_model(model, cfg, dev)
+    if args.pretrained_freeze:
+        body = model.backbone.body
+        for mod in (body.conv1, body.bn1, body.layer1, body.layer2):
+            for p in mod.parameters():
+                p.requires_grad = False
+    model = deploy_model(model, cfg, True, device=dev)
     criterion.to(dev)
     model.train()
     criterion.train()
     optimizer = build_optimizer(model, cfg)
     hw = (args.height, args.width)
     clips = synth.synthetic_clips(args.batch, 32, hw[0], hw[1], seed=1234 + rank, device=dev)
-    targets = synth.synthetic_targets(args.batch, "ava", cfg.CONFIG.DATA.NUM_CLASSES, seed=4321 + rank, device=dev, hw=hw)
+    dataset = "ava" if cfg.CONFIG.DATA.DATASET_NAME == "ava" else "jhmdb"
+    targets = synth.synthetic_targets(args.batch, dataset, cfg.CONFIG.DATA.NUM_CLASSES, seed=4321 + rank, device=dev, hw=hw)
     max_norm = cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM
 
     def eager_step():
@@ -303,16 +326,20 @@ def main():
     dt = float(t)
     ms = 1e3 * dt / args.steps
     total_clips = args.batch * world * args.steps
+    headline = args.config == "TubeR_CSN152_AVA21.yaml" and hw == (256, 340)
+    alg_gflop = (704.0 if args.pretrained_freeze else 981.0) if headline else None      # SURVEY.md section 8d (fwd+bwd per clip)
     line = {
-        "metric": "clips/sec (TubeR CSN-152 AVA2.1 training step fwd+bwd+clip+AdamW, 32x256x340 clips; whole job)",
+        "metric": "clips/sec (TubeR CSN-152 AVA2.1 training step fwd+bwd+clip+AdamW, 32x256x340 clips; whole job)" if headline else
+                  "clips/sec (%s training step fwd+bwd+clip+AdamW, 32x%dx%d clips; whole job)" % (args.config.replace(".yaml", ""), hw[0], hw[1]),
         "value": round(total_clips / dt, 3), "unit": "clips/s", "per_gpu": round(total_clips / dt / world, 3),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights"
-                               % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1]),
+        "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights%s"
+                               % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1],
+                                  ", stem+layer1+layer2 frozen (pretrained recipe)" if args.pretrained_freeze else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce)" % world, "launch_mode": mode},
         "final_loss": round(float(loss.detach()), 4) if loss is not None else None,
-        "alg_gflop_per_clip_fwd_bwd": 981.0,
+        "alg_gflop_per_clip_fwd_bwd": alg_gflop,
         "readme_implied_gflops": round(total_clips / dt * 120.0, 1),
     }
     if rank == 0 and timer is not None:
@@ -336,10 +363,11 @@ def main():
                             "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
                             "share_of_step": round(s["ms"] / timed_steps / ms, 4)}
         line["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(prepass.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-        line["end_to_end"] = {"hbm_frac_of_alg_bytes": round(8.4e9 * total_clips / dt / (HBM_PEAK_GBS * 1e9 * world), 4),
-                              "mfma_frac_of_alg_flops": round(981e9 * total_clips / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12 * world), 4)}
+        if headline and not args.pretrained_freeze:
+            line["end_to_end"] = {"hbm_frac_of_alg_bytes": round(8.4e9 * total_clips / dt / (HBM_PEAK_GBS * 1e9 * world), 4),
+                                  "mfma_frac_of_alg_flops": round(981e9 * total_clips / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12 * world), 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfg, hw)
+        line["cpu_baseline"] = cpu_baseline(cfg, hw, dataset, batch=args.batch)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

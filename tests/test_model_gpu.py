@@ -2,7 +2,9 @@
 and against the CPU oracle run on the GPU box with the same name-hashed weights and seeded inputs.
 
 Stated tolerances for the bf16 path (bf16-autocast noise of the reference itself is 1.3e-3 .. 7.3e-3):
-  eval outputs:  |logits| err <= 5e-2 abs (class / actor logits are O(1..3)), boxes <= 1e-2 abs
+  eval outputs:  |logits| err <= 5e-2 abs (class / actor logits are O(1..3)), boxes <= 1e-2 abs, AND <= 2x the error of a
+                 bf16-rounded execution of the fp32 oracle on the same fixture (+4e-3 / +1e-3): the numbers per fixture are in
+                 DESIGN.md section 4; the BASELINE-size cases live in tests/test_fullsize_gpu.py
   train step (golden, deep bodies): the Hungarian assignment is discontinuous and training-mode BatchNorm over the
                  few samples of the tiny fixtures amplifies bf16 rounding (a bf16-ROUNDED run of the fp32 oracle itself
                  flips 12/12 assignments and decorrelates early-layer gradients: see DESIGN.md "parity"), so the golden
@@ -80,10 +82,22 @@ def test_eval_forward_matches_reference_golden(dev, golden_dir, name):
         kind = k.split(".")[-1]
         worst[kind] = max(worst.get(kind, 0.0), err)
         assert np.isfinite(v).all(), k
-    print("%-32s max abs err vs reference: %s" % (name, {k: "%.2e" % v for k, v in worst.items()}))
+    # yardstick: the same fixture through a bf16-ROUNDED execution of the fp32 oracle (parity_util.run_oracle), against the same golden
+    from parity_util import run_oracle
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cl = [c.cpu() for c in clips] if isinstance(clips, list) else clips.cpu()
+    rnd = flat_outputs(run_oracle(cfg, state, cl, train=False, rounded=True)[0])
+    yard = {}
+    for k, v in rnd.items():
+        kind = k.split(".")[-1]
+        yard[kind] = max(yard.get(kind, 0.0), float(np.abs(v - gold[k]).max()))
+    print("%-32s max abs err vs reference: hip %s | bf16-rounded oracle %s" % (name, {k: "%.2e" % v for k, v in worst.items()},
+                                                                              {k: "%.2e" % v for k, v in yard.items()}))
     assert worst["pred_boxes"] <= 1e-2
     assert worst["pred_logits"] <= 5e-2
     assert worst["pred_logits_b"] <= 5e-2
+    for kind in worst:
+        assert worst[kind] <= 2.0 * yard[kind] + (1e-3 if kind == "pred_boxes" else 4e-3), (kind, worst[kind], yard[kind])
     # post-processing on the HIP outputs vs the reference's post-processing of its own outputs
     tsz = torch.as_tensor(gold["post.target_sizes"])
     scores, boxes, out_b = post["bbox"](out, tsz)
@@ -377,29 +391,6 @@ def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE.json full size (CSN-152, 3x32x256x340) ----------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize("yaml_name", ["TubeR_CSN152_AVA21.yaml", "TubeR_CSN152_AVA22.yaml"])
-def test_full_size_eval_forward_matches_oracle(dev, yaml_name):
-    """configs[1..3] of BASELINE.json at their real size: eval forward of one 3x32x256x340 clip through the HIP path against the fp32
-    CPU oracle run live on the box's host cores (a few seconds).  Same tolerances as the reference-golden cases: boxes 1e-2, logits 5e-2."""
-    from oracle import tuber_oracle as O
-    cfg, model, _, _ = build(yaml_name, dev)
-    clips = synth.synthetic_clips(1, 32, 256, 340, seed=1234)
-    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    with torch.no_grad():
-        want = O.tuber_forward(state, cfg, clips, train=False)
-        got = model(clips.to(dev))
-    worst = {}
-    for k, v in flat_outputs(want).items():
-        g = flat_outputs(got)[k]
-        assert g.shape == v.shape and np.isfinite(g).all(), k
-        kind = k.split(".")[-1]
-        worst[kind] = max(worst.get(kind, 0.0), float(np.abs(g - v).max()))
-    print("%s full size: max abs err vs oracle %s" % (yaml_name, {k: "%.2e" % v for k, v in worst.items()}))
-    assert worst["pred_boxes"] <= 1e-2 and worst["pred_logits"] <= 5e-2 and worst["pred_logits_b"] <= 5e-2
-
-
 @pytest.mark.gpu
 def test_full_size_training_step_properties(dev):
     """size-independent properties of the whole fwd+bwd at BASELINE size (2 clips of 3x32x256x340, CSN-152, dropout on):

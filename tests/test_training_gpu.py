@@ -1,0 +1,268 @@
+"""Optimizer, frozen-parameter and captured-step semantics of the training path.
+
+  * ``csrc/optim.hip`` (sum-of-squares, clip coefficient, AdamW) against ``torch.nn.utils.clip_grad_norm_`` +
+    ``torch.optim.AdamW`` with the reference's four parameter groups (train_tuber_ava.py:41-58,
+    utils/video_action_recognition.py:150-154): fp32, <= 1e-6 relative on parameters / moments / clip coefficient;
+  * ``requires_grad = False`` parameters (the pretrained recipe freezes stem + layer1 + layer2: ir_CSN_152.py:251-254,301-303):
+    no gradient is computed or stored for them, the trainable tensors' gradients are bit-identical to the unfrozen run,
+    the clip coefficient ignores them, AdamW leaves them untouched, BatchNorm running statistics keep updating;
+  * the captured hipGraph step replays with the CURRENT batch's targets / mask, the current learning rate and loss
+    weights, i.e. it is bit-identical to the eager step sequence.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+from tubelet_transformer_amd import synth
+from tubelet_transformer_amd.config import load_cfg
+from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer, train_step
+from tubelet_transformer_amd.tuber import build_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(yaml_name, dev, body="CSN-TEST", dropout=True):
+    cfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
+    if body:
+        cfg.CONFIG.MODEL.BACKBONE_NAME = body
+    model, crit, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    if not dropout:
+        synth.zero_dropout(model)
+    model.to(dev).train()
+    crit.to(dev).train()
+    return cfg, model, crit
+
+
+def _freeze_like_load_csn_mat(model):
+    """the requires_grad pattern ``load_csn_mat(tune_point=4)`` leaves behind: stem, layer1, layer2 frozen"""
+    body = model.backbone.body
+    for mod in (body.conv1, body.bn1, body.layer1, body.layer2):
+        for p in mod.parameters():
+            p.requires_grad = False
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("frozen", [False, True])
+def test_fused_clip_adamw_matches_torch(dev, frozen):
+    cfg, model, _ = _model("TubeR_CSN152_AVA21.yaml", dev)
+    if frozen:
+        _freeze_like_load_csn_mat(model)
+    opt = build_optimizer(model, cfg)
+    store, _ = model.engine()
+    # plain-torch twin: cloned fp32 parameters in the same four groups, same hyper-parameters
+    named = list(model.named_parameters())
+    twin = {n: torch.nn.Parameter(p.detach().clone()) for n, p in named}
+    T = cfg.CONFIG.TRAIN
+    groups = [
+        {"params": [twin[n] for n, p in named if "backbone" not in n and "class_embed" not in n and "query_embed" not in n and p.requires_grad]},
+        {"params": [twin[n] for n, p in named if "backbone" in n and p.requires_grad], "lr": T.LR_BACKBONE},
+        {"params": [twin[n] for n, p in named if "class_embed" in n and p.requires_grad], "lr": T.LR},
+        {"params": [twin[n] for n, p in named if "query_embed" in n and p.requires_grad], "lr": T.LR},
+    ]
+    ref = torch.optim.AdamW(groups, lr=T.LR, weight_decay=T.W_DECAY, foreach=False)
+    trainable = [n for n, p in named if p.requires_grad]
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    for step in range(3):
+        opt.zero_grad()
+        for n, p in named:
+            if p.requires_grad:
+                g = (torch.randn(p.shape, generator=gen) * (0.05 + 0.02 * step)).to(dev)
+                p.grad.copy_(g)                       # windows of the flat gradient buffer
+                twin[n].grad = g.clone()
+            else:
+                assert p.grad is None
+        if step == 2:                                  # a scheduler step between optimizer steps must reach the kernel
+            for a, b in zip(opt.param_groups, ref.param_groups):
+                a["lr"] *= 0.5
+                b["lr"] *= 0.5
+        tot = torch.nn.utils.clip_grad_norm_([twin[n] for n in trainable], 0.1)
+        ref.step()
+        opt.step(max_norm=0.1)
+        torch.cuda.synchronize()
+        norm, coef = float(opt.norm_out[0]), float(opt.norm_out[1])
+        want_coef = min(1.0, 0.1 / (float(tot) + 1e-6))
+        assert abs(norm - float(tot)) <= 1e-5 * float(tot), (norm, float(tot))
+        assert abs(coef - want_coef) <= 1e-5 * want_coef
+        worst = 0.0
+        for n, p in named:
+            d = float((p.detach() - twin[n].detach()).abs().max())
+            scale = max(1.0, float(twin[n].detach().abs().max()))
+            worst = max(worst, d / scale)
+            if not p.requires_grad:
+                assert d == 0.0, n                     # frozen: bit-unchanged
+        assert worst <= 1e-6, worst
+        for n in trainable:
+            o = store.offsets[n]
+            k = twin[n].numel()
+            st = ref.state[twin[n]]
+            m, v = opt.exp_avg[o:o + k].view(twin[n].shape), opt.exp_avg_sq[o:o + k].view(twin[n].shape)
+            assert float((m - st["exp_avg"]).abs().max()) <= 1e-6 * max(1e-3, float(st["exp_avg"].abs().max())), n
+            assert float((v - st["exp_avg_sq"]).abs().max()) <= 1e-6 * max(1e-6, float(st["exp_avg_sq"].abs().max())), n
+        print("step %d: |g| hip %.6f torch %.6f, clip coef %.6e, worst relative parameter difference %.2e" % (step, norm, float(tot), coef, worst))
+    assert opt.t == 3
+    # optimizer state round trip (moments + step count live outside Optimizer.state)
+    sd = opt.state_dict()
+    opt2 = build_optimizer(model, cfg)
+    opt2.load_state_dict(sd)
+    assert opt2.t == 3 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
+def _surrogate(out):
+    g = torch.Generator().manual_seed(5)
+    tot = 0
+    for o in [out] + list(out.get("aux_outputs", [])):
+        for k in ("pred_logits", "pred_boxes", "pred_logits_b"):
+            tot = tot + (o[k].float() * torch.randn(o[k].shape, generator=g).to(o[k].device)).sum()
+    return tot
+
+
+def test_frozen_backbone_prefix_gradients_and_step(dev):
+    """freeze pattern of the pretrained recipe on the shallow body: (a) frozen tensors get no gradient, their windows of the flat
+    buffer stay zero; (b) every trainable gradient is bit-identical to the unfrozen run (same kernels above the cut);
+    (c) BatchNorm buffers of frozen layers still update; (d) one full step leaves the frozen tensors bit-unchanged and uses the
+    clip coefficient of the trainable gradients only."""
+    cfg, model, crit = _model("TubeR_CSN152_AVA21.yaml", dev, dropout=False)
+    store, runner = model.engine()
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=3, device=dev)
+    bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def run():
+        model.load_state_dict(bn0, strict=False)
+        store.zero_grad()
+        _surrogate(model(clips)).backward()
+        torch.cuda.synchronize()
+        return store.gflat.detach().clone()
+
+    g_full = run()
+    bn_full = {k: v.clone() for k, v in model.state_dict().items() if k in bn0}
+    _freeze_like_load_csn_mat(model)
+    plans, stem, lowest = runner.trainable_plan()
+    assert not stem["any"] and runner.blocks[lowest]["stage"] == 3 and runner.blocks[lowest]["first"]
+    g_frozen = run()
+    for k, v in model.state_dict().items():
+        if k in bn0:
+            assert torch.equal(v, bn_full[k]), k                     # (c) running statistics identical to the unfrozen run
+            if "running_mean" in k:
+                assert not torch.equal(v, bn0[k]), k
+    nfrozen, gsum = 0, 0.0
+    for n, p in model.named_parameters():
+        o = store.offsets[n]
+        w = slice(o, o + p.numel())
+        if p.requires_grad:
+            assert torch.equal(g_frozen[w], g_full[w]), n            # (b)
+        else:
+            nfrozen += 1
+            assert p.grad is None and float(g_frozen[w].abs().max()) == 0.0, n      # (a)
+            gsum += float(g_full[w].abs().sum())
+    assert nfrozen > 20 and gsum > 0.0          # ... and the unfrozen run did produce gradients there
+    # (d) one optimisation step
+    opt = build_optimizer(model, cfg)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(64, 96))
+    train_step(model, crit, opt, clips, targets, 0.1)
+    torch.cuda.synchronize()
+    tr = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).double()
+    want = math.sqrt(float((tr ** 2).sum()))
+    assert abs(float(opt.norm_out[0]) - want) <= 1e-5 * want
+    moved = 0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            moved += int(not torch.equal(p.detach(), before[n]))
+        else:
+            assert torch.equal(p.detach(), before[n]), n
+    assert moved > 100
+
+
+def test_lr_backbone_zero_skips_the_body_backward(dev):
+    """LR_BACKBONE <= 0 freezes the whole CSN body (backbone_builder.py:38-40): no body gradient, transformer gradients unchanged"""
+    cfg, model, _ = _model("TubeR_CSN152_AVA21.yaml", dev, dropout=False)
+    store, runner = model.engine()
+    clips = synth.synthetic_clips(1, 32, 64, 64, seed=4, device=dev)
+    bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    store.zero_grad()
+    _surrogate(model(clips)).backward()
+    g_full = store.gflat.detach().clone()
+    for p in model.backbone.body.parameters():
+        p.requires_grad_(False)
+    assert not runner.any_trainable()
+    model.load_state_dict(bn0, strict=False)
+    store.zero_grad()
+    _surrogate(model(clips)).backward()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        o = store.offsets[n]
+        w = slice(o, o + p.numel())
+        if n.startswith("backbone.body."):
+            assert float(store.gflat[w].abs().max()) == 0.0, n
+        else:
+            assert torch.equal(store.gflat[w], g_full[w]), n
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def _ragged_batch(dev, seed, hw=(64, 96)):
+    """two clips of different width padded to a common size: NestedTensor with a non-trivial mask"""
+    from tubelet_transformer_amd.misc import nested_tensor_from_tensor_list
+    a, b = synth.synthetic_clips(2, 32, 0, 0, seed=seed, sizes=[hw, (hw[0] - 16, hw[1] - 16)])
+    return nested_tensor_from_tensor_list([a.to(dev), b.to(dev)])
+
+
+@pytest.mark.parametrize("yaml_name,dataset", [("TubeR_CSN152_AVA21.yaml", "ava"), ("Tuber_CSN152_JHMDB.yaml", "jhmdb")])
+def test_graph_replay_tracks_batch_state_like_eager(dev, yaml_name, dataset):
+    """four steps with per-step different clips, padding masks, targets (JHMDB: key_pos and vis too), a learning-rate change after
+    step 2 and the loss_ce weight switch after step 3: the captured step must reproduce the eager sequence bit for bit"""
+    results = []
+    for graphed in (False, True):
+        cfg, model, crit = _model(yaml_name, dev)
+        opt = build_optimizer(model, cfg)
+        store, _ = model.engine()
+        store.manual_seed(321)
+        step = GraphedTrainStep(model, crit, opt, 0.1) if graphed else None
+        losses = []
+        for i in range(4):
+            samples = _ragged_batch(dev, seed=50 + i)
+            targets = synth.synthetic_targets(2, dataset, cfg.CONFIG.DATA.NUM_CLASSES, seed=70 + i, device=dev, hw=(64, 96))
+            if dataset != "ava":
+                for b, t in enumerate(targets):
+                    t["key_pos"] = torch.tensor((5 * i + 3 * b) % 32, dtype=torch.int64, device=dev)
+                    t["vis"] = torch.tensor([(i + b) % 2], dtype=torch.int64, device=dev)
+            if i == 2:
+                for gr in opt.param_groups:
+                    gr["lr"] = gr["lr"] * 0.1
+            if i == 3:
+                crit.weight_dict["loss_ce"] = 3.0
+            if graphed:
+                loss, _ = step(samples, targets)
+            else:
+                loss, _ = train_step(model, crit, opt, samples, targets, 0.1)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        if graphed:
+            assert len(step.graphs) == 1, "one clip shape -> one captured graph"
+        results.append((losses, store.flat.detach().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}, opt.t))
+    (l0, f0, b0, t0), (l1, f1, b1, t1) = results
+    print("eager losses %s\ngraph losses %s" % (l0, l1))
+    assert t0 == 4 and t1 == 4, "capture warm-up passes must not count as optimisation steps"
+    assert l0 == l1
+    assert torch.equal(f0, f1), "%d parameters differ" % int((f0 != f1).sum())
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
+def test_graph_cache_is_bounded_and_keyed_on_frozen_set(dev):
+    cfg, model, crit = _model("TubeR_CSN50_AVA21.yaml", dev)
+    opt = build_optimizer(model, cfg)
+    step = GraphedTrainStep(model, crit, opt, 0.1, max_graphs=2)
+    targets = synth.synthetic_targets(1, "ava", 80, seed=5, device=dev, hw=(64, 64))
+    for hw in ((64, 64), (64, 80), (64, 96), (64, 64)):
+        clips = synth.synthetic_clips(1, 32, hw[0], hw[1], seed=3, device=dev)
+        loss, _ = step(clips, targets)
+        assert math.isfinite(float(loss)) and len(step.graphs) <= 2
+    _freeze_like_load_csn_mat(model)
+    n = len(step.graphs)
+    step(clips, targets)
+    assert len(step.graphs) <= 2 and (tuple(clips.shape), model.engine()[0].trainable_signature(), True) in step.graphs and n <= 2
+    torch.cuda.synchronize()
