@@ -1,0 +1,197 @@
+"""Boundary rows on the device:
+
+  * checkpoints imported AFTER the engine exists (flat parameter store, bf16 shadow and transposed-weight copies already built):
+    ``load_model`` with the DDP ``module.`` prefix, ``load_detr_weights``, the Caffe2 ``.mat`` CSN loader -- the HIP path must
+    compute with the imported weights (bit-equal to a model that had them from the start);
+  * ``validate_tuber_ucf_detection`` end to end (JHMDB config): result files in the reference's format + frame-mAP.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tubelet_transformer_amd import checkpoint as ck
+from tubelet_transformer_amd import synth
+from tubelet_transformer_amd.config import load_cfg
+from tubelet_transformer_amd.tuber import build_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(yaml_name, tmp_path=None):
+    cfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
+    cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+    if tmp_path is not None:
+        cfg.CONFIG.LOG.BASE_PATH, cfg.CONFIG.LOG.EXP_NAME, cfg.CONFIG.LOG.RES_DIR = str(tmp_path), "exp", "tmp_res"
+    return cfg
+
+
+def _outputs(model, clips):
+    model.eval()
+    with torch.no_grad():
+        o = model(clips)
+    return {k: o[k].detach().clone() for k in ("pred_logits", "pred_boxes", "pred_logits_b")}
+
+
+def _same(a, b):
+    return all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_checkpoint_import_after_engine_drives_the_hip_path(dev, tmp_path):
+    cfg = _cfg("TubeR_CSN152_AVA21.yaml", tmp_path)
+    clips = synth.synthetic_clips(1, 32, 64, 96, seed=8, device=dev)
+    src, _, _ = build_model(cfg)
+    synth.load_name_hashed(src, salt=3)
+    src.to(dev)
+    want = _outputs(src, clips)
+    path = ck.save_checkpoint(cfg, 3, src, 0.0, None, None)             # keys carry the DDP "module." prefix like the released files
+    assert all(k.startswith("module.") for k in torch.load(path, weights_only=False)["model"])
+    # fresh model, engine built and used BEFORE the import
+    dst, _, _ = build_model(cfg)
+    synth.load_name_hashed(dst, salt=0)
+    dst.to(dev)
+    store, _ = dst.engine()
+    before = _outputs(dst, clips)
+    assert not _same(before, want)
+    cfg.CONFIG.MODEL.PRETRAINED_PATH = path
+    ck.load_model(dst, cfg)
+    assert dst.engine()[0] is store and store.valid()                  # in-place copies: the flat store and its views survive
+    assert _same(_outputs(dst, clips), want)
+    for n, p in dst.named_parameters():                                # every parameter is still a window of the flat buffer
+        o = store.offsets[n]
+        assert p.data_ptr() == store.flat.data_ptr() + 4 * o, n
+    # wrong-shape checkpoint must raise, not load partially (reference: load_state_dict)
+    bad = torch.load(path, weights_only=False)
+    bad["model"]["module.class_fc.weight"] = torch.zeros(7, 256)
+    bad_path = str(tmp_path / "bad.pth")
+    torch.save(bad, bad_path)
+    cfg.CONFIG.MODEL.PRETRAINED_PATH = bad_path
+    with pytest.raises(RuntimeError):
+        ck.load_model(dst, cfg)
+
+    # DETR initialisation (transformer.*, bbox_embed.*, first QUERY_NUM rows of query_embed) into a live engine
+    detr = {"model": {"detr." + k: v.detach().cpu().clone() for k, v in src.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
+    qe = torch.randn(100, 256, generator=torch.Generator().manual_seed(1))
+    detr["model"]["detr.query_embed.weight"] = qe
+    dpath = str(tmp_path / "detr.pth")
+    torch.save(detr, dpath)
+    m3, _, _ = build_model(cfg)
+    synth.load_name_hashed(m3, salt=0)
+    m3.to(dev)
+    _outputs(m3, clips)
+    ck.load_detr_weights(m3, dpath, cfg)
+    assert torch.equal(m3.query_embed.weight.detach().cpu(), qe[:15])
+    m4, _, _ = build_model(cfg)                                         # twin that has the same weights from the start
+    m4.load_state_dict({k: v.detach().cpu() for k, v in m3.state_dict().items()})
+    m4.to(dev)
+    assert _same(_outputs(m3, clips), _outputs(m4, clips))
+
+
+def _fake_csn_mat(body, path, seed=0):
+    import scipy.io as sio
+    rng = np.random.default_rng(seed)
+    mat, count = {}, 0
+
+    def bn(name, c):
+        mat[name + "_s"] = (1.0 + 0.1 * rng.standard_normal((1, c))).astype(np.float32)
+        mat[name + "_b"] = (0.1 * rng.standard_normal((1, c))).astype(np.float32)
+        mat[name + "_rm"] = (0.1 * rng.standard_normal((1, c))).astype(np.float32)
+        mat[name + "_riv"] = (1.0 + 0.2 * rng.random((1, c))).astype(np.float32)
+    mat["conv1_w"] = (rng.standard_normal((64, 3, 3, 7, 7)) / 21.0).astype(np.float32)
+    bn("conv1_spatbn_relu", 64)
+    for stage in (body.layer1, body.layer2, body.layer3, body.layer4):
+        for blk in stage:
+            for j, conv in ((1, blk.conv1), (3, blk.conv3), (4, blk.conv4)):
+                w = conv.weight
+                mat["comp_%d_conv_%d_w" % (count, j)] = (rng.standard_normal(tuple(w.shape)) / np.sqrt(w[0].numel())).astype(np.float32)
+                bn("comp_%d_spatbn_%d" % (count, j), w.shape[0])
+            if blk.down_sample is not None:
+                w = blk.down_sample[0].weight
+                mat["shortcut_projection_%d_w" % count] = (rng.standard_normal(tuple(w.shape)) / np.sqrt(w[0].numel())).astype(np.float32)
+                bn("shortcut_projection_%d_spatbn" % count, w.shape[0])
+            count += 1
+    sio.savemat(path, mat)
+
+
+def test_csn_mat_import_into_live_engine_then_frozen_training_step(dev, tmp_path):
+    """the pretrained recipe end to end: Caffe2 .mat weights into a model whose engine already exists, stem + layer1 + layer2
+    frozen by the loader (ir_CSN_152.py:251-254,301-303), then one optimisation step: frozen tensors bit-unchanged, their
+    BatchNorm running statistics still moving, trainable tensors updated."""
+    from tubelet_transformer_amd.training import build_optimizer, train_step
+    cfg = _cfg("TubeR_CSN152_AVA21.yaml", tmp_path)
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=8, device=dev)
+    m, crit, _ = build_model(cfg)
+    synth.load_name_hashed(m)
+    m.to(dev)
+    crit.to(dev)
+    before = _outputs(m, clips)
+    path = str(tmp_path / "csn.mat")
+    _fake_csn_mat(m.backbone.body, path)
+    ck.load_csn_mat(m.backbone.body, path, "CSN-TEST", verbose=False)
+    assert m.engine()[0].valid()
+    after = _outputs(m, clips)
+    assert not _same(before, after)
+    twin, _, _ = build_model(cfg)                                        # same weights from the start
+    twin.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    twin.to(dev)
+    assert _same(after, _outputs(twin, clips))
+    body = m.backbone.body
+    assert not body.conv1.weight.requires_grad and not body.layer2[1].bn3.weight.requires_grad and body.layer3[0].conv1.weight.requires_grad
+    m.train()
+    crit.train()
+    opt = build_optimizer(m, cfg)
+    p0 = {n: p.detach().clone() for n, p in m.named_parameters()}
+    rm0 = body.layer1[0].bn1.running_mean.clone()
+    targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(64, 96))
+    loss, _ = train_step(m, crit, opt, clips, targets, 0.1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert not torch.equal(rm0, body.layer1[0].bn1.running_mean)
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            continue
+        assert p.grad is None and torch.equal(p.detach(), p0[n]), n
+    assert not torch.equal(body.layer3[0].conv1.weight.detach(), p0["backbone.body.layer3.0.conv1.weight"])
+
+
+def test_ucf_validation_loop_writes_reference_format_and_scores(dev, tmp_path):
+    """validate_tuber_ucf_detection (utils/video_action_recognition.py:456-689) over a two-batch synthetic JHMDB-style loader"""
+    from tubelet_transformer_amd.evaluation import validate_tuber_ucf_detection
+    cfg = _cfg("Tuber_CSN152_JHMDB.yaml", tmp_path)
+    model, criterion, post = build_model(cfg)
+    synth.load_name_hashed(model)
+    model.to(dev)
+    criterion.to(dev)
+    H, W = 64, 64
+    Q, nc = cfg.CONFIG.MODEL.QUERY_NUM, cfg.CONFIG.DATA.NUM_CLASSES
+    loader, nclips = [], 0
+    for i in range(2):
+        clips = synth.synthetic_clips(2, 32, H, W, seed=10 + i)
+        tg = synth.synthetic_targets(2, "jhmdb", nc, seed=20 + i, device="cpu", hw=(H, W))
+        for b, t in enumerate(tg):
+            kp = (7 * i + 3 * b) % 32
+            t["key_pos"] = torch.tensor(kp, dtype=torch.int64)
+            t["image_id"] = ["clip%d_%05d" % (i, 10 + b), kp]
+            t["size"] = torch.tensor([H, W])
+            raw = torch.zeros(1, 6)
+            raw[:, 0] = 2 * i + b                  # running clip index; the loop maps it back through the batch's first index
+            raw[:, 1] = kp
+            raw[:, 2:] = torch.tensor([4.0 + b, 6.0, 40.0 + 3 * i, 50.0])
+            t["raw_boxes"] = raw
+            nclips += 1
+        loader.append((clips, tg))
+    mAP = validate_tuber_ucf_detection(cfg, model, criterion, post, loader, epoch=0, writer=None, verbose=False)
+    assert mAP == mAP and 0.0 <= mAP <= 1.0
+    res = os.path.join(str(tmp_path), "tmp_res")
+    det = open(os.path.join(res, "0.txt")).read().splitlines()
+    gt = open(os.path.join(res, "GT_0.txt")).read().splitlines()
+    binary = open(os.path.join(res, "binary_0.txt")).read().splitlines()
+    assert len(det) == nclips * Q and len(binary) == nclips * Q and len(gt) == nclips
+    key, rest = det[0].split(" [")
+    vals = [float(v) for v in rest.split("]")[0].split(",")]
+    assert key == "clip0_00010" and len(vals) == 4 + nc + 1
+    assert abs(sum(vals[4:]) - 1.0) < 1e-4                                  # softmax over the C classes + no-object
+    gvals = [float(v) for v in gt[0].split(" [")[1].split("]")[0].split(",")]
+    assert len(gvals) == 6 + 21 and sum(gvals[6:]) == 1.0

@@ -334,3 +334,59 @@ def test_frame_map_matches_reference_evaluator_golden(tmp_path):
     vals = [float(x) for x in lines[2].split(" [")[1].split("]")[0].split(",")]
     assert np.array_equal(np.asarray(vals), np.concatenate([boxes[2], sc[2], bn[2]]))
     assert len(open(gp).read().splitlines()) == 2
+
+
+def test_frame_map_ucf_matches_reference_evaluator(tmp_path):
+    """FrameMAPUCF == the reference's STDetectionEvaluaterUCF (evaluates/evaluate_ucf.py) on JHMDB-style result files with a tiny
+    (< 10 px^2) ground-truth box, frames without ground truth, 'no object on top' detections and score ties: same bits."""
+    from tubelet_transformer_amd.evaluation import FrameMAPUCF
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "frame_map_ucf_case.json")))
+    gp, dp = str(tmp_path / "GT_0.txt"), str(tmp_path / "0.txt")
+    open(gp, "w").write("\n".join(g["gt_lines"]) + "\n")
+    open(dp, "w").write("\n".join(g["det_lines"]) + "\n")
+    ev = FrameMAPUCF(class_num=g["class_num"])
+    ev.load_gt([gp])
+    ev.load_detections([dp])
+    mAP, per_class = ev.evaluate()
+    assert mAP == g["mAP"]
+    want = [v for v in g["per_class_ap"].values()]
+    for cls in range(1, 25):
+        assert per_class.get(cls) == want[cls - 1], cls
+
+
+def _launch_main(cfg):
+    import torch.distributed as dist
+    t = torch.ones(1) * (cfg.DDP_CONFIG.GPU_WORLD_RANK + 1)
+    if cfg.DDP_CONFIG.DISTRIBUTED:
+        dist.all_reduce(t)
+    open(os.path.join(cfg.CONFIG.LOG.BASE_PATH, "rank%d.txt" % cfg.DDP_CONFIG.GPU_WORLD_RANK), "w").write(
+        "%d %d %d" % (int(t), cfg.DDP_CONFIG.GPU, cfg.DDP_CONFIG.GPU_WORLD_SIZE))
+    if cfg.DDP_CONFIG.DISTRIBUTED:
+        dist.destroy_process_group()
+
+
+def test_spawn_workers_and_reference_call_forms(tmp_path):
+    """pipelines/launch.py:spawn_workers(main, cfg) with the reference's argument list: one worker process per device, process
+    group from DDP_CONFIG (gloo here, two CPU workers), main(cfg) with GPU / GPU_WORLD_RANK / GPU_WORLD_SIZE filled in; and the
+    signatures the reference scripts call: deploy_model(model, cfg, is_tuber=True), validate_tuber_ucf_detection(cfg, model,
+    criterion, postprocessors, data_loader, epoch, writer)."""
+    import inspect
+    from pipelines.launch import spawn_workers
+    from utils.model_utils import deploy_model, load_detr_weights, load_model, save_checkpoint  # noqa: F401
+    from utils.video_action_recognition import train_tuber_detection, validate_tuber_detection, validate_tuber_ucf_detection  # noqa: F401
+    assert list(inspect.signature(deploy_model).parameters)[:3] == ["model", "cfg", "is_tuber"]
+    assert list(inspect.signature(validate_tuber_ucf_detection).parameters)[:7] == ["cfg", "model", "criterion", "postprocessors", "data_loader", "epoch", "writer"]
+    assert list(inspect.signature(spawn_workers).parameters)[:2] == ["main", "cfg"]
+    cfg = cfg_of("TubeR_CSN50_AVA21")
+    cfg.CONFIG.LOG.BASE_PATH = str(tmp_path)
+    cfg.DDP_CONFIG.DISTRIBUTED = True
+    cfg.DDP_CONFIG.DIST_BACKEND = "gloo"
+    cfg.DDP_CONFIG.DIST_URL = "tcp://127.0.0.1:%d" % (23000 + os.getpid() % 2000)
+    cfg.DDP_CONFIG.WORLD_SIZE, cfg.DDP_CONFIG.WORLD_RANK = 1, 0
+    spawn_workers(_launch_main, cfg, nprocs=2)
+    got = sorted(open(str(tmp_path / ("rank%d.txt" % r))).read() for r in range(2))
+    assert got == ["3 0 2", "3 1 2"], got
+    cfg.DDP_CONFIG.DISTRIBUTED = False
+    cfg.DDP_CONFIG.GPU, cfg.DDP_CONFIG.GPU_WORLD_RANK = 0, 0
+    spawn_workers(_launch_main, cfg, nprocs=1)
+    assert open(str(tmp_path / "rank0.txt")).read().split()[0] == "1"

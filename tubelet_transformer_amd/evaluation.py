@@ -153,7 +153,13 @@ class FrameMAP:
             t = t[order]
             ctp = np.cumsum(t).astype(float); cfp = np.cumsum(~t).astype(float)
             per_class[cls] = _average_precision(ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps), ctp / n_gt[cls])
-        mAP = float(np.mean(list(per_class.values()))) if per_class else float("nan")
+        # the reference's mean: np.nanmean over an array indexed by class id up to the largest category id, NaN where a class has
+        # no ground truth (object_detection_evaluation.py: average_precision_per_class) -- same summation order, same bits
+        ncat = getattr(self, "num_categories", None) or (max(self.whitelist) if self.whitelist else self.class_num)
+        arr = np.full(max(ncat, max(per_class) if per_class else 0), np.nan)
+        for cls, ap in per_class.items():
+            arr[cls - 1] = ap
+        mAP = float(np.nanmean(arr)) if per_class else float("nan")
         return mAP, per_class
 
 
@@ -260,5 +266,143 @@ def validate_tuber_detection(cfg, model, criterion, postprocessors, data_loader,
         if writer is not None:
             writer.add_scalar("val/val_mAP_epoch", mAP, epoch)
     if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    return mAP
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# JHMDB / UCF101-24 (utils/video_action_recognition.py:456-689, evaluates/evaluate_ucf.py)
+# ---------------------------------------------------------------------------------------------------------------------
+class FrameMAPUCF(FrameMAP):
+    """``STDetectionEvaluaterUCF`` semantics (evaluates/evaluate_ucf.py:22-166) on top of the same PASCAL matching:
+    ground-truth lines whose box is smaller than 10 px^2 put their image on an exclude list (:60-62); a detection line is
+    ``[x1,y1,x2,y2, <C class probabilities>, <no-object probability>]`` and counts ONCE, as its arg-max class with that score,
+    unless the no-object column is the overall arg-max (:109-126).  Pinned against the reference evaluator by
+    ``oracle/gen_eval_golden.py`` -> ``tests/golden/frame_map_ucf_case.json``."""
+
+    def __init__(self, class_num=24, iou_threshold=0.5):
+        super().__init__(class_num, None, (), iou_threshold)
+        self.num_categories = 24          # evaluate_ucf.py:15-20: the category list is the 24 UCF101-24 names whatever class_num is
+
+    def load_gt(self, paths):
+        for path in paths:
+            for line in open(path):
+                key, v = _parse(line)
+                if (v[4] - v[2]) * (v[5] - v[3]) < 10:
+                    self.exclude.add(key)
+                    continue
+                labels = np.asarray(v[6:])
+                self.gt.setdefault(key, [])
+                for x in np.nonzero(~(labels <= 1e-2))[0]:
+                    self.gt[key].append((int(x) + 1, np.asarray(v[2:6], dtype=float)))
+        self.gt = {k: g for k, g in self.gt.items() if g}
+
+    def load_detections(self, paths):
+        for path in paths:
+            for line in open(path):
+                key, v = _parse(line)
+                if key in self.exclude:
+                    continue
+                rest = np.asarray(v[4:])
+                if int(np.argmax(rest)) == len(rest) - 1:
+                    continue
+                scores = np.asarray(v[4:self.class_num + 4])
+                x = int(np.argmax(scores))
+                self.det.setdefault(key, []).append((x + 1, np.asarray(v[0:4], dtype=float), float(scores[x])))
+
+
+@torch.no_grad()
+def validate_tuber_ucf_detection(cfg, model, criterion, postprocessors, data_loader, epoch, writer=None, verbose=True):
+    """utils/video_action_recognition.py:456-689 (called by train_tuber_jhmdb.py:83 / eval_tuber_jhmdb.py:77): eval-mode forward on
+    the HIP path, ``PostProcess``, the key frame's QUERY_NUM tubelet queries of every clip written to ``{rank}.txt`` (box + C+1
+    class probabilities), ``binary_{rank}.txt`` (visibility probabilities) and ``GT_{rank}.txt`` (raw box + one-hot label), then
+    frame-mAP@0.5 by ``FrameMAPUCF`` on rank 0.  Differences from the reference: barriers only when torch.distributed is
+    initialised; the one-hot width is max(21, NUM_CLASSES) (the reference hard-codes 21, :564, which UCF101-24 would overflow)."""
+    import torch.distributed as dist
+    C = cfg.CONFIG
+    ddp = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if ddp else 0
+    world = dist.get_world_size() if ddp else 1
+    model.eval()
+    criterion.eval()
+    dev = next(model.parameters()).device
+    res = os.path.join(C.LOG.BASE_PATH, C.LOG.RES_DIR)
+    if rank == 0:
+        os.makedirs(res, exist_ok=True)
+        for p in glob.glob(os.path.join(res, "*.txt")):
+            os.remove(p)
+    Q, nc = C.MODEL.QUERY_NUM, C.DATA.NUM_CLASSES
+    width = max(21, nc)
+    buff_output, buff_anno, buff_id, buff_binary, gt_label, gt_anno, gt_id = [], [], [], [], [], [], []
+    meters = {k: [0.0, 0] for k in ("loss", "loss_bbox", "loss_giou", "loss_ce", "class_error")}
+    end = time.time()
+    for idx, data in enumerate(data_loader):
+        samples, targets = data[0], data[1]
+        samples = samples.to(dev)
+        batch_id = [t["image_id"] for t in targets]
+        targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
+        outputs = model(samples)
+        loss_dict = criterion(outputs, targets)
+        sizes = torch.stack([t["size"] for t in targets], dim=0)
+        scores, boxes, output_b = postprocessors["bbox"](outputs, sizes)
+        for b in range(scores.shape[0]):
+            raw = targets[b]["raw_boxes"]
+            if len(raw) == 0:
+                continue
+            frame_id, key_pos = batch_id[b][0], int(batch_id[b][1])
+            buff_output.append(scores[b, key_pos * Q:(key_pos + 1) * Q, :])
+            buff_anno.append(boxes[b, key_pos * Q:(key_pos + 1) * Q, :])
+            for _ in range(Q):
+                buff_id.append(frame_id)
+                buff_binary.append(output_b[..., 0])
+            lab = targets[b]["labels"]
+            onehot = np.zeros((len(lab), width), dtype=np.int64)
+            for i in range(len(lab)):
+                onehot[i, int(lab[i])] = 1
+            raw = raw.reshape(-1, raw.shape[-1])
+            gt_label.append(onehot)
+            gt_anno.append(raw.detach().cpu().numpy())
+            first = float(targets[0]["raw_boxes"].reshape(-1, raw.shape[-1])[0, 0])
+            gt_id.extend(batch_id[int(float(raw[x, 0]) - first)][0] for x in range(len(raw)))
+        wd = criterion.weight_dict
+        total = float(sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd))
+        if not math.isfinite(total):
+            raise FloatingPointError("loss is %r in evaluation: %r" % (total, {k: float(v) for k, v in loss_dict.items()}))
+        n = len(targets)
+        for k, v in (("loss", total), ("loss_bbox", loss_dict["loss_bbox"]), ("loss_giou", loss_dict["loss_giou"]),
+                     ("loss_ce", loss_dict["loss_ce"]), ("class_error", loss_dict["class_error"])):
+            meters[k][0] += float(v) * n; meters[k][1] += n
+        if verbose and rank == 0:
+            print("Epoch: [%d][%d/%d]  batch time %.3f  " % (epoch, idx + 1, len(data_loader), time.time() - end) +
+                  ", ".join("%s: %.3f" % (k, s / max(c, 1)) for k, (s, c) in meters.items()))
+        end = time.time()
+    if writer is not None and rank == 0:
+        for k, name in (("class_error", "class_error"), ("loss", "totall_loss"), ("loss_bbox", "loss_bbox"), ("loss_giou", "loss_giou"), ("loss_ce", "loss_ce")):
+            writer.add_scalar("val/" + name, meters[k][0] / max(meters[k][1], 1), epoch)
+    cat = lambda xs, w: np.concatenate(xs, axis=0) if xs else np.zeros((0, w))
+    out_a, anno_a = cat(buff_output, nc + 1), cat(buff_anno, 4)
+    gl, ga = cat(gt_label, width), cat(gt_anno, 6)
+    with open(os.path.join(res, "%d.txt" % rank), "w") as f:
+        for x in range(len(buff_id)):
+            f.write("{} {}\n".format(buff_id[x], np.concatenate([anno_a[x], out_a[x]]).tolist()))
+    with open(os.path.join(res, "binary_%d.txt" % rank), "w") as f:
+        for x in range(len(buff_id)):
+            f.write("{} {}\n".format(buff_id[x], np.asarray(buff_binary[x]).tolist()))
+    with open(os.path.join(res, "GT_%d.txt" % rank), "w") as f:
+        for x in range(len(gt_id)):
+            f.write("{} {}\n".format(gt_id[x], np.concatenate([ga[x], gl[x]]).tolist()))
+    if ddp:
+        dist.barrier()
+    mAP = 0
+    if rank == 0:
+        ev = FrameMAPUCF(class_num=nc)
+        ev.load_gt([os.path.join(res, "GT_%d.txt" % r) for r in range(world)])
+        ev.load_detections([os.path.join(res, "%d.txt" % r) for r in range(world)])
+        mAP, per_class = ev.evaluate()
+        if verbose:
+            print("mAP: %.5f" % mAP)
+        if writer is not None:
+            writer.add_scalar("val/val_mAP_epoch", mAP, epoch)
+    if ddp:
         dist.barrier()
     return mAP
