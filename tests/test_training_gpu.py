@@ -266,3 +266,119 @@ def test_graph_cache_is_bounded_and_keyed_on_frozen_set(dev):
     step(clips, targets)
     assert len(step.graphs) <= 2 and (tuple(clips.shape), model.engine()[0].trainable_signature(), True) in step.graphs and n <= 2
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the N > 1 code path on ONE GPU: a one-rank RCCL communicator (csrc/collective.cpp) forced through the DDP branch
+# ------------------------------------------------------------------------------------------------------------------------------
+def _ddp_run(dev, mode, monkeypatch, steps=2):
+    from tubelet_transformer_amd.ddp import attach_reducer
+    for k in ("TUBER_RCCL_IN_GRAPH", "TUBER_DDP_BF16", "TUBER_FORCE_SPLIT_GRAPH"):
+        monkeypatch.delenv(k, raising=False)
+    if mode == "in_graph":
+        monkeypatch.setenv("TUBER_RCCL_IN_GRAPH", "1")
+    if mode == "bf16":
+        monkeypatch.setenv("TUBER_DDP_BF16", "1")
+    cfg, model, crit = _model("TubeR_CSN50_AVA21.yaml", dev)
+    opt = build_optimizer(model, cfg)
+    store, _ = model.engine()
+    red = None
+    if mode != "single" and mode != "single_eager":
+        red = attach_reducer(store, force=True)
+        assert red is not None and red.comm is not None and red.comm.version >= 20000 and red.world == 1
+    store.manual_seed(99)
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=3, device=dev)
+    targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(64, 96))
+    eager = mode in ("eager", "single_eager")
+    step = None if eager else GraphedTrainStep(model, crit, opt, 0.1)
+    for _ in range(steps):
+        if eager:
+            loss, _ = train_step(model, crit, opt, clips, targets, 0.1)
+        else:
+            loss, _ = step(clips, targets)
+    torch.cuda.synchronize()
+    info = {}
+    if red is not None:
+        info["issued"] = red.issued
+        info["trainable"] = sum(b - a for a, b in store.trainable_ranges())
+        if step is not None:
+            g = next(iter(step.graphs.values()))
+            info["split"] = g.A2 is not None
+            info["in_graph"] = g.in_graph
+        red.comm.close()
+    return float(loss), store.flat.detach().clone(), info
+
+
+def test_one_rank_rccl_communicator_drives_the_ddp_step(dev, monkeypatch):
+    """RCCL init through the C ABI, ncclAllReduce on the reducer's own stream, the cut graph (A / all-reduce / A2 / all-reduce / B2),
+    the in-graph capture of the collectives, the eager hook path and the bf16-compressed transport -- all on a one-rank
+    communicator, so the results must equal the plain single-GPU step (bit for bit; bf16 compression within its rounding)."""
+    l0, f0, _ = _ddp_run(dev, "single", monkeypatch)
+    l1, f1, i1 = _ddp_run(dev, "split", monkeypatch)
+    assert i1["split"] and not i1["in_graph"] and i1["issued"] == i1["trainable"], i1
+    assert l1 == l0 and torch.equal(f1, f0)
+    l2, f2, i2 = _ddp_run(dev, "in_graph", monkeypatch)
+    assert i2["in_graph"] and not i2["split"], i2
+    assert l2 == l0 and torch.equal(f2, f0)
+    l3, f3, _ = _ddp_run(dev, "single_eager", monkeypatch)
+    l4, f4, i4 = _ddp_run(dev, "eager", monkeypatch)
+    assert i4["issued"] == i4["trainable"], i4
+    assert l4 == l3 and torch.equal(f4, f3)
+    l5, f5, i5 = _ddp_run(dev, "bf16", monkeypatch)
+    assert i5["issued"] == i5["trainable"]
+    assert abs(l5 - l0) <= 1e-2 * abs(l0) and float((f5 - f0).abs().max()) <= 1e-3
+
+
+_NCCL_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tubelet_transformer_amd import synth
+from tubelet_transformer_amd.config import load_cfg
+from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer, deploy_model
+from tubelet_transformer_amd.tuber import build_model
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1)
+cfg = load_cfg(os.path.join(sys.argv[1], "configuration", "TubeR_CSN50_AVA21.yaml"))
+cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+cfg.DDP_CONFIG.GPU = 0
+model, crit, _ = build_model(cfg)
+synth.load_name_hashed(model)
+model = deploy_model(model, cfg, is_tuber=True)
+crit.to("cuda:0")
+model.train(); crit.train()
+store, _ = model.engine()
+assert (store.reducer is not None) == bool(os.environ.get("TUBER_FORCE_DDP"))
+if store.reducer is not None:
+    assert store.reducer.comm is not None        # own RCCL communicator next to torch's nccl process group
+    t = torch.ones(4, device="cuda:0"); dist.all_reduce(t); assert float(t.sum()) == 4.0
+opt = build_optimizer(model, cfg)
+store.manual_seed(99)
+clips = synth.synthetic_clips(2, 32, 64, 96, seed=3, device="cuda:0")
+targets = synth.synthetic_targets(2, "ava", 80, seed=5, device="cuda:0", hw=(64, 96))
+step = GraphedTrainStep(model, crit, opt, 0.1)
+for _ in range(2):
+    loss, _ = step(clips, targets)
+torch.cuda.synchronize()
+print("RESULT %.9e %.17e %d" % (float(loss), float(store.flat.double().sum()), int(store.reducer.issued) if store.reducer is not None else 0))
+dist.destroy_process_group()
+"""
+
+
+def test_deploy_model_under_a_one_rank_nccl_process_group(tmp_path):
+    """the reference's launch shape (init_process_group('nccl') then deploy_model(model, cfg, is_tuber=True)) in a fresh process, with
+    and without the forced DDP branch: the own communicator coexists with torch's process group (one RCCL instance), results equal"""
+    import subprocess
+    import sys
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_NCCL_WORKER)
+    out = []
+    for i, force in enumerate((False, True)):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("TUBER_FORCE_DDP", None)
+        if force:
+            env["TUBER_FORCE_DDP"] = "1"
+        r = subprocess.run([sys.executable, script, ROOT, str(29600 + os.getpid() % 300 + i)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        out.append(line)
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2], out
+    assert int(out[1][3]) > 0 and int(out[0][3]) == 0

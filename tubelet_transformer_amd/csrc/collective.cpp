@@ -1,0 +1,163 @@
+// Gradient all-reduce over xGMI: RCCL bound directly (reference: the
+// DistributedDataParallel wrapper of utils/model_utils.py:43-52 whose backward hooks all-reduce gradient buckets over NCCL).
+//
+// One communicator per process (= per GPU).  ncclAllReduce is enqueued by the caller on a HIP stream it owns (the reducer's side
+// stream, event-ordered against the backward stream), in place on windows of the flat fp32 gradient buffer -- no bucket copies.
+// librccl is resolved at run time with dlopen("librccl.so.1"): inside a PyTorch process that is the RCCL instance torch already
+// loaded (one RCCL per process), in a plain C host it is ROCm's.  Nothing here needs torch: a C host passes raw pointers.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#define TUBER_OK 0
+#define TUBER_EINVAL (-1)
+#define TUBER_ENOLIB (-2)
+
+namespace {
+
+// the stable subset of the NCCL/RCCL C API (rccl.h): opaque communicator, 128-byte unique id, enum values fixed by the ABI
+typedef struct { char internal[128]; } UniqueId;
+typedef void* Comm;
+enum { kFloat32 = 7, kBfloat16 = 9, kSum = 0 };
+
+struct Api {
+    void* handle = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Api g_api;
+std::mutex g_mu;
+std::string g_err;
+
+void set_err(const std::string& s) {
+    std::lock_guard<std::mutex> l(g_mu);
+    g_err = s;
+}
+
+int fail(const char* what, int rc) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (rccl result %d)", what, g_api.GetErrorString ? g_api.GetErrorString(rc) : "?", rc);
+    set_err(buf);
+    return rc == 0 ? TUBER_EINVAL : rc;
+}
+
+int load_api() {
+    static std::once_flag once;
+    static int status = TUBER_ENOLIB;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* h = nullptr;
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            set_err(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"));
+            return;
+        }
+        g_api.handle = h;
+#define SYM(field, name)                                                   \
+    g_api.field = (decltype(g_api.field))dlsym(h, name);                   \
+    if (!g_api.field) { set_err(std::string("librccl lacks ") + name); return; }
+        SYM(GetVersion, "ncclGetVersion")
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllReduce, "ncclAllReduce")
+        SYM(GroupStart, "ncclGroupStart")
+        SYM(GroupEnd, "ncclGroupEnd")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        status = TUBER_OK;
+    });
+    return status;
+}
+
+}  // namespace
+
+extern "C" {
+
+// RCCL version code (e.g. 22606) or a negative error when librccl cannot be loaded.
+int tuber_comm_version(void) {
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    int v = 0;
+    const int rc = g_api.GetVersion(&v);
+    return rc == 0 ? v : fail("ncclGetVersion", rc);
+}
+
+// message of the last failing tuber_comm_* call (valid until the next failure).
+const char* tuber_comm_last_error(void) {
+    std::lock_guard<std::mutex> l(g_mu);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+// rank 0: fill the 128-byte rendez-vous id that every rank passes to tuber_comm_init (ship it over any side channel).
+int tuber_comm_unique_id(void* id128) {
+    if (!id128) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    UniqueId id;
+    const int rc = g_api.GetUniqueId(&id);
+    if (rc != 0) return fail("ncclGetUniqueId", rc);
+    memcpy(id128, &id, sizeof id);
+    return TUBER_OK;
+}
+
+// collective: every rank calls it with the same id; binds the communicator to HIP device `device`.
+int tuber_comm_init(const void* id128, int nranks, int rank, int device, void** comm_out) {
+    if (!id128 || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { set_err(std::string("hipSetDevice: ") + hipGetErrorString(e)); return (int)e; }
+    UniqueId id;
+    memcpy(&id, id128, sizeof id);
+    Comm c = nullptr;
+    const int rc = g_api.CommInitRank(&c, nranks, id, rank);
+    if (rc != 0) return fail("ncclCommInitRank", rc);
+    *comm_out = c;
+    return TUBER_OK;
+}
+
+// in-place sum over all ranks of buf[0..count) (dtype 0 = fp32, 1 = bf16), enqueued on `stream`; capturable into a hipGraph.
+int tuber_comm_allreduce_sum(void* comm, void* buf, long count, int dtype, hipStream_t stream) {
+    if (!comm || !buf || count <= 0 || (dtype != 0 && dtype != 1)) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    const int rc = g_api.AllReduce(buf, buf, (size_t)count, dtype == 0 ? kFloat32 : kBfloat16, kSum, (Comm)comm, stream);
+    return rc == 0 ? TUBER_OK : fail("ncclAllReduce", rc);
+}
+
+// several windows as ONE RCCL group (one launch on the stream): ptrs[i] / counts[i] are host arrays of n entries.
+int tuber_comm_allreduce_sum_multi(void* comm, void* const* ptrs, const long* counts, int n, int dtype, hipStream_t stream) {
+    if (!comm || !ptrs || !counts || n <= 0 || (dtype != 0 && dtype != 1)) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    int rc = g_api.GroupStart();
+    if (rc != 0) return fail("ncclGroupStart", rc);
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] <= 0) continue;
+        rc = g_api.AllReduce(ptrs[i], ptrs[i], (size_t)counts[i], dtype == 0 ? kFloat32 : kBfloat16, kSum, (Comm)comm, stream);
+        if (rc != 0) { g_api.GroupEnd(); return fail("ncclAllReduce", rc); }
+    }
+    rc = g_api.GroupEnd();
+    return rc == 0 ? TUBER_OK : fail("ncclGroupEnd", rc);
+}
+
+int tuber_comm_destroy(void* comm) {
+    if (!comm) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    const int rc = g_api.CommDestroy((Comm)comm);
+    return rc == 0 ? TUBER_OK : fail("ncclCommDestroy", rc);
+}
+
+}  // extern "C"

@@ -12,6 +12,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_comm_version": "RCCL bound at run time (dlopen librccl.so.1: the instance the host process already loaded, else ROCm's): its version code, "
+                          "or < 0 when it cannot be loaded. Replaces the NCCL process group the reference's DistributedDataParallel wrapper uses "
+                          "(utils/model_utils.py:43-52, pipelines/launch.py:44-49).",
+    "tuber_comm_last_error": "message of the last failing tuber_comm_* call.",
+    "tuber_comm_unique_id": "ncclGetUniqueId: rank 0 fills the 128-byte rendez-vous id (HOST memory) that every rank hands to tuber_comm_init "
+                            "(shipped over any side channel: torch.distributed store, MPI, a file).",
+    "tuber_comm_init": "ncclCommInitRank on HIP device `device` (collective over all `nranks` processes, one per GPU); *comm_out receives the communicator.",
+    "tuber_comm_allreduce_sum": "in-place sum over all ranks of buf[0..count) (dtype 0 = fp32, 1 = bf16) enqueued on `stream` -- the gradient all-reduce DDP's "
+                                "reducer issues per bucket (torch/nn/parallel/distributed.py via utils/model_utils.py:46-52), here on windows of the flat "
+                                "gradient buffer with no bucket copies; stream-ordered, capturable into a hipGraph.",
+    "tuber_comm_allreduce_sum_multi": "the same for n windows (HOST arrays ptrs[n], counts[n]) as ONE RCCL group.",
+    "tuber_comm_destroy": "ncclCommDestroy.",
+    "tuber_cast_bf16_f32_scale": "dst = float(src) * scale: expands a bf16-compressed, all-reduced gradient window back into the fp32 gradient buffer and averages it in the same pass.",
     "tuber_frames_resize": "PIL.Image.resize((nw, nh)) of every decoded frame (datasets/ava_frame.py:146-150; jhmdb_frame.py alike): Pillow's 8-bit two-pass "
                            "fixed-point bicubic (libImaging/Resample.c), packed RGB uint8 [nimg][H][W][3] -> [nimg][Ho][Wo][3], bit-exact.",
     "tuber_clip_prepare": "hflip + crop + ColorJitter + ToTensor/Normalize (datasets/video_transforms.py:69-85,20-66,333-369,308-322; pipeline "
@@ -169,7 +182,7 @@ def prototypes():
     out = []
     for f in sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.cpp"))):
         s = open(f).read()
-        for m in re.finditer(r'^(int|long) (tuber_\w+)\(([^)]*)\)\s*\{', s, re.M):
+        for m in re.finditer(r'^(int|long|const char\*) (tuber_\w+)\(([^)]*)\)\s*\{', s, re.M):
             out.append((os.path.basename(f), m.group(1), m.group(2), " ".join(m.group(3).split())))
     return out
 

@@ -3,21 +3,34 @@
 The reference wraps the model in ``DistributedDataParallel(find_unused_parameters=True)`` (utils/model_utils.py:39-58,
 pipelines/launch.py:20-50).  Here every parameter gradient already lives in ONE flat fp32 buffer in ``named_parameters()``
 order -- transformer, embeddings, projections, class-branch encoder, heads, THEN the CSN body (stem, layer1..4) and the pool
-decoder -- so the reducer is a handful of large all-reduces on contiguous slices, issued from the backward pass as soon as a
-slice is final and overlapped with the remaining backward kernels on RCCL's own stream:
+decoder -- so the reducer is a handful of large all-reduces on contiguous windows of that buffer, issued as soon as a window is
+final and overlapped with the remaining backward kernels:
 
-    backward reaches ...            slice that is final              -> dist.all_reduce(slice, async_op=True)
+    backward reaches ...            window that is final             -> all-reduce on the reducer's side stream
     body backward entry             everything laid out behind the body (pool decoder)
     end of layer4 / 3 / 2 / 1       that stage's parameters (offsets >= the stage's first block)
-    end of backward                 the rest: stem, and the transformer / head slice laid out before the body
+    end of backward                 the rest: stem, and the transformer / head window laid out before the body
 
-(The hipGraph step, training.GraphedTrainStep, does not use these hooks: it cuts its graph once, where layer3's backward ends,
-and reduces [layer3 .. end) and [0 .. body) under the layer2 / layer1 / stem backward.)
+Transport (``RcclComm``): RCCL bound directly through the C ABI (``csrc/collective.cpp``: ``ncclAllReduce`` from the librccl the
+process already has), on a communicator and a HIP stream this module owns.  Ordering is by events only: the side stream waits for
+the backward stream at each issue point, the optimizer waits for the side stream once; the host never blocks.  The averaging
+(x 1/world) runs on the side stream right behind each window's all-reduce, so it is overlapped too.  Windows of frozen parameters
+(``requires_grad = False``) hold no gradient and are never sent.  Optional bf16 compression (``TUBER_DDP_BF16=1`` or
+``compress=True``): a window is cast to bf16 into a staging buffer, summed in bf16, and expanded + averaged back into the fp32
+buffer -- half the xGMI bytes (xGMI is point-to-point, 7 links x ~153 GB/s per GPU: the ring is per-link bound), at bf16 sum
+precision.  Without a GPU / with the gloo backend (CPU tests, two ranks sharing one GPU) the same windows go through
+``torch.distributed.all_reduce``.
 
-No bucket copies, no unused-parameter bitmap (C2), no per-step buffer broadcast (C3): BatchNorm statistics stay local
-like the reference's non-synchronised BatchNorm3d; rank 0's running statistics are what a checkpoint holds.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few 25-100 MB messages keep RCCL in its bandwidth regime.
+The hipGraph step (training.GraphedTrainStep) does not use the backward hooks: it cuts its graph once, where layer3's backward
+ends, and calls ``reduce()`` for the final windows before replaying the rest (layer2 / layer1 / stem backward) -- or, with
+``TUBER_RCCL_IN_GRAPH=1``, keeps the hooks and captures the collectives INTO the graph as a forked branch.
+
+No bucket copies, no unused-parameter bitmap (C2), no per-step buffer broadcast (C3): BatchNorm statistics stay local like the
+reference's non-synchronised BatchNorm3d; rank 0's running statistics are what a checkpoint holds.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,41 +50,125 @@ def trainable_ranges(store):
     return [(a, b) for a, b in out]
 
 
+class RcclComm:
+    """One RCCL communicator + one HIP stream owned by this process (= this GPU).  The 128-byte unique id travels from rank 0
+    through whatever torch.distributed process group exists (any backend); a single-rank communicator needs none."""
+
+    def __init__(self, device, rank=None, world=None):
+        from . import lib
+        self.lib = lib.load()
+        self.device = torch.device(device)
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world = rank, world
+        v = self.lib.tuber_comm_version()
+        if v < 0:
+            raise RuntimeError("RCCL unavailable: %s" % self.lib.tuber_comm_last_error().decode())
+        self.version = v
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self.lib.tuber_comm_unique_id(ctypes.addressof(uid)), "tuber_comm_unique_id")
+        if world > 1:
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._check(self.lib.tuber_comm_init(ctypes.addressof(uid), world, rank, idx, ctypes.addressof(comm)), "tuber_comm_init")
+        self.comm = comm.value
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.tuber_comm_last_error().decode()))
+
+    def all_reduce(self, ptr, count, bf16=False, stream=None):
+        """in-place sum of ``count`` elements at device address ``ptr`` on ``stream`` (default: the owned side stream)."""
+        s = (stream or self.stream).cuda_stream
+        self._check(self.lib.tuber_comm_allreduce_sum(self.comm, ptr, count, 1 if bf16 else 0, s), "tuber_comm_allreduce_sum")
+
+    def close(self):
+        if getattr(self, "comm", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.tuber_comm_destroy(self.comm)
+            self.comm = None
+
+
 class FlatGradReducer:
-    def __init__(self, store, world_size=None, min_bucket=8 << 20):
+    def __init__(self, store, world_size=None, min_bucket=8 << 20, comm=None, compress=None):
         self.store = store
-        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.comm = comm
+        self.world = world_size if world_size is not None else (comm.world if comm is not None else (dist.get_world_size() if dist.is_initialized() else 1))
         self.min_bucket = min_bucket          # elements
+        self.compress = bool(os.environ.get("TUBER_DDP_BF16")) if compress is None else bool(compress)
+        self.stage = None                     # bf16 staging buffer of the compressed path (allocated on first use)
+        self.dry = False                      # hooks fire but nothing is sent (capture warm-up)
+        self._joined = True
         self.handles = []
-        self.done_from = store.total          # everything at offsets >= done_from has been handed to RCCL
-        self.late = []                        # [(begin, end)] slices that must wait for the end of backward
+        self.issued = 0                       # elements handed to the transport since begin() (tests / logging)
+        self.done_from = store.total          # everything at offsets >= done_from has been handed to the transport
+        self.late = []                        # [(begin, end)] windows that must wait for the end of backward
         for n in store.names:
             if n.endswith("query_embed.weight") or n.endswith("query_pool.weight"):
                 o = store.offsets[n]
                 self.late.append((o, o + (store.module.get_parameter(n).numel() + 63) // 64 * 64))
         self.late.sort()
+        self.ranges = trainable_ranges(store)
 
+    # -- step protocol -----------------------------------------------------------------------------------------------------
     def begin(self):
         self.handles = []
+        self.issued = 0
         self.done_from = self.store.total
         self.ranges = trainable_ranges(self.store)       # windows of frozen parameters hold no gradient: never sent
+        self._joined = True
 
-    def _reduce(self, lo, hi):
-        if hi <= lo or self.world <= 1:
+    def reduce(self, lo, hi):
+        """all-reduce (and average) the trainable part of gflat[lo:hi); returns immediately."""
+        if hi <= lo or (self.world <= 1 and self.comm is None):
             return
-        for a, b in self.ranges:
-            a, b = max(a, lo), min(b, hi)
-            if b > a:
-                self.handles.append(dist.all_reduce(self.store.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        wins = [(max(a, lo), min(b, hi)) for a, b in self.ranges]
+        wins = [(a, b) for a, b in wins if b > a]
+        if not wins or self.dry:
+            return
+        st = self.store
+        if self.comm is None:
+            for a, b in wins:
+                self.handles.append(dist.all_reduce(st.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                self.issued += b - a
+            return
+        from . import lib
+        cs = self.comm.stream
+        cs.wait_stream(torch.cuda.current_stream())            # the windows are final on the backward stream up to here
+        self._joined = False
+        inv = 1.0 / self.world
+        base = st.gflat.data_ptr()
+        with torch.cuda.stream(cs):
+            for a, b in wins:
+                n = b - a
+                if self.compress:
+                    if self.stage is None:
+                        self.stage = torch.empty(st.total, dtype=torch.bfloat16, device=st.device)
+                    sp = self.stage.data_ptr() + 2 * a
+                    lib.call("tuber_cast_f32_bf16", base + 4 * a, sp, n)
+                    self.comm.all_reduce(sp, n, bf16=True)
+                    lib.call("tuber_cast_bf16_f32_scale", sp, base + 4 * a, n, inv)
+                else:
+                    self.comm.all_reduce(base + 4 * a, n)
+                    if self.world > 1:
+                        lib.call("tuber_scale_f32", base + 4 * a, n, None, inv)
+                self.issued += n
 
     def _reduce_excluding_late(self, lo, hi):
         cur = lo
         for a, b in self.late:
             if b <= lo or a >= hi:
                 continue
-            self._reduce(cur, max(cur, a))
+            self.reduce(cur, max(cur, a))
             cur = max(cur, b)
-        self._reduce(cur, hi)
+        self.reduce(cur, hi)
 
     def notify(self, offset, force=False):
         """Backward has finished every parameter at flat offsets >= ``offset``."""
@@ -82,20 +179,30 @@ class FlatGradReducer:
         self._reduce_excluding_late(offset, self.done_from)
         self.done_from = offset
 
-    def finish(self):
-        """End of backward: reduce what is left (stem + late slices), wait, and average."""
-        self.notify(0, force=True)
-        for a, b in self.late:
-            self._reduce(a, b)
+    def finish(self, rest=True):
+        """End of backward: reduce what is left (stem + late windows) when ``rest``, then make the optimizer's stream wait for
+        the transport (events only) -- gradients are averaged when this returns (in stream order)."""
+        if rest:
+            self.notify(0, force=True)
+            for a, b in self.late:
+                self.reduce(a, b)
+        if self.comm is not None:
+            if not self._joined:
+                torch.cuda.current_stream().wait_stream(self.comm.stream)
+                self._joined = True
+            return
         for h in self.handles:
             h.wait()
         self.handles = []
-        if self.world > 1:
+        if self.world > 1 and not self.dry:
             from . import lib
-            if self.store.gflat.is_cuda:
-                lib.call("tuber_scale_f32", self.store.gflat, self.store.total, None, 1.0 / self.world)
+            st = self.store
+            if st.gflat.is_cuda:
+                for a, b in self.ranges:
+                    lib.call("tuber_scale_f32", st.gflat.data_ptr() + 4 * a, b - a, None, 1.0 / self.world)
             else:
-                self.store.gflat.mul_(1.0 / self.world)
+                for a, b in self.ranges:
+                    st.gflat[a:b].mul_(1.0 / self.world)
 
 
 def broadcast_parameters(store, src=0):
@@ -105,3 +212,19 @@ def broadcast_parameters(store, src=0):
     dist.broadcast(store.flat, src)
     for b in store.module.buffers():
         dist.broadcast(b, src)
+
+
+def attach_reducer(store, force=False):
+    """reducer for ``store`` when a process group with > 1 rank exists (or ``force``: a one-rank communicator, used to exercise the
+    whole N > 1 code path -- RCCL init, stream ordering, graph cut -- on a single GPU).  RCCL transport when the parameters are on
+    a GPU and the process group is nccl (or there is none / TUBER_OWN_RCCL=1); torch.distributed otherwise."""
+    ddp = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if ddp else 1
+    if world <= 1 and not force:
+        return None
+    comm = None
+    own = store.device.type == "cuda" and (not ddp or dist.get_backend() == "nccl" or os.environ.get("TUBER_OWN_RCCL"))
+    if own and not os.environ.get("TUBER_NO_OWN_RCCL"):
+        comm = RcclComm(store.device)
+    store.reducer = FlatGradReducer(store, world_size=world, comm=comm)
+    return store.reducer

@@ -15,7 +15,7 @@ LIBPATH = os.path.join(HERE, "lib", "libtuber_hip.so")
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
-    "unsigned long long": ctypes.c_ulonglong, "hipStream_t": ctypes.c_void_p,
+    "unsigned long long": ctypes.c_ulonglong, "hipStream_t": ctypes.c_void_p, "const char*": ctypes.c_char_p,
 }
 _lib = None
 _sigs = None
@@ -25,7 +25,7 @@ def header_prototypes(path=HEADER):
     """[(ret, name, [(ctype_string, argname), ...])] for every `tuber_*` prototype in the header."""
     text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     protos = []
-    for m in re.finditer(r"\b(int|long)\s+(tuber_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(int|long|const char\*)\s*(tuber_\w+)\s*\(([^)]*)\)\s*;", text):
         args = []
         body = m.group(3).strip()
         if body and body != "void":

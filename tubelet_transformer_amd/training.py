@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from .ddp import FlatGradReducer, broadcast_parameters
+from .ddp import attach_reducer, broadcast_parameters
 from .optim import FusedClipAdamW, build_param_groups
 
 
@@ -38,7 +38,7 @@ def deploy_model(model, cfg, is_tuber=True, device=None):
     store, _ = model.engine()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         broadcast_parameters(store)
-        store.reducer = FlatGradReducer(store)
+    attach_reducer(store, force=bool(os.environ.get("TUBER_FORCE_DDP")))      # None with a single rank (unless forced)
     path = getattr(cfg.CONFIG.MODEL, "PRETRAIN_TRANSFORMER_DIR", "")
     if is_tuber and path:
         from .checkpoint import load_detr_weights
@@ -101,7 +101,10 @@ class GraphedTrainStep:
     AdamW step count.  A new clip shape or a changed set of frozen parameters captures a new graph (the eager warm-up passes of
     a capture are rolled back, so they are not optimisation steps); at most ``max_graphs`` graphs are kept (LRU).
 
-    With >1 rank (ddp.py) the gradient all-reduce runs between / under the graph pieces; see ``_capture``.
+    With > 1 rank (ddp.py) the step is graph A (refresh .. layer3's backward) -> RCCL all-reduce of the ~97 % of the gradient
+    buffer that is final at that point, on the reducer's own stream -> graph A2 (layer2 / layer1 / stem backward, running UNDER
+    the all-reduce) -> all-reduce of the remainder -> graph B2 (clip + AdamW) which waits for the side stream by event.  With
+    ``TUBER_RCCL_IN_GRAPH=1`` the collectives are captured into ONE graph as a forked branch instead.
     """
 
     def __init__(self, model, criterion, optimizer, max_norm, tmax=16, max_graphs=4):
@@ -117,9 +120,10 @@ class GraphedTrainStep:
         store, _ = model.engine()
         dev = store.device
         red = getattr(store, "reducer", None)
-        world = getattr(red, "world", 1) if red is not None else getattr(self, "world", 1)
-        self.world = world
+        ddp = red is not None                        # N > 1 ranks (or a forced one-rank communicator): gradients are all-reduced
+        in_graph = ddp and red.comm is not None and bool(os.environ.get("TUBER_RCCL_IN_GRAPH"))
         g = type("Captured", (), {})()
+        g.red, g.in_graph = red, in_graph
         g.clips = clips.clone()
         g.mask = mask.clone()
         g.pt = PaddedTargets(targets, crit.ava, crit.num_classes if crit.ava else crit.num_classes + 1, dev, tmax=self.tmax)
@@ -148,22 +152,42 @@ class GraphedTrainStep:
         # reductions per bottleneck where the captured backward flushes twice): sizes every workspace, builds the reduce tables and
         # the loss-weight / hyper-parameter device tables.  Rolled back afterwards -- a capture is not an optimisation step.
         snap = _Snapshot(model, store, opt)
-        store.reducer = None
+        store.reducer = red if in_graph else None
+        if in_graph:
+            red.dry = True                           # hooks fire (same deferred-reduce flush points as the capture), nothing is sent
         try:
             for _ in range(2):
                 head()
                 g.on_device = g.cost.shape[2] <= 128 and g.cost.shape[3] <= 128      # the bound of tuber_lsap_device (criterion.assign)
                 g.match = crit.assign(g.cost, g.pt)
-                tail(True)
+                if in_graph:
+                    red.begin()
+                tail(not in_graph)
+                if in_graph:
+                    red.finish()
+                    opt.step(max_norm=max_norm)
             torch.cuda.synchronize()
         finally:
             snap.restore()
+            if in_graph:
+                red.dry = False
         opt.sync_hyper()
         crit.sync_weights(dev)
         g.A, g.A2, g.B1, g.B2, g.split = torch.cuda.CUDAGraph(), None, None, None, None
-        split = world > 1 and g.on_device and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
+        split = ddp and not in_graph and g.on_device and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
         split = split or bool(os.environ.get("TUBER_FORCE_SPLIT_GRAPH"))
-        if split and g.on_device:
+        own_step = not ddp or in_graph               # clip + AdamW inside the main graph (else graph B2, behind the all-reduce)
+        if in_graph:
+            # ONE graph: the reducer's hooks fork its side stream off the capture stream inside the backward pass, so the RCCL
+            # all-reduces (+ averaging) are captured as a parallel branch that joins before clip + AdamW
+            with torch.cuda.graph(g.A, capture_error_mode="relaxed"):      # RCCL may touch the runtime while enqueuing
+                head()
+                g.match = crit.assign(g.cost, g.pt)
+                red.begin()
+                tail(False)
+                red.finish()
+                opt.step(max_norm=max_norm)
+        elif split and g.on_device:
             # DDP: graph A is cut where layer3's backward ends (~97 % of the gradient bytes are final there), so the RCCL
             # all-reduce of that slice runs under the layer2 / layer1 / stem backward (graph A2) instead of after it.
             _, runner = model.engine()
@@ -184,7 +208,7 @@ class GraphedTrainStep:
                 try:
                     head()
                     g.match = crit.assign(g.cost, g.pt)
-                    tail(world == 1)
+                    tail(own_step)
                 finally:
                     runner.split_hook = None
                 if "off" in cut:
@@ -197,7 +221,7 @@ class GraphedTrainStep:
             with torch.cuda.graph(g.A):
                 head()
                 g.match = crit.assign(g.cost, g.pt)
-                tail(world == 1)
+                tail(own_step)
         else:
             # assignment problems beyond the device solver's 128 x 128 bound: graph A / host tuber_lsap / graph B1
             with torch.cuda.graph(g.A):
@@ -208,8 +232,9 @@ class GraphedTrainStep:
             g.cost_host = torch.empty(g.cost.shape, dtype=torch.float32).pin_memory()
             g.B1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.B1, pool=g.A.pool()):
-                tail(world == 1)
-        if world > 1:
+                tail(own_step)
+        store.reducer = red
+        if not own_step:
             g.B2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.B2, pool=g.A.pool()):
                 opt.step(max_norm=max_norm)
@@ -252,26 +277,22 @@ class GraphedTrainStep:
             L = len(indices)
             self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
             g.B1.replay()
-        if g.B2 is None and g.A2 is None:
-            return g.loss, g.loss_dict
-        import torch.distributed as dist
-        ddp = g.B2 is not None and dist.is_initialized()
-        from . import lib
+        red = g.red
+        if red is not None and not g.in_graph:
+            red.begin()
         if g.A2 is not None:
             # final at the cut: layer3, layer4 and everything laid out behind the body [split, total) and everything laid out
             # before it (transformer, heads: [0, body_begin)); pending: stem, layer1, layer2 [body_begin, split)
-            bb = g.body_begin
-            h1 = [dist.all_reduce(store.gflat[g.split:], op=dist.ReduceOp.SUM, async_op=True),
-                  dist.all_reduce(store.gflat[:bb], op=dist.ReduceOp.SUM, async_op=True)] if ddp else []
+            if red is not None:
+                red.reduce(g.split, store.total)
+                red.reduce(0, g.body_begin)
             g.A2.replay()                                     # layer2 / layer1 / stem backward, under the all-reduce
-            if ddp:
-                h1.append(dist.all_reduce(store.gflat[bb:g.split], op=dist.ReduceOp.SUM, async_op=True))
-                for h in h1:
-                    h.wait()
-        elif ddp:
-            dist.all_reduce(store.gflat, op=dist.ReduceOp.SUM)
-        if ddp:
-            lib.call("tuber_scale_f32", store.gflat, store.total, None, 1.0 / dist.get_world_size())
+            if red is not None:
+                red.reduce(g.body_begin, g.split)
+        elif red is not None and not g.in_graph:
+            red.reduce(0, store.total)
+        if red is not None and not g.in_graph:
+            red.finish(rest=False)                            # the optimizer graph waits for the side stream (events only)
         if g.B2 is not None:
             g.B2.replay()
         return g.loss, g.loss_dict
