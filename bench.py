@@ -39,8 +39,9 @@ def alg_cost(name, a):
             by += 2 * M * N          # residual read
         if epi == 2:
             by += 2 * M * N          # mask source read
-        tile = {0: "128,128,2,2,2", 1: "128,64,4,1,2", 2: "64,64,2,2,4", 7: "64,128,1,4,2", 8: "64,64,2,2,4", 9: "64,128,1,4,2"}[cfg]
-        return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, 2 if cfg in (8, 9) else 1), by, 2 * M * N * K
+        tile, occ = {0: ("128,128,2,2,2", 2), 2: ("64,64,2,2,4", 4), 7: ("64,128,1,4,2", 3), 12: ("64,64,2,2,4", 3), 13: ("64,64,2,2,2", 4),
+                     17: ("64,128,1,4,2", 4)}[cfg]
+        return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, occ), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
         T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64
@@ -77,9 +78,6 @@ def alg_cost(name, a):
         B, T, H, W = a[5:9]
         Mo = B * T * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
         return "stem_conv_bwd_w_kernel", 4 * B * 3 * T * H * W + 2 * Mo * 64, 2 * Mo * 64 * 441
-    if name == "tuber_stem_im2col":
-        N, T, H, W, Ho, Wo = a[2:8]
-        return "stem_im2col_kernel", 4 * N * 3 * T * H * W + 2 * N * T * Ho * Wo * 448, 0
     return name.replace("tuber_", "") + "*", 0, 0
 
 

@@ -122,21 +122,74 @@ def test_full_size_backward_per_parameter_vs_oracle(dev):
     assert not worse, "gradients worse than 2x a bf16-rounded oracle (+0.05): %s" % worse[:20]
     med = len(rows) // 2
     assert sorted(r[2] for r in rows)[med] <= 1.25 * sorted(r[3] for r in rows)[med] + 0.02
-    # BatchNorm buffers after one training-mode forward
-    bufs = dict(model.named_buffers())
+    _check_bn_buffers(cfg, model, state, clips)
+
+
+def _check_bn_buffers(cfg, model, state, clips):
+    """BatchNorm running statistics after one training-mode forward: HIP vs the fp32 oracle, yardstick = the rounded oracle"""
     from oracle import tuber_oracle as O
+    from parity_util import RoundBF
+    import torch.nn.functional as F
+    bufs = dict(model.named_buffers())
     st2 = {k: v.clone() for k, v in state.items()}
+    st3 = {k: v.clone() for k, v in state.items()}
     with torch.no_grad():
         O.tuber_forward(st2, cfg, clips, train=True)
-    worst = 0.0
+        oc, ol = F.conv3d, F.linear
+        O.F.conv3d = lambda x, w, *a, **k: RoundBF.apply(oc(RoundBF.apply(x), RoundBF.apply(w), *a, **k))
+        O.F.linear = lambda x, w, b=None: RoundBF.apply(ol(RoundBF.apply(x), RoundBF.apply(w), b))
+        try:
+            O.tuber_forward(st3, cfg, clips, train=True)
+        finally:
+            O.F.conv3d, O.F.linear = oc, ol
+    worst, yard = 0.0, 0.0
     for k, v in st2.items():
         if "running_mean" in k or "running_var" in k:
-            e = float((bufs[k].float().cpu() - v).abs().max()) / max(1.0, float(v.abs().max()))
-            worst = max(worst, e)
+            sc = max(1.0, float(v.abs().max()))
+            worst = max(worst, float((bufs[k].float().cpu() - v).abs().max()) / sc)
+            yard = max(yard, float((st3[k] - v).abs().max()) / sc)
         if "num_batches_tracked" in k:
             assert int(bufs[k]) == int(v), k
-    print("BatchNorm running statistics: worst relative error %.3e" % worst)
-    assert worst <= 2e-2
+    print("BatchNorm running statistics: worst relative error hip %.3e / bf16-rounded oracle %.3e" % (worst, yard))
+    assert worst <= 2.0 * yard + 1e-2
+
+
+@pytest.mark.parametrize("yaml_name,hw,dataset", [("TubeR_CSN152_AVA21.yaml", (256, 340), "ava"), ("Tuber_CSN152_JHMDB.yaml", (288, 384), "jhmdb")])
+def test_full_resolution_shallow_body_backward_per_parameter(dev, yaml_name, hw, dataset):
+    """Every kernel SHAPE of the BASELINE-size step (configs 3 and 5: 2 clips of 3x32x256x340 / 3x32x288x384 -- the same per-stage
+    [rows, channels] as CSN-152, whose extra depth only repeats the identity-block shapes) with a body shallow enough (CSN-TEST: 2
+    bottlenecks per stage) that the gradient is well-conditioned under bf16 rounding: per parameter, relerr(hip) <= 2 x relerr(rounded
+    oracle) + 0.05 and norm ratio in (0.5, 2) -- for ALL tensors, no conditioning filter -- and cos >= 0.9 wherever the rounded
+    oracle reaches 0.99."""
+    cfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
+    cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+    model, _, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    synth.zero_dropout(model)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pn = [n for n, _ in model.named_parameters()]
+    model.to(dev).train()
+    clips = synth.synthetic_clips(2, 32, hw[0], hw[1], seed=1234)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    o32, g32 = run_oracle(cfg, state, clips, train=True, param_names=pn, loss=surrogate)
+    obf, gbf = run_oracle(cfg, state, clips, train=True, rounded=True, param_names=pn, loss=surrogate)
+    store, _ = model.engine()
+    store.zero_grad()
+    out = model(clips.to(dev))
+    surrogate(out).backward()
+    torch.cuda.synchronize()
+    det = lambda o: {k: (v.detach() if torch.is_tensor(v) else [{kk: vv.detach() for kk, vv in a.items()} for a in v]) for k, v in o.items()}
+    errs = output_errors(out, det(o32), det(obf))
+    print("%s CSN-TEST body at 2x3x32x%dx%d, train-mode outputs hip / rounded oracle vs fp32: %s" % (yaml_name, hw[0], hw[1], {k: "%.2e / %.2e" % v for k, v in errs.items()}))
+    for kind, (eh, eb) in errs.items():
+        assert eh <= 3 * eb + 2e-2, (kind, eh, eb)
+    rows, worse = compare_gradients([(n, p.grad) for n, p in model.named_parameters()], g32, gbf, min_cb=None)
+    report(rows, "%s shallow body, full resolution" % yaml_name)
+    assert len(rows) >= 280, len(rows)
+    assert not worse, "gradients worse than 2x a bf16-rounded oracle (+0.05): %s" % worse[:20]
+    weak = [(n, ch, cb) for ch, cb, eh, eb, nr, n in rows if cb >= 0.99 and ch < 0.9]
+    assert not weak, weak[:10]
+    _check_bn_buffers(cfg, model, state, clips)
 
 
 @pytest.mark.parametrize("case", ["cfg2_csn50_decode", "cfg5_csn152_jhmdb"])

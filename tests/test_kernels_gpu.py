@@ -75,11 +75,11 @@ def test_gemm_nt_bn_prologue_stats(dev, M, N, K):
     close("gemm_nt stats sumsq", st1.sum(0), (ref * ref).sum(0), rel=2e-3)
 
 
-@pytest.mark.parametrize("cfg", [2, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [2, 7, 12, 13, 17, 0])
 @pytest.mark.parametrize("M,N,K", [(5632, 256, 1024), (5632, 1024, 256), (700, 128, 192), (130, 64, 64)])
 def test_gemm_nt_forced_tile_configs(dev, cfg, M, N, K):
-    """every shipped tile configuration (2: 64x64, 7: 64x128, 8/9: the same with the k-tiles split over two 4-wave groups, incl. an
-    odd number of k-tiles and a single tile) through all prologue / epilogue variants"""
+    """every built tile configuration (2: 64x64 and 7: 64x128 are the ones chosen automatically; 12 / 13 / 17 / 0 = register-budget,
+    prefetch-depth and 128x128 A/B variants) through all prologue / epilogue variants, incl. an odd number of k-tiles and a single tile"""
     A = rnd(M, K, dev=dev, seed=1).to(BF)
     B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
     sc, sh = 1.0 + 0.2 * rnd(K, dev=dev, seed=5), 0.3 * rnd(K, dev=dev, seed=6)
@@ -301,17 +301,6 @@ def test_bn_finalize_and_bwd(dev):
     dx = torch.empty(M, C, device=dev, dtype=BF)
     lib.call("tuber_bn_bwd_apply", dzb, xb, cA, cB, cC, dx, M, C)
     close("bn bwd apply kernel", dx, cA * dzb.float() + cB * xb.float() + cC)
-    if C % 32 == 0:      # finalize + apply in one launch (short partial lists): bit-identical to the pair, also when accumulating
-        for accumulate in (0, 1):
-            ref = [torch.full((C,), 0.5, device=dev) for _ in range(5)]
-            lib.call("tuber_bn_bwd_finalize", b0, b1, R, C, float(M), gamma, mean, invstd, *ref, accumulate)
-            dx_ref = torch.empty(M, C, device=dev, dtype=BF)
-            lib.call("tuber_bn_bwd_apply", dzb, xb, ref[0], ref[1], ref[2], dx_ref, M, C)
-            got = [torch.full((C,), 0.5, device=dev) for _ in range(5)]
-            dx2 = torch.full((M, C), float("nan"), device=dev, dtype=BF)
-            lib.call("tuber_bn_bwd_fused", b0, b1, R, C, float(M), gamma, mean, invstd, *got, accumulate, dzb, xb, dx2, M)
-            assert all(torch.equal(a, b) for a, b in zip(ref, got)), "fused BN backward coefficients differ"
-            assert torch.equal(dx2, dx_ref), "fused BN backward apply differs"
     sc2, sh2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
     lib.call("tuber_bn_eval_affine", gamma, beta, rm, rv, 1e-3, sc2, sh2, C)
     close("bn eval affine", x * sc2 + sh2, F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-3), rel=1e-5)
@@ -435,33 +424,6 @@ def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
     gm = torch.empty_like(dpre)
     lib.call("tuber_relu_mask", g.new_ones(M, N), h, gm, M * N, alpha)
     close("relu_mask alpha", gm, alpha * (h.float() > 0))
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(5632, 256, 1024, 2), (700, 512, 128, 0), (130, 64, 256, 2)])
-def test_gemm_nt_bn_backward_prologue(dev, M, N, K, epi):
-    """amode 2: the A operand is the BatchNorm backward apply cA[k]*dz + cB[k]*x + cC[k], formed while loading (the data-gradient
-    GEMMs of conv4 / conv1 / down_sample consume it without dx ever being written)."""
-    dz = rnd(M, K, dev=dev, seed=1).to(BF)
-    x = rnd(M, K, dev=dev, seed=2).to(BF)
-    cA, cB, cC = 1 + 0.2 * rnd(K, dev=dev, seed=3), 0.1 * rnd(K, dev=dev, seed=4), 0.05 * rnd(K, dev=dev, seed=5)
-    w = (rnd(N, K, dev=dev, seed=6) / K ** 0.5).to(BF)
-    res = rnd(M, N, dev=dev, seed=7).to(BF)
-    cm = rnd(M, N, dev=dev, seed=8).to(BF)
-    out = torch.empty(M, N, device=dev, dtype=BF)
-    a_ref = bfr(dz.float() * cA + x.float() * cB + cC)
-    ref = a_ref @ w.float().t()
-    R = lib.query("tuber_gemm_nt_stat_rows", M, N)
-    st0, st1 = torch.zeros(R, N, device=dev), torch.zeros(R, N, device=dev)
-    if epi == 0:
-        lib.call("tuber_gemm_nt", dz, K, w, K, out, N, M, N, K, 2, cA, cB, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                 0, None, res, N, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, x, K, cC)
-        close("gemm_nt amode2 (+residual)", out, ref + res.float())
-    else:
-        lib.call("tuber_gemm_nt", dz, K, w, K, out, N, M, N, K, 2, cA, cB, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                 2, None, None, 0, 0, 0, st0, st1, cm, N, None, None, 1.0, 0.0, None, 0, x, K, cC)
-        refm = ref * (cm.float() > 0)
-        close("gemm_nt amode2 epi2", out, refm)
-        close("gemm_nt amode2 epi2 sum dz", st0.sum(0), refm.sum(0), abs_=2e-3 * float(refm.abs().sum(0).max()))
 
 
 @pytest.mark.parametrize("M,N,K", [(704, 2048, 256), (30, 256, 256), (180, 256, 2048), (704, 256, 2048)])
@@ -660,13 +622,7 @@ def test_stem(dev, N, T, H, W):
     w = rnd(64, 3, 3, 7, 7, dev=dev, seed=2, scale=441 ** -0.5)
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     M = N * T * Ho * Wo
-    col = torch.empty(M, 448, device=dev, dtype=BF)
-    lib.call("tuber_stem_im2col", clip, col, N, T, H, W, Ho, Wo)
-    wb = torch.zeros(64, 448, device=dev, dtype=BF)
-    wb[:, :441] = w.view(64, 441).to(BF)
-    C, st0, st1 = gemm_nt(col, wb, M, 64, 448, epi=1)
     ref = F.conv3d(bfr(clip), bfr(w), stride=(1, 2, 2), padding=(1, 3, 3)).permute(0, 2, 3, 4, 1).reshape(M, 64)
-    close("stem conv via im2col+gemm", C, ref)
     # implicit-GEMM stem conv (the shipped path): forward + BN partial stats + weight gradient
     wp = torch.zeros(64, 512, device=dev, dtype=BF)
     lib.call("tuber_stem_pack_weight", w.contiguous(), wp)

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
     // combine the 16 partial softmaxes of this query row
     float M = mx;
-    M = fmaxf(M, __shfl_xor(M, 1)); M = fmaxf(M, __shfl_xor(M, 2)); M = fmaxf(M, __shfl_xor(M, 4)); M = fmaxf(M, __shfl_xor(M, 8));
+    M = quad16_max(M);
     const float f = mx == -INFINITY ? 0.f : __expf(mx - M);
     l = quad16_sum(l * f);
 #pragma unroll
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 #define WT_MAX 8
 __device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes sharing a head
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+    v = quad16_sum(v);
+    v += __shfl_xor(v, 16);
     return v;
 }
 __device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {

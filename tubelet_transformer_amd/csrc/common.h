@@ -38,28 +38,42 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return base + (b >> 3);
 }
 
-// wave64 butterfly sum over the 16 lanes that share (lane >> 4)
+// Lane exchange inside a 16-lane DPP row: one VALU operand modifier, no LDS traffic (``__shfl_xor`` compiles to ds_bpermute_b32,
+// an LDS-pipe instruction plus address arithmetic).  xor 1 / xor 2 are quad permutes; once the four lanes of a quad hold the same
+// value, row_half_mirror (lane l <- 7-l inside each 8) delivers the neighbouring quad's value and row_mirror (l <- 15-l) the other
+// half-row's: the results are bit-identical to the xor butterflies they replace.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141  /* after xor1+xor2: acts as xor 4 */
+#define DPP_MIRROR 0x140       /* after xor1+xor2+xor4: acts as xor 8 */
+
+// sum over the 16 lanes that share (lane >> 4); every lane gets the total
 __device__ __forceinline__ float quad16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_f32<DPP_XOR1>(v);
+    v += dpp_f32<DPP_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
+    v += dpp_f32<DPP_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float quad16_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v = quad16_sum(v);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 8));
+    v = quad16_max(v);
     v = fmaxf(v, __shfl_xor(v, 16));
     v = fmaxf(v, __shfl_xor(v, 32));
     return v;

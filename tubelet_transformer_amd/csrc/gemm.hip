@@ -45,18 +45,18 @@ __device__ __forceinline__ int swz_act(int row) { return (row >> 1) & 7; }
 template <int NT>
 __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
 
-// KS = 2: two 4-wave groups per workgroup split the k-tiles (group kg takes tiles kg, kg+2, ..) with their own LDS double
-// buffers and are summed through LDS before the epilogue: half the dependent k-iterations per workgroup and twice the waves
-// per CU for the short-M shapes (layer3/4: M = 5 632 gives only 352 workgroups of 64x64) that are latency- not bandwidth-bound.
-template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int KS>
-__global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 4 && AMODE != 2) ? 4 : 1)) void gemm_nt_kernel(GemmNT p) {
+// OCC = waves per SIMD the register allocation is held to (= workgroups per CU: a workgroup is one wave per SIMD).  It must not
+// exceed what the LDS allows anyway -- 2*(BM+BN)*128 B per workgroup of the 160 KB: 64x64 -> 4-5, 64x128 -> 3, 128x128 -> 2 --
+// or the compiler spills the prefetch registers to scratch inside the k-loop for occupancy the kernel can never reach.
+template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
+    constexpr int KS = 1, kg = 0;               // (the in-workgroup k-split of round 1 was measured and dropped; the index math keeps its shape)
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int kg = KS == 2 ? (int)(threadIdx.x >> 8) : 0;          // k group of this thread
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // thread / wave id INSIDE the group
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -243,29 +243,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
             }
         }
     }
-    if (KS == 2) {
-        // sum the two k groups: group 1 parks its accumulators in LDS ([tile][thread] float4: 16-byte accesses), group 0 adds them
-        // and runs the epilogue alone (group 1 only keeps hitting the barriers)
-        __syncthreads();
-        f32x4* xr = (f32x4*)smem;
-        if (kg == 1) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) xr[(i * NT + j) * 256 + tid] = acc[i][j];
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const f32x4 o = xr[(i * NT + j) * 256 + tid];
-                    acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
-                }
-        }
-    }
-    const bool epi_on = KS == 1 || kg == 0;
+    const bool epi_on = true;
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
     float s0[NC], s1[NC];
@@ -384,22 +362,22 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : ((BM * BN * G <= 64 * 64 * 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int G, int KS = 1>
+template <int BM, int BN, int WM, int WN, int G, int OCC>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    const size_t lds = KS * 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
-    dim3 grid(tiles), block(256 * KS);
+    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
+    dim3 grid(tiles), block(256);
 #define LNT(AM, EP)                                                                                                   \
     do {                                                                                                              \
         if (lds > 65536) { /* more than 64 KB of dynamic LDS needs a one-time opt-in per kernel */                    \
             static bool done = false;                                                                                 \
             if (!done) {                                                                                              \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, KS>,                     \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>,                    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
                 done = true;                                                                                          \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, KS>), grid, block, lds, s, p);                      \
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), grid, block, lds, s, p);                     \
     } while (0)
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
@@ -410,9 +388,8 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
             if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
             else LNT(A_BN_RELU, EPI_BWD);
-        } else {                                          // data-gradient GEMMs only: plain (+residual) or masked epilogue
-            if (epi == EPI_PLAIN) LNT(A_BN_BWD, EPI_PLAIN);
-            else LNT(A_BN_BWD, EPI_BWD);
+        } else {
+            return TUBER_EINVAL;                          // A_BN_BWD prologue: measured slower than the separate apply kernel, not built
         }
     }
 #undef LNT
@@ -435,9 +412,8 @@ static int nt_pick_cfg(int M, int N, int K) {
     return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 2;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
-    if (cfg == 0 || cfg == 3) { *bm = 128; *wm = 2; }
-    else if (cfg == 1 || cfg == 5) { *bm = 128; *wm = 4; }
-    else if (cfg == 6 || cfg == 7 || cfg == 9) { *bm = 64; *wm = 1; }
+    if (cfg == 0) { *bm = 128; *wm = 2; }
+    else if (cfg == 7 || cfg == 17) { *bm = 64; *wm = 1; }
     else { *bm = 64; *wm = 2; }
 }
 
@@ -483,16 +459,12 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
     switch (nt_pick_cfg(M, N, K)) {
-        case 0: return launch_nt_cfg<128, 128, 2, 2, 2>(p, amode, epi, stream);
-        case 1: return launch_nt_cfg<128, 64, 4, 1, 2>(p, amode, epi, stream);
-        case 3: return launch_nt_cfg<128, 128, 2, 2, 4>(p, amode, epi, stream);
-        case 4: return launch_nt_cfg<64, 64, 2, 2, 8>(p, amode, epi, stream);
-        case 5: return launch_nt_cfg<128, 64, 4, 1, 4>(p, amode, epi, stream);
-        case 6: return launch_nt_cfg<64, 256, 1, 4, 2>(p, amode, epi, stream);
-        case 7: return launch_nt_cfg<64, 128, 1, 4, 2>(p, amode, epi, stream);
-        case 8: return launch_nt_cfg<64, 64, 2, 2, 4, 2>(p, amode, epi, stream);
-        case 9: return launch_nt_cfg<64, 128, 1, 4, 2, 2>(p, amode, epi, stream);
-        default: return launch_nt_cfg<64, 64, 2, 2, 4>(p, amode, epi, stream);
+        case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // A/B only
+        case 7: return launch_nt_cfg<64, 128, 1, 4, 2, 3>(p, amode, epi, stream);
+        case 12: return launch_nt_cfg<64, 64, 2, 2, 4, 3>(p, amode, epi, stream);     // A/B: 64x64 without register pressure
+        case 13: return launch_nt_cfg<64, 64, 2, 2, 2, 4>(p, amode, epi, stream);     // A/B: shallower prefetch
+        case 17: return launch_nt_cfg<64, 128, 1, 4, 2, 4>(p, amode, epi, stream);    // A/B: round-1 register cap (spills)
+        default: return launch_nt_cfg<64, 64, 2, 2, 4, 4>(p, amode, epi, stream);
     }
 }
 
@@ -978,8 +950,8 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     p.accumulate = accumulate;
     p.P = p.S == 1 ? out : partial;            // a single slab writes (or accumulates into) the gradient directly
     p.a_scale = a_scale; p.a_shift = a_shift;
-    const int gmode = G2 ? 1 : 0;
-    if (gmode && (!gA || !gB || !gC || (ldg2 & 3) || ldg2 < ((N + 3) & ~3))) return TUBER_EINVAL;
+    const int gmode = 0;
+    if (G2) return TUBER_EINVAL;               // BatchNorm-backward apply on the G operand (GMODE 1): measured slower than the apply kernel, not built
     p.G2 = (const bf16*)G2; p.ldg2 = ldg2; p.gA = gA; p.gB = gB; p.gC = gC;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     const int T = tn_tile(N, K);
@@ -996,11 +968,9 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
         if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn2_kernel<A_BN_RELU>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(gemm_tn2_kernel<A_PLAIN>, grid, block, 0, stream, p);
     } else if (T == 128) {
-        if (amode == A_BN_RELU) { if (gmode) LTN(A_BN_RELU, 128, 1); else LTN(A_BN_RELU, 128, 0); }
-        else { if (gmode) LTN(A_PLAIN, 128, 1); else LTN(A_PLAIN, 128, 0); }
+        if (amode == A_BN_RELU) LTN(A_BN_RELU, 128, 0); else LTN(A_PLAIN, 128, 0);
     } else {
-        if (amode == A_BN_RELU) { if (gmode) LTN(A_BN_RELU, 64, 1); else LTN(A_BN_RELU, 64, 0); }
-        else { if (gmode) LTN(A_PLAIN, 64, 1); else LTN(A_PLAIN, 64, 0); }
+        if (amode == A_BN_RELU) LTN(A_BN_RELU, 64, 0); else LTN(A_PLAIN, 64, 0);
     }
 #undef LTN
     if (p.S > 1 && accumulate != 2) {          // accumulate == 2: the caller reduces the slabs later (tuber_multi_reduce)

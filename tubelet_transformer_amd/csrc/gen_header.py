@@ -77,7 +77,6 @@ DOC = {
     "tuber_stat_rows_reduced": "rows left by tuber_stat_rows_reduce (R itself when no first stage is needed).",
     "tuber_bn_eval_affine": "eval-mode BatchNorm3d folded to scale/shift from the running statistics.",
     "tuber_bn_bwd_finalize": "BatchNorm backward coefficients: dx = cA*dz + cB*x + cC, dgamma = sum dz*xhat, dbeta = sum dz.",
-    "tuber_bn_bwd_fused": "tuber_bn_bwd_finalize + tuber_bn_bwd_apply in one launch for short partial lists (R <= 128: layer3 / layer4), bit-identical to the pair.",
     "tuber_bn_bwd_apply": "dx = cA*dz + cB*x + cC (BatchNorm backward apply), bf16 [M,C].",
     "tuber_block_out_fwd": "bottleneck join y = relu(bn4(c4) + shortcut) (ir_CSN_152.py:81-90); shortcut = res or bn_ds(res) when rs/rh given.",
     "tuber_block_out_bwd": "backward of the join: dz = dy*[y>0] and the partial statistics of bn4 (and of the down_sample BN).",
@@ -96,7 +95,6 @@ DOC = {
     "tuber_stem_conv_bwd_weight": "weight gradient of the stem conv ([64][441] fp32) as an implicit MFMA GEMM (no patch matrix in HBM).",
     "tuber_stem_conv_blocks": "persistent grid size of the stem conv kernels = partial-stat rows of the forward.",
     "tuber_stem_pack_weight": "conv1.weight [64][441] fp32 -> [64][512] bf16 with k' = (c,kt,kh)*8 + kw (zero padded).",
-    "tuber_stem_im2col": "patch matrix [N*T*Ho*Wo, 448] bf16 of the stem Conv3d(3,64,(3,7,7),s=(1,2,2),p=(1,3,3)) (ir_CSN_152.py:109-115) from the fp32 NCDHW clip.",
     "tuber_stem_pool_fwd": "relu(bn1(.)) + MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1)) (ir_CSN_152.py:119-122) on NDHWC bf16, C=64; saves the argmax tap.",
     "tuber_stem_pool_bwd": "backward of the pool + relu(bn1(.)): dz and the BN-backward partial statistics.",
     "tuber_stem_pool_bwd_stat_rows": "partial-stat rows written by tuber_stem_pool_bwd.",

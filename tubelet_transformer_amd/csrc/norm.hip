@@ -272,63 +272,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-// BatchNorm backward for SHORT partial lists (layer3 / layer4: R <= 128 rows of statistics, activations of a few MB): finalize and
-// apply in one launch.  Every workgroup (32 channels x a chunk of rows) re-derives the coefficients of its channels from the R partial
-// rows with the same fp64 reduction as bn_bwd_finalize_kernel (bit-identical coefficients), then applies them like bn_bwd_apply_kernel;
-// the workgroups of row chunk 0 also write cA/cB/cC and dgamma/dbeta.  Saves one ~5 us launch per BatchNorm on the latency-bound stages.
-__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(
-    const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-    const bf16* __restrict__ dz, const bf16* __restrict__ x, bf16* __restrict__ dx, long M, int rows_per_chunk) {
-    __shared__ double red[2][32][33];
-    __shared__ float coef[3][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    const bool fin = threadIdx.x < 32 && c < C;
-    const bool first = blockIdx.y == 0;
-    const float mu_f = fin ? mean[c] : 0.f, r_f = fin ? invstd[c] : 0.f, g_f = fin ? gamma[c] : 0.f;
-    const float dg0 = (fin && first && dgamma && accumulate) ? dgamma[c] : 0.f, db0 = (fin && first && dgamma && accumulate) ? dbeta[c] : 0.f;
-    // start the first row of activations before the reduction: its latency hides behind the partial sums
-    const int q = threadIdx.x & 3;
-    const long r_begin = (long)blockIdx.y * rows_per_chunk, r_end = min(M, r_begin + rows_per_chunk);
-    const long coff = (long)blockIdx.x * 32 + q * 8;
-    long row = r_begin + (threadIdx.x >> 2);
-    uint4 d0 = make_uint4(0, 0, 0, 0), x0 = make_uint4(0, 0, 0, 0);
-    if (row < r_end) { d0 = *(const uint4*)(dz + row * C + coff); x0 = *(const uint4*)(x + row * C + coff); }
-    double a, b;
-    bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
-    if (rg == 0 && c < C) {
-        const double mu = mu_f, r = r_f, g = g_f;
-        const double sum_dz = a, sum_dz_xhat = (b - mu * a) * r;
-        const double m1 = sum_dz / count, m2 = sum_dz_xhat / count;
-        const float fa = (float)(g * r), fb = (float)(-g * r * r * m2), fc = (float)(g * r * r * m2 * mu - g * r * m1);
-        coef[0][cl] = fa; coef[1][cl] = fb; coef[2][cl] = fc;
-        if (first) {
-            cA[c] = fa; cB[c] = fb; cC[c] = fc;
-            if (dgamma) {
-                dgamma[c] = dg0 + (float)sum_dz_xhat;
-                dbeta[c] = db0 + (float)sum_dz;
-            }
-        }
-    }
-    __syncthreads();
-    float ka[8], kb[8], kc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ka[e] = coef[0][q * 8 + e]; kb[e] = coef[1][q * 8 + e]; kc[e] = coef[2][q * 8 + e]; }
-    while (row < r_end) {
-        const long nrow = row + 256;
-        uint4 d1 = d0, x1 = x0;
-        if (nrow < r_end) { d1 = *(const uint4*)(dz + nrow * C + coff); x1 = *(const uint4*)(x + nrow * C + coff); }
-        const bf16x8 d = as_bf16x8(d0), xx = as_bf16x8(x0);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(ka[e], bf2f(d[e]), fmaf(kb[e], bf2f(xx[e]), kc[e])));
-        *(uint4*)(dx + row * C + coff) = as_uint4(o);
-        d0 = d1; x0 = x1; row = nrow;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm(x + res) over the last dim E (256 or 2048), eps 1e-5, one wave per row.
@@ -660,17 +603,6 @@ int tuber_bn_bwd_finalize(const float* st0, const float* st1, int R, int C, floa
     if (R <= 0 || C <= 0) return TUBER_EINVAL;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, mean,
                        invstd, cA, cB, cC, dgamma, dbeta, accumulate);
-    TUBER_RETURN_LAUNCH();
-}
-
-// finalize + apply in one launch (bn_bwd_fused_kernel); meant for R <= 128 partial rows.  C % 32 == 0.
-int tuber_bn_bwd_fused(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* mean,
-                       const float* invstd, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
-                       const void* dz, const void* x, void* dx, long M, hipStream_t stream) {
-    if (R <= 0 || C <= 0 || (C & 31) || M <= 0) return TUBER_EINVAL;
-    const int rows_per_chunk = 512;
-    hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(C / 32, ceil_div(M, rows_per_chunk)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma,
-                       mean, invstd, cA, cB, cC, dgamma, dbeta, accumulate, (const bf16*)dz, (const bf16*)x, (bf16*)dx, M, rows_per_chunk);
     TUBER_RETURN_LAUNCH();
 }
 

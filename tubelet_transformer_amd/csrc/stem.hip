@@ -1,40 +1,8 @@
 // CSN stem: Conv3d(3,64,k=(3,7,7),s=(1,2,2),p=(1,3,3)) -> BN -> ReLU -> MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1))
 // reference: models/backbones/ir_CSN_152.py:109-122,172-179.
-// Round-1 formulation: the 3->64 conv runs on the MFMA GEMM over an explicit bf16 patch matrix
-// [M, 448] (441 taps padded to a multiple of 64) built here from the fp32 NCDHW clip; its weight
-// gradient is the TN GEMM over the same matrix.  BN-apply + ReLU are fused into the max-pool read;
-// the pool backward fuses the ReLU mask and the BN-backward partial statistics.
+// The conv itself is the implicit MFMA GEMM of stem_conv.hip; here: BN-apply + ReLU fused into the max-pool read, and the pool
+// backward fused with the ReLU mask and the BN-backward partial statistics.
 #include "common.h"
-
-#define STEM_K 441
-#define STEM_KP 448
-
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ clip, bf16* __restrict__ col, int N, int T,
-                                                          int H, int W, int Ho, int Wo, long total_chunks) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % (STEM_KP / 8));
-        long m = i / (STEM_KP / 8);
-        const int wo = (int)(m % Wo); long r = m / Wo;
-        const int ho = (int)(r % Ho); r /= Ho;
-        const int t = (int)(r % T); const int n = (int)(r / T);
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = ch * 8 + e;
-            float f = 0.f;
-            if (k < STEM_K) {
-                const int kw = k % 7; int q = k / 7;
-                const int kh = q % 7; q /= 7;
-                const int kt = q % 3; const int c = q / 3;
-                const int ti = t + kt - 1, hi = ho * 2 + kh - 3, wi = wo * 2 + kw - 3;
-                if (ti >= 0 && ti < T && hi >= 0 && hi < H && wi >= 0 && wi < W)
-                    f = clip[((((long)n * 3 + c) * T + ti) * H + hi) * W + wi];
-            }
-            v[e] = f2bf(f);
-        }
-        *(uint4*)(col + m * STEM_KP + ch * 8) = as_uint4(v);
-    }
-}
 
 // out = max over the 3x3 window of relu(x*sc+sh); arg = window tap index (first maximum, like ATen)
 __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ sc,
@@ -150,14 +118,6 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restri
 }
 
 extern "C" {
-
-int tuber_stem_im2col(const float* clip, void* col, int N, int T, int H, int W, int Ho, int Wo, hipStream_t stream) {
-    const long chunks = (long)N * T * Ho * Wo * (STEM_KP / 8);
-    long nb = (chunks + 255) / 256;
-    if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(stem_im2col_kernel, dim3((int)nb), dim3(256), 0, stream, clip, (bf16*)col, N, T, H, W, Ho, Wo, chunks);
-    TUBER_RETURN_LAUNCH();
-}
 
 int tuber_stem_pool_fwd(const void* x, const float* sc, const float* sh, void* out, void* arg, int NT, int Hs, int Ws, int Hp, int Wp,
                         hipStream_t stream) {

@@ -164,6 +164,7 @@ class ParamStore:
         self.nmat = len(entries)
         self.step_seed = 0
         self._by_name = dict(zip(names, params))
+        self.reducer = None              # ddp.FlatGradReducer when gradients are all-reduced (attach_reducer)
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.defer = DeferredReduce(self.device)
