@@ -151,10 +151,11 @@ def test_library_exports_every_symbol_the_header_declares():
         assert hasattr(L, name), name
     # pure host helpers may be called without a GPU
     cfg = lib.query("tuber_gemm_nt_cfg", 348160, 64, 256)
-    assert cfg in (0, 1, 2, 7, 8, 9)
-    assert lib.query("tuber_gemm_nt_stat_rows", 348160, 64) == (348160 + (63 if cfg == 2 else 127)) // (64 if cfg == 2 else 128)
-    assert lib.query("tuber_gemm_nt_cfg", 30, 256, 256) == 2
-    assert lib.query("tuber_gemm_nt_cfg", 348160, 256, 64) == 7
+    assert cfg == 13                                     # 64x64 tiles, two-tile prefetch
+    assert lib.query("tuber_gemm_nt_stat_rows", 348160, 64) == 348160 // 64
+    assert lib.query("tuber_gemm_nt_cfg", 30, 256, 256) == 13
+    assert lib.query("tuber_gemm_nt_cfg", 348160, 256, 64) == 7      # 64x128
+    assert lib.query("tuber_gemm_nt_cfg", 16896, 2048, 512) == 0     # 128x128: the class-branch FFN
 
 
 def test_lsap_matches_scipy_including_ties():

@@ -471,25 +471,6 @@ def test_gemm_tn_fused_bias_gradient_multi_slab(dev, M, N, K):
     assert torch.equal(out2, out) and torch.equal(db2, db)
 
 
-@pytest.mark.parametrize("M,N,K,amode", [(5632, 1024, 256, 1), (700, 64, 192, 0), (44032, 128, 64, 0)])
-def test_gemm_tn_bn_backward_prologue(dev, M, N, K, amode):
-    """G operand = cA[n]*dz + cB[n]*x + cC[n] formed on load (weight gradients of conv4 / conv1 / down_sample)."""
-    dz = rnd(M, N, dev=dev, seed=1).to(BF)
-    x = rnd(M, N, dev=dev, seed=2).to(BF)
-    cA, cB, cC = 1 + 0.2 * rnd(N, dev=dev, seed=3), 0.1 * rnd(N, dev=dev, seed=4), 0.05 * rnd(N, dev=dev, seed=5)
-    A = rnd(M, K, dev=dev, seed=6).to(BF)
-    sc, sh = 1 + 0.1 * rnd(K, dev=dev, seed=7), 0.1 * rnd(K, dev=dev, seed=8)
-    g_ref = bfr(dz.float() * cA + x.float() * cB + cC)
-    a_ref = bfr((A.float() * sc + sh).relu()) if amode else A.float()
-    ref = g_ref.t() @ a_ref
-    S = lib.query("tuber_gemm_tn_slabs", M, N, K)
-    part = torch.empty(S * N * K, device=dev)
-    out = torch.ones(N, K, device=dev)
-    lib.call("tuber_gemm_tn", dz, N, A, K, part, out, 1, M, N, K, amode, sc if amode else None, sh if amode else None,
-             0, 0, 0, 0, 0, 0, 0, 0, 0, x, N, cA, cB, cC, None)
-    close("gemm_tn G prologue", out - 1, ref, rel=4e-3)
-
-
 @pytest.mark.parametrize("M,C,ld", [(704, 256, 256), (30, 2048, 2048), (180, 3, 64), (24, 3840, 3840), (16896, 512, 512), (5000, 80, 128)])
 def test_colsum(dev, M, C, ld):
     g = rnd(M, ld, dev=dev, seed=1).to(BF)

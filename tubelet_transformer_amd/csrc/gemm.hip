@@ -404,12 +404,14 @@ static int nt_force_cfg() {
 }
 static int nt_pick_cfg(int M, int N, int K) {
     if (nt_force_cfg() >= 0) return nt_force_cfg();       // tuning / experiments only
-    // measured on MI355X in isolation (scripts/gemm_bench.py, profiles/r01_*): every tile here has 64 rows (one partial-statistics
-    // row per 64 output rows); 64x64 (4-5 workgroups resident per CU) wins the small-N and long-K shapes, 64x128 the wide
-    // short-K ones (conv4 / dgrad1 of layer1-3, class-branch projections) where re-reading A per 64 columns is what costs
-    // (cfg 8 / 9 = the same tiles with the k-tiles split over two wave groups: -13..-20 % on the long-K short-M shapes in
-    // isolation, nothing measurable on the step -- available through tuber_gemm_nt_set_cfg, not chosen automatically)
-    return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 2;
+    // measured on MI355X in isolation (scripts/gemm_bench.py, profiles/r02_gemm_nt_tile_ab.txt): 64-row tiles everywhere except the two
+    // FLOP-dense class-branch FFN GEMMs.  64x128 (3 workgroups per CU by LDS, registers budgeted for exactly that) wins the wide
+    // short-K shapes (conv4 / dgrad1 of layer1-3, class-branch projections) where re-reading A per 64 columns is what costs;
+    // 64x64 with a TWO-tile prefetch (cfg 13: 93-109 VGPRs, no spills at 4 workgroups per CU) the small-N and long-K ones -- the
+    // four-tile prefetch of round 1 (cfg 2) spilled in the BN-prologue / masked-epilogue variants and is 5-15 % slower everywhere;
+    // 128x128 only where M*N is large enough to fill the chip with 2 workgroups per CU.
+    if ((long)M * N >= (1L << 25) && N >= 1024 && K >= 256) return 0;
+    return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 13;
 }
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0) { *bm = 128; *wm = 2; }
@@ -458,7 +460,9 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
-    switch (nt_pick_cfg(M, N, K)) {
+    int cfg = nt_pick_cfg(M, N, K);
+    if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
+    switch (cfg) {
         case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // A/B only
         case 7: return launch_nt_cfg<64, 128, 1, 4, 2, 3>(p, amode, epi, stream);
         case 12: return launch_nt_cfg<64, 64, 2, 2, 4, 3>(p, amode, epi, stream);     // A/B: 64x64 without register pressure
