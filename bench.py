@@ -49,6 +49,9 @@ def alg_cost(name, a):
         if T == 64 and not gmode and not ((N | K | ldg | lda) & 7):      # the LDS-transpose-read kernel (gemm.hip: gemm_tn2_kernel)
             return "gemm_tn2_kernel<%d>" % a[10], 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
         return "gemm_tn_kernel<%d,%d,%d>" % (a[10], T, 1 if gmode else 0), 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
+    if name == "tuber_gemm_tn_group":
+        by = sum(2 * e.M * (e.N + e.K) + 4 * e.N * e.K for e in a[0])
+        return "gemm_tn2_group_kernel", by, sum(2 * e.M * e.N * e.K for e in a[0])
     if name in ("tuber_dwconv_fwd", "tuber_dwconv_bwd_data", "tuber_dwconv_bwd_weight"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
         N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss = a[off:off + 10]
@@ -86,6 +89,8 @@ def shape_of(name, a):
         return "M%d N%d K%d amode%d epi%d" % (a[6], a[7], a[8], a[9], a[21])
     if name == "tuber_gemm_tn":
         return "M%d N%d K%d amode%d" % (a[7], a[8], a[9], a[10])
+    if name == "tuber_gemm_tn_group":
+        return "%d x (M%d N%d K%d ..)" % (len(a[0]), a[0][0].M, a[0][0].N, a[0][0].K)
     if name in ("tuber_attn_fwd", "tuber_attn_bwd"):
         off = 10 if name == "tuber_attn_fwd" else 19
         return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])

@@ -20,6 +20,7 @@
 // Fused epilogues: bias / ReLU / residual add; per-column partial statistics (sum, sum of
 // squares) for training-mode BatchNorm; ReLU-mask + BN-backward partial statistics.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -491,6 +492,7 @@ struct GemmTN {
     const bf16* G2; long ldg2; const float* gA; const float* gB; const float* gC;   // GMODE 1: G := gA[n]*G + gB[n]*G2 + gC[n]
     float* bias_grad;            // gemm_tn2, single slab: dbias[n] += sum_m G[m][n] from the LDS image (no separate column-sum launch)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
+    int amode;                   // grouped launches: A_PLAIN / A_BN_RELU per problem
 };
 
 // transposed staging: the 64 x 128 tile (m x col) is cut in 4x4 blocks; thread -> block
@@ -734,16 +736,19 @@ __device__ __forceinline__ bf16x8 tn2_frag(const bf16* img, int m0, int col0, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// AMODE = A_PLAIN / A_BN_RELU at compile time, or -1: read p.amode at run time (grouped launches mix both; the branch is uniform).
+// bid / nblocks: this workgroup's index inside the problem's own grid (a grouped launch concatenates several grids).
 template <int AMODE>
-__global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
+__device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblocks) {
     constexpr int T = 64, TM = 32, TN = 32, MT = 2, NT = 2;
     constexpr int IMG = 64 * TNP;                       // one operand image (elements)
     __shared__ __attribute__((aligned(16))) bf16 smem[2][2][IMG];     // [buf][G | A][64 m][TNP]
+    const bool bn_relu = AMODE < 0 ? p.amode == A_BN_RELU : AMODE == A_BN_RELU;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, g = lane >> 4;
     const int tiles_n = (p.N + T - 1) / T, tiles_k = (p.K + T - 1) / T;
-    int b = xcd_remap(blockIdx.x, gridDim.x);
+    int b = xcd_remap(bid, nblocks);
     const int slab = b / (tiles_n * tiles_k);
     b -= slab * tiles_n * tiles_k;
     const int tile_n = b % tiles_n, tile_k = b / tiles_n;
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
     const int c = tid & 7, r = tid >> 3;
     const bool g_col_ok = n0 + c * 8 < p.N, a_col_ok = k0 + c * 8 < p.K;
     float asc[8], ash[8];
-    if (AMODE == A_BN_RELU) {
+    if (bn_relu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + c * 8 + e;
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint4 av = xa[h];
-            if (AMODE == A_BN_RELU) {
+            if (bn_relu) {
                 const bf16x8 x = as_bf16x8(av);
                 bf16x8 y;
 #pragma unroll
@@ -876,6 +881,23 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) {
     }
 }
 
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_body<AMODE>(p, blockIdx.x, gridDim.x); }
+
+// Several weight-gradient GEMMs in ONE launch: the conv weight gradients of a bottleneck (conv4, conv1, down_sample) feed nothing
+// until the optimizer, so they are queued and launched together -- one launch gap instead of 2-3 per bottleneck, and for the
+// short-M layer3 / layer4 shapes (512 workgroups of a few 64-row steps each) enough independent workgroups to fill 256 CUs.
+// The argument blocks travel BY VALUE in the kernel argument segment (a captured hipGraph bakes them in like any other launch).
+#define TN_GROUP_MAX 8
+struct GemmTNGroup { GemmTN p[TN_GROUP_MAX]; int begin[TN_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void gemm_tn2_group_kernel(GemmTNGroup g) {
+    int e = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.begin[i]) e = i;
+    gemm_tn2_body<-1>(g.p[e], (int)blockIdx.x - g.begin[e], g.begin[e + 1] - g.begin[e]);
+}
+
 // out[j] (+)= sum_s P[s][j], few slabs: one thread per element
 __global__ void reduce_slabs_flat_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -958,6 +980,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     if (G2) return TUBER_EINVAL;               // BatchNorm-backward apply on the G operand (GMODE 1): measured slower than the apply kernel, not built
     p.G2 = (const bf16*)G2; p.ldg2 = ldg2; p.gA = gA; p.gB = gB; p.gC = gC;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
+    p.amode = amode;
     const int T = tn_tile(N, K);
     const int tiles = ceil_div(N, T) * ceil_div(K, T);
     dim3 grid(tiles * p.S), block(256);
@@ -982,6 +1005,52 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
         if (p.S <= 16) hipLaunchKernelGGL(reduce_slabs_flat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partial, out, n, p.S, accumulate);
         else hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 32)), dim3(1024), 0, stream, partial, out, n, p.S, accumulate);
     }
+    TUBER_RETURN_LAUNCH();
+}
+
+
+// one entry of tuber_gemm_tn_group (HOST memory): the tuber_gemm_tn arguments of one weight-gradient GEMM
+struct TuberGemmTNArgs {
+    const void* G; long ldg; const void* A; long lda; float* partial; float* out;
+    int accumulate, M, N, K, amode, gather, To, Ho, Wo, Ti, Hi, Wi, st, ss;
+    const float* a_scale; const float* a_shift;
+};
+int tuber_gemm_tn_args_bytes(void) { return (int)sizeof(TuberGemmTNArgs); }
+int tuber_gemm_tn_group_max(void) { return TN_GROUP_MAX; }
+
+// n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly what tuber_gemm_tn would compute, transpose-read kernel
+// shapes only: 64 x 64 tiles, N / K / ld multiples of 8) in ONE launch.  Slab partials / accumulate flags per entry as in
+// tuber_gemm_tn; with several slabs the caller reduces them (accumulate must be 2 then: the second stage is not launched here).
+int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
+    if (!args_host || n <= 0 || n > TN_GROUP_MAX) return TUBER_EINVAL;
+    const TuberGemmTNArgs* a = (const TuberGemmTNArgs*)args_host;
+    GemmTNGroup g;
+    memset(&g, 0, sizeof g);
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const TuberGemmTNArgs& x = a[i];
+        if (x.M <= 0 || x.N <= 0 || x.K <= 0 || ((x.N | x.K | x.ldg | x.lda) & 7) || x.ldg < x.N || x.lda < x.K) return TUBER_EINVAL;
+        if (tn_tile(x.N, x.K) != 64 || (x.amode != A_PLAIN && x.amode != A_BN_RELU)) return TUBER_EINVAL;
+        if (x.amode == A_BN_RELU && (!x.a_scale || !x.a_shift)) return TUBER_EINVAL;
+        GemmTN& p = g.p[i];
+        p.G = (const bf16*)x.G; p.ldg = x.ldg; p.A = (const bf16*)x.A; p.lda = x.lda;
+        p.M = x.M; p.N = x.N; p.K = x.K;
+        p.rows_per_slab = tn_rows_per_slab(x.M, x.N, x.K);
+        p.S = tuber_gemm_tn_slabs(x.M, x.N, x.K);
+        if (p.S > 1 && x.accumulate != 2) return TUBER_EINVAL;
+        p.accumulate = x.accumulate;
+        p.P = p.S == 1 ? x.out : x.partial;
+        if (!p.P) return TUBER_EINVAL;
+        p.a_scale = x.a_scale; p.a_shift = x.a_shift;
+        p.G2 = nullptr; p.ldg2 = 0; p.gA = p.gB = p.gC = nullptr; p.bias_grad = nullptr;
+        p.gather = x.gather; p.To = x.To; p.Ho = x.Ho; p.Wo = x.Wo; p.Ti = x.Ti; p.Hi = x.Hi; p.Wi = x.Wi; p.st = x.st; p.ss = x.ss;
+        p.amode = x.amode;
+        g.begin[i] = total;
+        total += ceil_div(x.N, 64) * ceil_div(x.K, 64) * p.S;
+    }
+    for (int i = n; i <= TN_GROUP_MAX; ++i) g.begin[i] = total;
+    g.n = n;
+    hipLaunchKernelGGL(gemm_tn2_group_kernel, dim3(total), dim3(256), 0, stream, g);
     TUBER_RETURN_LAUNCH();
 }
 

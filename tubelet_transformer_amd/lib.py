@@ -68,6 +68,8 @@ def _conv(v, ctype_str):
             return None
         if isinstance(v, torch.Tensor):
             return v.data_ptr()
+        if isinstance(v, (ctypes.Array, ctypes.Structure)):
+            return ctypes.addressof(v)          # HOST argument blocks (tuber_gemm_tn_group)
         return v
     return v
 
