@@ -1,6 +1,6 @@
 """MFMA utilisation per kernel family from a rocprofv3 --pmc database holding SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_MFMA, SQ_BUSY_CU_CYCLES
 (or GRBM_GUI_ACTIVE): util = MFMA busy cycles / (SIMDs x elapsed shader cycles).  The elapsed cycles of a dispatch are taken from its
-duration x the measured clock (GRBM_GUI_ACTIVE / duration when collected, else 2.4 GHz nominal).
+duration x the 2.4 GHz peak clock the dense-MFMA peak figure assumes (GRBM_GUI_ACTIVE / duration is printed for reference).
 usage: rocpd_mfma_util.py pmc.db [out.json]"""
 import collections
 import json
@@ -31,13 +31,11 @@ for name, c in per.items():
     busy, insts, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("SQ_INSTS_MFMA", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
     if insts <= 0:
         continue
-    ghz = gui / ns if gui > 0 and ns > 0 else 2.4          # GRBM_GUI_ACTIVE counts shader-clock cycles while the dispatch is active
-    if ghz > 4.0:                                           # aggregated over the 8 XCDs
-        ghz /= 8.0
-    cycles = ns * ghz
+    ghz = gui / ns if gui > 0 and ns > 0 else 0.0          # reported only: per-dispatch GRBM_GUI_ACTIVE includes profiling overhead
+    cycles = ns * 2.4                                       # utilisation is quoted against the 2.4 GHz peak clock (what the dense-MFMA peak assumes)
     rows.append((ns, name, n, busy, insts, ghz, busy / (SIMDS * cycles) if cycles else 0.0))
 rows.sort(reverse=True)
-print("%-58s %6s %10s %14s %12s %9s %7s %9s" % ("kernel", "calls", "total_us", "mfma_busy_cyc", "mfma_insts", "cyc/inst", "GHz", "mfma_util"))
+print("%-58s %6s %10s %14s %12s %9s %7s %9s" % ("kernel", "calls", "total_us", "mfma_busy_cyc", "mfma_insts", "cyc/inst", "gui/ns", "mfma_util"))
 out = {}
 for ns, name, n, busy, insts, ghz, util in rows:
     print("%-58s %6d %10.1f %14.0f %12.0f %9.2f %7.2f %8.2f%%" % (name[:58], n, ns / 1e3, busy, insts, busy / insts, ghz, 100 * util))

@@ -11,13 +11,19 @@ kd = [t for t in tabs if "kernel_dispatch" in t][0]
 ks = [t for t in tabs if "kernel_symbol" in t][0]
 names = {r[0]: r[1] for r in cur.execute("select id, kernel_name from %s" % ks)}
 rows = list(cur.execute("select start,end,queue_id,kernel_id from %s order by start" % kd))
-# last step = from the last stem_conv_fwd launch to the end
+# one step = from a stem_conv_fwd launch to the next one; the SHORTEST one is a hipGraph replay (the eager warm-up / per-kernel timing
+# passes of bench.py are host-bound and much longer)
 idx = [i for i, r in enumerate(rows) if "stem_conv_fwd" in names[r[3]]]
-first = idx[-1]
-# include the weight refresh kernels right before the stem (multi_cast_transpose, cast)
-while first > 0 and rows[first][0] - rows[first - 1][1] < 50_000 and first > idx[-1] - 12:
+spans = [(rows[(idx[j + 1] if j + 1 < len(idx) else len(rows)) - 1][1] - rows[idx[j]][0], j) for j in range(len(idx) - 1)]
+best = min(spans)[1] if spans else len(idx) - 1
+first, last = idx[best], (idx[best + 1] if best + 1 < len(idx) else len(rows))
+# the weight refresh kernels right before the stem (multi_cast_transpose, cast) belong to the step; the ones before the NEXT stem do not
+lo = first
+while first > 0 and rows[first][0] - rows[first - 1][1] < 50_000 and first > lo - 12:
     first -= 1
-step = rows[first:]
+while last > first and last - 1 > idx[best] and any(k in names[rows[last - 1][3]] for k in ("multi_cast_transpose", "cast_f32_bf16", "stem_pack_weight")):
+    last -= 1
+step = rows[first:last]
 t0 = step[0][0]
 print("step span %.3f ms, %d kernels" % ((step[-1][1] - t0) / 1e6, len(step)))
 perq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0]))

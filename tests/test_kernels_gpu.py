@@ -626,21 +626,21 @@ def test_stem(dev, N, T, H, W):
     Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
     out = torch.empty(N * T * Hp * Wp, 64, device=dev, dtype=BF)
     arg = torch.empty(N * T * Hp * Wp, 64, device=dev, dtype=torch.uint8)
-    lib.call("tuber_stem_pool_fwd", C, sc, sh, out, arg, N * T, Ho, Wo, Hp, Wp)
-    a = (C.float() * sc + sh).relu().view(N * T, Ho, Wo, 64).permute(0, 3, 1, 2).requires_grad_(True)
+    lib.call("tuber_stem_pool_fwd", c2, sc, sh, out, arg, N * T, Ho, Wo, Hp, Wp)
+    a = (c2.float() * sc + sh).relu().view(N * T, Ho, Wo, 64).permute(0, 3, 1, 2).requires_grad_(True)
     pr = F.max_pool2d(a, 3, 2, 1)
     close("stem pool fwd", out, pr.detach().permute(0, 2, 3, 1).reshape(-1, 64))
     g = rnd(N * T * Hp * Wp, 64, dev=dev, seed=5).to(BF)
     pr.backward(g.float().view(N * T, Hp, Wp, 64).permute(0, 3, 1, 2))
     da = a.grad.permute(0, 2, 3, 1).reshape(M, 64)
-    dz_ref = da * ((C.float() * sc + sh) > 0)
+    dz_ref = da * ((c2.float() * sc + sh) > 0)
     dz = torch.empty(M, 64, device=dev, dtype=BF)
     R = lib.query("tuber_stem_pool_bwd_stat_rows", M)
     s0, s1 = torch.zeros(R, 64, device=dev), torch.zeros(R, 64, device=dev)
-    lib.call("tuber_stem_pool_bwd", g, arg, C, sc, sh, dz, s0, s1, N * T, Ho, Wo, Hp, Wp)
+    lib.call("tuber_stem_pool_bwd", g, arg, c2, sc, sh, dz, s0, s1, N * T, Ho, Wo, Hp, Wp)
     close("stem pool bwd dz", dz, dz_ref)
     close("stem pool bwd sum dz", s0.sum(0), dz_ref.sum(0), abs_=2e-3 * float(dz_ref.abs().sum(0).max()))
-    close("stem pool bwd sum dz*x", s1.sum(0), (dz_ref * C.float()).sum(0), abs_=2e-3 * float((dz_ref * C.float()).abs().sum(0).max()))
+    close("stem pool bwd sum dz*x", s1.sum(0), (dz_ref * c2.float()).sum(0), abs_=2e-3 * float((dz_ref * c2.float()).abs().sum(0).max()))
 
 
 def test_elementwise(dev):
