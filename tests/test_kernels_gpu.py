@@ -712,14 +712,16 @@ def test_gemm_tn_group_is_bit_identical_to_single_launches(dev):
     """tuber_gemm_tn_group: several weight-gradient GEMMs (plain and BN+ReLU operand, one with the strided row gather of the
     down_sample conv, single- and multi-slab, direct accumulation and slab partials) in one launch == the individual launches"""
     import ctypes
-    from tubelet_transformer_amd.backbone import TnArgs
+    from tubelet_transformer_amd.engine import TnArgs
     assert lib.query("tuber_gemm_tn_args_bytes") == ctypes.sizeof(TnArgs)
     n_, Ti, Hi, Wi, st, ss = 2, 4, 8, 10, 2, 2
     To, Ho, Wo = Ti // st, Hi // ss, Wi // ss
     probs = [(5632, 1024, 256, 1, None), (5632, 256, 1024, 0, None), (704, 512, 2048, 0, None), (n_ * To * Ho * Wo, 512, 256, 0, (To, Ho, Wo, Ti, Hi, Wi, st, ss)),
-             (44032, 128, 512, 0, None)]
+             (44032, 128, 512, 0, None), (704, 2048, 256, 0, "bias"), (16896, 256, 256, 0, "bias")]
     entries, keep, singles = [], [], []
     for i, (M, N, K, amode, gather) in enumerate(probs):
+        bias = gather == "bias"                      # fused bias gradient (nn.Linear weight gradients of the transformer)
+        gather = None if bias else gather
         rows_a = n_ * Ti * Hi * Wi if gather else M
         G = rnd(M, N, dev=dev, seed=10 + i).to(BF)
         A = rnd(rows_a, K, dev=dev, seed=20 + i).to(BF)
@@ -731,20 +733,24 @@ def test_gemm_tn_group_is_bit_identical_to_single_launches(dev):
             out = torch.full((N, K), 0.25, device=dev)
             part = torch.full((max(S, 1) * N * K,), float("nan"), device=dev) if S > 1 else None
             acc = 2 if S > 1 else 1
+            bg = torch.full((max(S, 1) * N,), 0.5, device=dev) if bias else None
             if grouped:
                 entries.append(TnArgs(G.data_ptr(), N, A.data_ptr(), K, part.data_ptr() if part is not None else None, out.data_ptr(), acc, M, N, K,
-                                      amode, 1 if gather else 0, *g, sc.data_ptr() if amode else None, sh.data_ptr() if amode else None))
+                                      amode, 1 if gather else 0, *g, sc.data_ptr() if amode else None, sh.data_ptr() if amode else None,
+                                      bg.data_ptr() if bias else None))
             else:
                 lib.call("tuber_gemm_tn", G, N, A, K, part, out, acc, M, N, K, amode, sc if amode else None, sh if amode else None,
-                         1 if gather else 0, *g, None, 0, None, None, None, None)
-            res.append((out, part))
+                         1 if gather else 0, *g, None, 0, None, None, None, bg)
+            res.append((out, part, bg))
         keep.append((G, A, sc, sh))
         singles.append(res)
     arr = (TnArgs * len(entries))(*entries)
     lib.call("tuber_gemm_tn_group", arr, len(entries))
     torch.cuda.synchronize()
-    for (M, N, K, amode, gather), ((o1, p1), (o2, p2)) in zip(probs, singles):
+    for (M, N, K, amode, gather), ((o1, p1, b1), (o2, p2, b2)) in zip(probs, singles):
         assert torch.equal(o1, o2), (M, N, K)
+        if b1 is not None:
+            assert torch.equal(b1, b2) and float((b1 - 0.5).abs().max()) > 0, (M, N, K)
         if p1 is not None:
             assert torch.equal(p1, p2), (M, N, K)
             assert bool(torch.isfinite(p1).all())

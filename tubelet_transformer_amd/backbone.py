@@ -13,13 +13,13 @@ Forward schedule per bottleneck (ir_CSN_152.py:70-90), all BN statistics fused i
     cd = gemm_nt(gather(x), Wd)    [+stats]   -> bn_finalize(down_sample.1)      (first block of a stage)
     y  = relu(bn4(c4) + (bn_d(cd) | x))
 """
-import ctypes
 import os
 
 import torch
 from torch import nn
 
 from . import lib
+from .engine import TnArgs, WgradQueue
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
 # measured on MI355X: one fused finalize+apply launch per layer3/4 BatchNorm (R <= 128) is 0.5 ms/step SLOWER than the two launches
@@ -107,17 +107,6 @@ def build_CSN(cfg):
 # ------------------------------------------------------------------------------------------------
 # fused schedule
 # ------------------------------------------------------------------------------------------------
-class TnArgs(ctypes.Structure):
-    """one entry of tuber_gemm_tn_group (struct TuberGemmTNArgs in csrc/gemm.hip)"""
-    _fields_ = [("G", ctypes.c_void_p), ("ldg", ctypes.c_long), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
-                ("partial", ctypes.c_void_p), ("out", ctypes.c_void_p)] + \
-               [(k, ctypes.c_int) for k in ("accumulate", "M", "N", "K", "amode", "gather", "To", "Ho", "Wo", "Ti", "Hi", "Wi", "st", "ss")] + \
-               [("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p)]
-
-
-GROUP_WGRADS = not os.environ.get("TUBER_NO_WGRAD_GROUPS")     # A/B switch: one tuber_gemm_tn launch per weight gradient
-
-
 class _BN:
     """Raw device pointers of one BatchNorm layer (params in the flat store + per-layer scratch)."""
     __slots__ = ("C", "gamma", "beta", "rmean", "rvar", "nbt", "dgamma", "dbeta", "scale", "shift", "mean", "invstd",
@@ -185,9 +174,6 @@ class CSNRunner:
                     d["bnd"] = mk_bn(p + "down_sample.1", blk.down_sample[1])
                 self.blocks.append(d)
         self._ws = {}
-        self._wq, self._wq_max = [], lib.query("tuber_gemm_tn_group_max")      # queued weight-gradient GEMMs (flush_wgrads)
-        if lib.query("tuber_gemm_tn_args_bytes") != ctypes.sizeof(TnArgs):
-            raise RuntimeError("TuberGemmTNArgs layout drift between backbone.py and libtuber_hip.so")
         # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
         body = [store.offsets[n] + (q.numel() + 63) // 64 * 64 for n, q in zip(store.names, store.params) if n.startswith(prefix)]
         self.body_end = max(body)
@@ -354,33 +340,24 @@ class CSNRunner:
         return dx
 
     def _wgrad(self, G, ldg, A, lda, out, M, N, K, amode=0, sc=None, sh=None, gather=None):
-        """weight gradient dW[N,K] += G^T f(A).  Nothing consumes it before the optimizer, so it is only QUEUED here (operand tensors
-        kept alive) and launched by ``flush_wgrads`` together with its neighbours in one tuber_gemm_tn_group launch."""
+        """weight gradient dW[N,K] += G^T f(A).  Nothing consumes it before the optimizer, so it is only QUEUED (engine.WgradQueue:
+        operand tensors kept alive) and launched together with its neighbours in one tuber_gemm_tn_group launch."""
         S = lib.query("tuber_gemm_tn_slabs", M, N, K)
         part, acc = self.store.partial("tn", S * N * K, self.ws) if S > 1 else (None, 1)
         g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
         outp = out if isinstance(out, int) else out.data_ptr()
-        if GROUP_WGRADS and (S == 1 or acc == 2) and not ((N | K | ldg | lda) & 7) and lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, lda):
+        wq = self.store.wq
+        if wq.enabled and (S == 1 or acc == 2) and WgradQueue.eligible(M, N, K, ldg, lda):
             ptr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
-            self._wq.append((TnArgs(ptr(G), ldg, ptr(A), lda, ptr(part), outp, acc, M, N, K, amode, 1 if gather else 0, *g, ptr(sc), ptr(sh)),
-                             (G, A), (part, outp, N * K, S) if acc == 2 else None))
-            if len(self._wq) >= self._wq_max:
-                self.flush_wgrads()
+            wq.add(TnArgs(ptr(G), ldg, ptr(A), lda, ptr(part), outp, acc, M, N, K, amode, 1 if gather else 0, *g, ptr(sc), ptr(sh), None),
+                   (G, A), [(part, outp, N * K, N * K, S, 0 if S <= 16 else 1)] if acc == 2 else [])
             return
         lib.call("tuber_gemm_tn", G, ldg, A, lda, part, out, acc, M, N, K, amode, sc, sh, 1 if gather else 0, *g, None, 0, None, None, None, None)
         if acc == 2:
             self.store.defer.add(part, outp, N * K, N * K, S, 0 if S <= 16 else 1)
 
     def flush_wgrads(self):
-        q, self._wq = self._wq, []
-        if not q:
-            return
-        arr = (TnArgs * len(q))(*[e[0] for e in q])
-        lib.call("tuber_gemm_tn_group", arr, len(q))
-        for _, _, d in q:
-            if d is not None:
-                part, outp, n, S = d
-                self.store.defer.add(part, outp, n, n, S, 0 if S <= 16 else 1)
+        self.store.wq.flush()
 
     def backward(self, saved, dfeat):
         """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients of the TRAINABLE tensors are

@@ -1014,6 +1014,7 @@ struct TuberGemmTNArgs {
     const void* G; long ldg; const void* A; long lda; float* partial; float* out;
     int accumulate, M, N, K, amode, gather, To, Ho, Wo, Ti, Hi, Wi, st, ss;
     const float* a_scale; const float* a_shift;
+    float* bias_grad;            // optional, as in tuber_gemm_tn: dbias[N] (single slab, accumulated) or [slabs][N] partial rows
 };
 int tuber_gemm_tn_args_bytes(void) { return (int)sizeof(TuberGemmTNArgs); }
 int tuber_gemm_tn_group_max(void) { return TN_GROUP_MAX; }
@@ -1042,7 +1043,7 @@ int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
         p.P = p.S == 1 ? x.out : x.partial;
         if (!p.P) return TUBER_EINVAL;
         p.a_scale = x.a_scale; p.a_shift = x.a_shift;
-        p.G2 = nullptr; p.ldg2 = 0; p.gA = p.gB = p.gC = nullptr; p.bias_grad = nullptr;
+        p.G2 = nullptr; p.ldg2 = 0; p.gA = p.gB = p.gC = nullptr; p.bias_grad = x.bias_grad;
         p.gather = x.gather; p.To = x.To; p.Ho = x.Ho; p.Wo = x.Wo; p.Ti = x.Ti; p.Hi = x.Hi; p.Wi = x.Wi; p.st = x.st; p.ss = x.ss;
         p.amode = x.amode;
         g.begin[i] = total;

@@ -15,7 +15,7 @@ DOC = {
     "tuber_gemm_tn_group": "n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly one tuber_gemm_tn: dW = G^T f(A) of a 1x1x1 conv, "
                            "autograd of models/backbones/ir_CSN_152.py:41,58,155-161) in ONE launch; args_host = HOST array of struct TuberGemmTNArgs "
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
-                           "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift;} with the meaning of the tuber_gemm_tn arguments. "
+                           "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift; float* bias_grad;} with the meaning of the tuber_gemm_tn arguments. "
                            "Transpose-read kernel shapes only (N, K, ld multiples of 8, 64x64 tiles); several slabs need accumulate = 2 (the caller reduces them).",
     "tuber_gemm_tn_args_bytes": "sizeof(struct TuberGemmTNArgs) as compiled (host-side layout check).",
     "tuber_gemm_tn_group_max": "largest n tuber_gemm_tn_group accepts (the argument blocks travel by value in the kernel argument segment).",

@@ -10,6 +10,7 @@ Layout in HBM (per model, per GPU):
                operands of the data-gradient GEMMs; leading dimension padded to a multiple of 64.
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -22,6 +23,49 @@ ALIGN = 64
 
 def _ceil(x, m):
     return (x + m - 1) // m * m
+
+
+class TnArgs(ctypes.Structure):
+    """one entry of tuber_gemm_tn_group (struct TuberGemmTNArgs in csrc/gemm.hip)"""
+    _fields_ = [("G", ctypes.c_void_p), ("ldg", ctypes.c_long), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
+                ("partial", ctypes.c_void_p), ("out", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int) for k in ("accumulate", "M", "N", "K", "amode", "gather", "To", "Ho", "Wo", "Ti", "Hi", "Wi", "st", "ss")] + \
+               [("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p)]
+
+
+class WgradQueue:
+    """Weight-gradient GEMMs feed nothing until the optimizer: the backbone and the tape queue them here (operand tensors kept
+    alive) and ``flush`` launches up to 8 of them in ONE tuber_gemm_tn_group launch -- fewer launch gaps, and for the short-M
+    layer3 / layer4 / transformer shapes enough independent workgroups in flight to fill 256 CUs.  Flushed before every deferred
+    second-stage reduction (DeferredReduce.flush), so gradient windows are complete wherever the old per-call launches had them."""
+
+    def __init__(self, store):
+        self.store, self.q = store, []
+        self.enabled = not os.environ.get("TUBER_NO_WGRAD_GROUPS")        # A/B switch: one tuber_gemm_tn launch per weight gradient
+        self.max = lib.query("tuber_gemm_tn_group_max")
+        if lib.query("tuber_gemm_tn_args_bytes") != ctypes.sizeof(TnArgs):
+            raise RuntimeError("TuberGemmTNArgs layout drift between engine.py and libtuber_hip.so")
+
+    @staticmethod
+    def eligible(M, N, K, ldg, lda):
+        """shapes the transpose-read kernel takes (64 x 64 output tiles, 8-element aligned)"""
+        return not ((N | K | ldg | lda) & 7) and lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, lda) != 0
+
+    def add(self, args, keep, defers):
+        """args: TnArgs; keep: tensors that must outlive the launch; defers: DeferredReduce.add argument tuples registered at flush"""
+        self.q.append((args, keep, defers))
+        if len(self.q) >= self.max:
+            self.flush()
+
+    def flush(self):
+        q, self.q = self.q, []
+        if not q:
+            return
+        arr = (TnArgs * len(q))(*[e[0] for e in q])
+        lib.call("tuber_gemm_tn_group", arr, len(q))
+        for _, _, defers in q:
+            for d in defers:
+                self.store.defer.add(*d)
 
 
 class DeferredReduce:
@@ -40,6 +84,7 @@ class DeferredReduce:
         self.enabled = not os.environ.get("TUBER_IMMEDIATE_REDUCE")
         self.chunks, self.ci, self.off = [], 0, 0
         self.entries, self.outs, self.heads, self.cache = [], {}, [], {}
+        self.pre_flush = None
 
     def reset(self):
         """start of a step: the arena is reused from its first byte (nothing may be pending)."""
@@ -86,6 +131,8 @@ class DeferredReduce:
         self.entries.append(ent)
 
     def flush(self):
+        if self.pre_flush is not None:
+            self.pre_flush()             # queued weight-gradient GEMMs register their slab reductions when they are launched
         if not self.entries:
             return
         key = tuple(tuple(e) for e in self.entries)
@@ -168,6 +215,8 @@ class ParamStore:
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.defer = DeferredReduce(self.device)
+        self.wq = WgradQueue(self)
+        self.defer.pre_flush = self.wq.flush
 
     @staticmethod
     def _is_gemm_weight(name, p):

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import lib
+from .engine import TnArgs
 
 BF = torch.bfloat16
 _WS = {}
@@ -100,6 +101,7 @@ class Tape:
                 self.put(t, g)
         for fn in reversed(self.ops):
             fn()
+        self.store.wq.flush()
         self.clear()
 
     def clear(self):
@@ -176,14 +178,22 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) if breq else 0
             part, acc = st.partial("tn", S * N * K, ws) if S > 1 else (None, 1)
             bpart = st.partial("cs", S * N, ws)[0] if fuse_b == 2 else None
-            lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, acc, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None,
-                     gbias if fuse_b == 1 else bpart)
+            bptr = gbias if fuse_b == 1 else bpart
+            defers = []
             if acc == 2:
-                st.defer.add(part, gw, N * K, N * K, S, 0 if S <= 16 else 1)
-            if fuse_b == 2:
-                if acc == 2:
-                    st.defer.add(bpart, gbias, N, N, S, 1)
-                else:
+                defers.append((part, gw, N * K, N * K, S, 0 if S <= 16 else 1))
+                if fuse_b == 2:
+                    defers.append((bpart, gbias, N, N, S, 1))
+            if st.wq.enabled and (S == 1 or acc == 2) and st.wq.eligible(M, N, K, ldg, K):
+                # nothing reads a weight gradient before the optimizer: queued, launched with its neighbours (engine.WgradQueue)
+                ptr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+                st.wq.add(TnArgs(gb.data_ptr(), ldg, x.data_ptr(), K, ptr(part), gw, acc, M, N, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None, ptr(bptr)),
+                          (gb, x), defers)
+            else:
+                lib.call("tuber_gemm_tn", gb, ldg, x, K, part, gw, acc, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, None, None, bptr)
+                for d in defers:
+                    st.defer.add(*d)
+                if fuse_b == 2 and acc != 2:
                     lib.call("tuber_reduce_rows", bpart, gbias, S, N, 1)
         if breq and not fuse_b:
             nbc = lib.query("tuber_colsum_blocks", M)
@@ -531,6 +541,7 @@ def backbone(tp, runner, clips, bn_train):
         def bwd():
             g = tp.take(f2)
             if g is not None:
+                tp.store.wq.flush()          # transformer / head weight gradients: complete before the reducer is told so
                 runner.backward(saved, g.contiguous())
         tp.rec(bwd)
     return f2
