@@ -42,6 +42,12 @@ def alg_cost(name, a):
         tile, occ = {0: ("128,128,2,2,2", 2), 2: ("64,64,2,2,4", 4), 7: ("64,128,1,4,2", 3), 12: ("64,64,2,2,4", 3), 13: ("64,64,2,2,2", 4),
                      17: ("64,128,1,4,2", 4)}[cfg]
         return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, occ), by, 2 * M * N * K
+    if name == "tuber_gemm_nt_join":
+        M, N, K = a[6], a[7], a[8]
+        cfg = lib.query("tuber_gemm_nt_cfg", M, N, K)
+        tile, occ = {0: ("64,128,1,4,2", 3), 7: ("64,128,1,4,2", 3), 13: ("64,64,2,2,2", 4)}.get(cfg, ("64,64,2,2,2", 4))
+        by = 2 * (M * K + N * K + M * N) + 2 * M * N * (3 if a[9] is not None else 2)      # + residual, mask source y, statistics operand c4
+        return "gemm_nt_kernel<%s,0,3,%d>" % (tile, occ), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
         T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64
@@ -87,6 +93,8 @@ def alg_cost(name, a):
 def shape_of(name, a):
     if name == "tuber_gemm_nt":
         return "M%d N%d K%d amode%d epi%d" % (a[6], a[7], a[8], a[9], a[21])
+    if name == "tuber_gemm_nt_join":
+        return "M%d N%d K%d join" % (a[6], a[7], a[8])
     if name == "tuber_gemm_tn":
         return "M%d N%d K%d amode%d" % (a[7], a[8], a[9], a[10])
     if name == "tuber_gemm_tn_group":
@@ -293,12 +301,12 @@ def main():
         step()
     dominant, prepass = None, None
     if not args.no_roofline:
+        eager_step()                                    # untimed: first eager step after the capture (allocator warm-up)
+        torch.cuda.synchronize()
         timer = LaunchTimer()
         lib.set_launch_hook(timer)
-        os.environ["TUBER_NO_SIDE_STREAM"] = "1"        # per-kernel timing: every launch on one stream even if TUBER_SIDE_STREAM is set
         eager_step()
         torch.cuda.synchronize()
-        os.environ.pop("TUBER_NO_SIDE_STREAM", None)
         lib.set_launch_hook(None)
         prepass = timer.summary()
         if os.environ.get("TUBER_BENCH_SHAPES") and rank == 0:
@@ -316,11 +324,9 @@ def main():
     timer = LaunchTimer(only=dominant) if dominant else None
     if timer:
         lib.set_launch_hook(timer)
-        os.environ["TUBER_NO_SIDE_STREAM"] = "1"
         for _ in range(min(args.steps, 3)):
             eager_step()
         torch.cuda.synchronize()
-        os.environ.pop("TUBER_NO_SIDE_STREAM", None)
         lib.set_launch_hook(None)
         timed_steps = min(args.steps, 3)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

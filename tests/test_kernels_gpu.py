@@ -756,3 +756,31 @@ def test_gemm_tn_group_is_bit_identical_to_single_launches(dev):
             assert bool(torch.isfinite(p1).all())
         else:
             assert float((o1 - 0.25).abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,N,K,res", [(5632, 1024, 256, True), (44032, 512, 128, True), (2816, 2048, 512, False), (1000, 256, 64, True)])
+def test_gemm_nt_join_equals_dgrad_then_block_out_bwd(dev, M, N, K, res):
+    """tuber_gemm_nt_join == tuber_gemm_nt(+R) followed by tuber_block_out_bwd: dz bit-identical, partial statistics equal after
+    summing their rows (the two paths cut the rows into different blocks)"""
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    Rr = rnd(M, N, dev=dev, seed=3).to(BF) if res else None
+    Y = rnd(M, N, dev=dev, seed=4).to(BF).relu()
+    C4 = rnd(M, N, dev=dev, seed=5).to(BF)
+    dx = torch.empty(M, N, device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt", A, K, B, K, dx, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+             0, None, Rr, N, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+    R0 = lib.query("tuber_rowblock_count", M, N)
+    a0, a1 = torch.zeros(R0, N, device=dev), torch.zeros(R0, N, device=dev)
+    dz0 = torch.empty(M, N, device=dev, dtype=BF)
+    lib.call("tuber_block_out_bwd", dx, Y, C4, None, dz0, a0, a1, None, M, N)
+    R1 = lib.query("tuber_gemm_nt_stat_rows", M, N)
+    b0, b1 = torch.full((R1, N), float("nan"), device=dev), torch.full((R1, N), float("nan"), device=dev)
+    dz1 = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt_join", A, K, B, K, dz1, N, M, N, K, Rr, N, Y, N, C4, N, b0, b1)
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1)
+    ref = (A.float() @ B.float().t() + (Rr.float() if res else 0)) * (Y.float() > 0)
+    close("join dz vs torch", dz1, ref)
+    close("join sum dz", b0.sum(0), a0.sum(0), abs_=1e-4 * float(dz0.float().abs().sum(0).max()))
+    close("join sum dz*c4", b1.sum(0), a1.sum(0), abs_=1e-4 * float((dz0.float() * C4.float()).abs().sum(0).max()))

@@ -25,6 +25,7 @@ BN_EPS = 1e-3       # ir_CSN_152.py:15
 # measured on MI355X: one fused finalize+apply launch per layer3/4 BatchNorm (R <= 128) is 0.5 ms/step SLOWER than the two launches
 # (1024-thread workgroups on 64-byte row segments, coefficients re-derived by every row chunk) -- off; A/B with the env variable
 BN_FUSED_MAX_ROWS = int(os.environ.get("TUBER_BN_FUSED_MAX_ROWS", "0"))
+JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -370,6 +371,7 @@ class CSNRunner:
         if red is not None:           # everything behind the body (transformer, heads, pool decoder) is final
             red.notify(self.body_end, force=True)
         nblk = len(self.blocks)
+        pre = None          # (dz, sum-dz rows, sum-dz*c4 rows, R) of this block's join backward, produced by the block above (tuber_gemm_nt_join)
         for bi in range(nblk - 1, lowest - 1, -1):
             d, sv, f = self.blocks[bi], saved["blocks"][bi], plans[bi]
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
@@ -382,10 +384,14 @@ class CSNRunner:
             # 3 = bn3, 2 = conv4 weight, 1 = bn4 / shortcut only
             depth = 7 if need_dx else (6 if f["w1"] else 5 if f["bn1"] else 4 if f["w3"] else 3 if f["bn3"] else 2 if f["w4"] else 1)
             # join backward: dz + stats of bn4 (and the shortcut BN)
-            R = lib.query("tuber_rowblock_count", Mout, C4)
-            sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
-            dz = torch.empty(Mout, C4, dtype=BF, device=dev)
-            lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
+            if pre is not None:
+                dz, sa, sb, R = pre
+                pre, sc_ = None, None
+            else:
+                R = lib.query("tuber_rowblock_count", Mout, C4)
+                sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
+                dz = torch.empty(Mout, C4, dtype=BF, device=dev)
+                lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
             dc4 = None
             if depth >= 2 or f["bn4"]:
                 dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2)
@@ -434,7 +440,6 @@ class CSNRunner:
             if d["ds"] and f["wd"]:
                 self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
             if need_dx:
-                dx = torch.empty(Min, cin, dtype=BF, device=dev)
                 res = dz if not d["ds"] else None
                 if d["ds"]:
                     dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
@@ -442,11 +447,25 @@ class CSNRunner:
                              0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
                     if not strided:
                         res = dxd           # stride-1 projection shortcut: its dense data gradient is the residual input
-                lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                         0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
-                if d["ds"] and strided:
-                    lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
-                dy = dx
+                # The input gradient dx IS the gradient of the block below's output y (= this block's x).  When that block is an
+                # identity block and dx is complete after this GEMM, its join backward (dz = dx * [y > 0] + the bn4 statistics) runs
+                # as the GEMM's epilogue: dx never reaches HBM and the block_out_bwd launch of the next iteration is gone.
+                fuse = JOIN_FUSION and bi - 1 >= 0 and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
+                if fuse:
+                    c4l = saved["blocks"][bi - 1][3]
+                    Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
+                    ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
+                    dzl = torch.empty(Min, cin, dtype=BF, device=dev)
+                    lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
+                    pre = (dzl, ja, jb, Rj)
+                    dy = None
+                else:
+                    dx = torch.empty(Min, cin, dtype=BF, device=dev)
+                    lib.call("tuber_gemm_nt", dc1, P, d["w1t"], d["ld1t"], dx, cin, Min, cin, P, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                             0, None, res, cin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+                    if d["ds"] and strided:
+                        lib.call("tuber_rows_scatter_add", dx, dxd, Mout, To, Hq, Wq, Ti, Hi, Wi, st, ss, cin)
+                    dy = dx
             # layer1 / layer2 weight gradients are long GEMMs: launched per bottleneck (their operands are 45-180 MB each);
             # layer3 / layer4 ones are short: up to 8 (four bottlenecks) share a launch
             if d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):

@@ -25,7 +25,10 @@
 #include "common.h"
 
 enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2 };     // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply)
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3 };
+// EPI_JOIN: the data-gradient GEMM of one bottleneck's conv1 fused with the join backward of the bottleneck below it:
+//   dz = (acc + R) * [Ym > 0]   (R = identity-shortcut gradient, Ym = the lower block's output y = relu(bn4(c4) + x))
+//   + BatchNorm-backward partial statistics (sum dz, sum dz * Cm) with Cm = the lower block's raw conv4 output.
 
 struct GemmNT {
     const bf16* A; long lda;
@@ -38,6 +41,7 @@ struct GemmNT {
     const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
     const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
+    const bf16* Ym; long ldym;                    // EPI_JOIN: mask source (dz = v * [Ym > 0]); Cm is the statistics operand
     float alpha;                                  // accumulators are scaled by alpha before the epilogue
     uint32_t drop_thresh; float drop_inv_keep; const uint64_t* seed_ptr; uint64_t salt;   // EPI_PLAIN: Dropout after bias/residual/ReLU
 };
@@ -210,15 +214,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
     for (int j = 0; j < G; ++j)
         if (j < nk) load_tile(j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
-    uint4 side[EPI == EPI_BWD ? MT : 1][NC / 8];         // EPI_BWD: the mask source c, fetched behind the k-loop
-    const bool side_vec = EPI == EPI_BWD && vec_ok && ((p.ldcm & 7) == 0);
-    if (EPI == EPI_BWD && side_vec) {
+    constexpr bool SIDE = EPI == EPI_BWD || EPI == EPI_JOIN;
+    uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
+    uint4 sidey[EPI == EPI_JOIN ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
+    const bool side_vec = SIDE && vec_ok && ((p.ldcm & 7) == 0) && (EPI != EPI_JOIN || (p.ldym & 7) == 0);
+    if (SIDE && side_vec) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * TM + i * 16 + li;
 #pragma unroll
-            for (int c8 = 0; c8 < NC / 8; ++c8)
-                side[EPI == EPI_BWD ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+            for (int c8 = 0; c8 < NC / 8; ++c8) {
+                side[SIDE ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (EPI == EPI_JOIN)
+                    sidey[EPI == EPI_JOIN ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+            }
         }
     }
     if (AMODE != A_PLAIN) {
@@ -303,12 +312,38 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
             }
+        } else if (EPI == EPI_JOIN) {
+            if (mok) {
+                if (p.R) {
+                    if (vec_ok && (p.ldr & 7) == 0) {
+#pragma unroll
+                        for (int c8 = 0; c8 < NC / 8; ++c8) {
+                            const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + (long)m * p.ldr + nb + c8 * 8));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[c8 * 8 + e] += bf2f(rv[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (nb + c < p.N) {
+                        const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
+                        const float yv = side_vec ? bf2f(as_bf16x8(sidey[EPI == EPI_JOIN ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c]);
+                        // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
+                        v[c] = yv > 0.f ? bf2f(f2bf(v[c])) : 0.f;
+                        s0[c] += v[c]; s1[c] += v[c] * cv;
+                    }
+                }
+            }
         } else {  // EPI_BWD: dz = acc * [relu'(bn(c))];  stats: sum dz, sum dz*c
             if (mok) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if (nb + c < p.N) {
-                        const float cv = side_vec ? bf2f(as_bf16x8(side[EPI == EPI_BWD ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
+                        const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
                         const float z = fmaf(cv, msc[c], msh[c]);
                         v[c] = z > 0.f ? v[c] : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
@@ -383,11 +418,13 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
+        else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
         else LNT(A_PLAIN, EPI_BWD);
     } else {
         if (amode == A_BN_RELU) {
             if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
+            else if (epi == EPI_JOIN) return TUBER_EINVAL;
             else LNT(A_BN_RELU, EPI_BWD);
         } else {
             return TUBER_EINVAL;                          // A_BN_BWD prologue: measured slower than the separate apply kernel, not built
@@ -414,6 +451,7 @@ static int nt_pick_cfg(int M, int N, int K) {
     if ((long)M * N >= (1L << 25) && N >= 1024 && K >= 256) return 0;
     return (N >= 256 && K <= 512 && M >= 2048) ? 7 : 13;
 }
+static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream);
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
     if (cfg == 0) { *bm = 128; *wm = 2; }
     else if (cfg == 7 || cfg == 17) { *bm = 64; *wm = 1; }
@@ -461,6 +499,31 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
+    p.Ym = nullptr; p.ldym = 0;
+    return nt_dispatch(p, amode, epi, stream);
+}
+
+// Conv1 data gradient of one bottleneck FUSED with the join backward of the bottleneck below it (whose output y is this conv's input):
+//   dz[M,N] = (A[M,K] . B[N,K]^T + R) * [Y > 0],  stat0 / stat1 rows = partial (sum dz, sum dz * Cm) per 64 output rows
+// i.e. tuber_gemm_nt(epi 0, +R) followed by tuber_block_out_bwd on its output, without dx ever reaching HBM
+// (autograd of ir_CSN_152.py:72,86-89 at a block boundary).  R may be NULL (projection-shortcut blocks add their own gradient first).
+int tuber_gemm_nt_join(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                       const void* R, long ldr, const void* Y, long ldy, const void* Cm, long ldcm, float* stat0, float* stat1,
+                       hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || !Y || !Cm || !stat0 || !stat1) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm;
+    p.Ym = (const bf16*)Y; p.ldym = ldy;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN, stream);
+}
+
+static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) {
+    const int M = p.M, N = p.N, K = p.K;
     int cfg = nt_pick_cfg(M, N, K);
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
     switch (cfg) {
@@ -933,7 +996,9 @@ static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 1
 static int tn_slabs_wanted(int M, int N, int K) {
     const int T = tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
-    long S = (512 + tiles - 1) / tiles;
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 512; }     // experiments only
+    long S = (target + tiles - 1) / tiles;
     // bound the fp32 slab traffic (S*N*K*4 B written + read) by the size of the operands (2*M*(N+K) B);
     // tiny outputs (<= 16 tiles: <= 256 KB per slab) may split deeply
     long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);

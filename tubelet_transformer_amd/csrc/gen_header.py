@@ -12,6 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_gemm_nt_join": "conv1 data gradient of one bottleneck fused with the join backward of the bottleneck below it: dz = (A.B^T + R) * [Y > 0] "
+                          "plus the BatchNorm-backward partial rows (sum dz, sum dz*Cm) per 64 output rows (tuber_gemm_nt_stat_rows) -- "
+                          "tuber_gemm_nt(epi 0, +R) followed by tuber_block_out_bwd without dx reaching HBM (autograd of "
+                          "models/backbones/ir_CSN_152.py:72,86-89 across a block boundary). Y = the lower block's output, Cm = its raw conv4 output; R may be NULL.",
     "tuber_gemm_tn_group": "n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly one tuber_gemm_tn: dW = G^T f(A) of a 1x1x1 conv, "
                            "autograd of models/backbones/ir_CSN_152.py:41,58,155-161) in ONE launch; args_host = HOST array of struct TuberGemmTNArgs "
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
