@@ -127,6 +127,13 @@ def build_matcher(cfg):
                             data_file=cfg.CONFIG.DATA.DATASET_NAME, binary_loss=M.BNY_LOSS, before=M.BEFORE)
 
 
+def _class_error(logits, pt, match, ava):
+    B, Q, C = logits.shape
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    lib.call("tuber_class_error", logits.contiguous(), match.contiguous(), pt.tlabels, B, Q, C, pt.tmax, 1 if ava else 0, out)
+    return out[0]
+
+
 class _LossFn(torch.autograd.Function):
     """losses[L,4] = (ce, ce_b, bbox, giou) per decoder layer; gradients precomputed by the forward kernel."""
 
@@ -298,17 +305,9 @@ class SetCriterionAVA(_SetCriterionBase):
 
     @torch.no_grad()
     def class_error(self, logits, pt, match):
-        """100 - exact-set accuracy of the matched queries (utils/misc.py:497-518), computed on the device without a sync:
-        top-k(labels) == labels  <=>  min logit over the labels > max logit over the rest."""
-        B, Q, C = logits.shape
-        valid = match >= 0                                                   # [B,Tmax]
-        q = match.clamp(min=0).long()
-        rows = torch.gather(logits, 1, q[:, :, None].expand(-1, -1, C))      # [B,Tmax,C]
-        lab = pt.tlabels > 0.5
-        lo = torch.where(lab, rows, rows.new_full((), float("inf"))).amin(-1)
-        hi = torch.where(lab, rows.new_full((), float("-inf")), rows).amax(-1)
-        ok = (lo > hi) & valid
-        return 100.0 - 100.0 * ok.sum() / valid.sum().clamp(min=1)
+        """100 - exact-set accuracy of the matched queries (utils/misc.py:497-518): top-k(labels) == labels  <=>  min logit over the
+        labels > max logit over the rest.  One kernel, no sync."""
+        return _class_error(logits, pt, match, True)
 
 
 class SetCriterion(_SetCriterionBase):
@@ -336,11 +335,8 @@ class SetCriterion(_SetCriterionBase):
 
     @torch.no_grad()
     def class_error(self, logits, pt, match):
-        valid = match >= 0
-        q = match.clamp(min=0).long()
-        rows = torch.gather(logits, 1, q[:, :, None].expand(-1, -1, logits.shape[-1]))
-        ok = (rows.argmax(-1) == pt.tlabels.long()) & valid
-        return 100.0 - 100.0 * ok.sum() / valid.sum().clamp(min=1)
+        """100 - top-1 accuracy of the matched queries (utils/misc.py:521-539)."""
+        return _class_error(logits, pt, match, False)
 
 
 class PostProcess(nn.Module):

@@ -299,6 +299,59 @@ __global__ void lsap_kernel(const float* __restrict__ cost, const int* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// class_error of the matched queries (utils/misc.py:497-518 accuracy_sigmoid / :521-539 accuracy, logged by criterion.py:76-78,
+// 258-260): 100 - 100 * (#matched queries whose prediction is exactly right) / (#matched queries), one workgroup, no host sync.
+//   AVA (multi-label):  right <=> top-k(logits) == label set <=> min logit over the labels > max logit over the rest
+//   JHMDB (single label): right <=> argmax(logits) == label
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void class_error_kernel(const float* __restrict__ logits, const int* __restrict__ match,
+                                                           const float* __restrict__ tlabels, int B, int Q, int C, int Tmax, int ava,
+                                                           float* __restrict__ out) {
+    __shared__ int sh_ok[256], sh_n[256];
+    int ok = 0, n = 0;
+    for (int i = threadIdx.x; i < B * Tmax; i += 256) {
+        const int q = match[i];
+        if (q < 0) continue;
+        const int b = i / Tmax;
+        const float* row = logits + ((long)b * Q + q) * C;
+        ++n;
+        if (ava) {
+            const float* lab = tlabels + (long)i * C;
+            float lo = INFINITY, hi = -INFINITY;
+            for (int c = 0; c < C; ++c) {
+                const float v = row[c];
+                if (lab[c] > 0.5f) lo = fminf(lo, v); else hi = fmaxf(hi, v);
+            }
+            ok += lo > hi;
+        } else {
+            int am = 0;
+            float best = row[0];
+            for (int c = 1; c < C; ++c) if (row[c] > best) { best = row[c]; am = c; }
+            ok += am == (int)tlabels[i];
+        }
+    }
+    sh_ok[threadIdx.x] = ok; sh_n[threadIdx.x] = n;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh_ok[threadIdx.x] += sh_ok[threadIdx.x + s]; sh_n[threadIdx.x] += sh_n[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = 100.f - 100.f * (float)sh_ok[0] / (float)(sh_n[0] > 0 ? sh_n[0] : 1);
+}
+
+// key-padding mask of the feature grid: nearest-neighbour resize of the clip padding mask, F.interpolate(mask[None].float(),
+// size=(h, w)).to(bool) (models/backbone_builder.py:85-86): src = min(floor(dst * (float)in / out), in - 1), ATen's rule
+__global__ void mask_resize_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int B, int H, int W, int h, int w,
+                                   float sy, float sx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * h * w) return;
+    const int x = i % w, y = (i / w) % h, b = i / (w * h);
+    const int yy = min((int)floorf(y * sy), H - 1), xx = min((int)floorf(x * sx), W - 1);
+    out[i] = mask[((long)b * H + yy) * W + xx] ? 1 : 0;
+}
+
 extern "C" {
 
 int tuber_criterion_cost(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
@@ -330,6 +383,24 @@ int tuber_criterion_loss(const float* logits, const float* logits_b, const float
 int tuber_lsap_device(const float* cost, const int* tcount, int* match, int L, int B, int Q, int Tmax, hipStream_t stream) {
     if (L <= 0 || B <= 0 || Q <= 0 || Tmax <= 0 || Q > LSAP_MAX || Tmax > LSAP_MAX) return TUBER_EINVAL;
     hipLaunchKernelGGL(lsap_kernel, dim3(L * B), dim3(64), 0, stream, cost, tcount, match, L, B, Q, Tmax);
+    TUBER_RETURN_LAUNCH();
+}
+
+// class_error [1] (fp32, device) of one decoder layer's matched queries; logits [B,Q,C] fp32, match [B,Tmax] (query or -1),
+// tlabels [B,Tmax,C] multi-hot (ava) or [B,Tmax] class index stored as float (jhmdb)
+int tuber_class_error(const float* logits, const int* match, const float* tlabels, int B, int Q, int C, int Tmax, int ava, float* out,
+                      hipStream_t stream) {
+    if (B <= 0 || Q <= 0 || C <= 0 || Tmax <= 0 || !out) return TUBER_EINVAL;
+    hipLaunchKernelGGL(class_error_kernel, dim3(1), dim3(256), 0, stream, logits, match, tlabels, B, Q, C, Tmax, ava, out);
+    TUBER_RETURN_LAUNCH();
+}
+
+// mask [B,H,W] (bool / uint8, nonzero = padding) -> out [B,h,w] uint8
+int tuber_mask_resize(const void* mask, void* out, int B, int H, int W, int h, int w, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return TUBER_EINVAL;
+    const int n = B * h * w;
+    hipLaunchKernelGGL(mask_resize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const uint8_t*)mask, (uint8_t*)out, B, H, W, h, w,
+                       (float)H / (float)h, (float)W / (float)w);
     TUBER_RETURN_LAUNCH();
 }
 

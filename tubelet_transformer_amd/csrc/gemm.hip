@@ -997,7 +997,9 @@ static int tn_slabs_wanted(int M, int N, int K) {
     const int T = tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
     static int target = -1;
-    if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 512; }     // experiments only
+    // workgroups aimed for per GEMM: 256 since the weight gradients travel in grouped launches (tuber_gemm_tn_group: 2-8 GEMMs share the
+    // chip, so each needs fewer slabs to fill it: 18.87 -> 18.65 ms/step against 512, and half the slab traffic; 128 loses again)
+    if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 256; }
     long S = (target + tiles - 1) / tiles;
     // bound the fp32 slab traffic (S*N*K*4 B written + read) by the size of the operands (2*M*(N+K) B);
     // tiny outputs (<= 16 tiles: <= 256 KB per slab) may split deeply

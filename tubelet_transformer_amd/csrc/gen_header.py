@@ -12,6 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_class_error": "class_error of the matched queries of one decoder layer, on the device: 100 - exact-set accuracy (AVA, utils/misc.py:497-518 "
+                         "via models/criterion.py:76-78) or top-1 accuracy (JHMDB, utils/misc.py:521-539 via criterion.py:258-260).",
+    "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "
+                         "clip padding mask to the feature grid = the transformer's key-padding mask, ATen's source-index rule.",
     "tuber_gemm_nt_join": "conv1 data gradient of one bottleneck fused with the join backward of the bottleneck below it: dz = (A.B^T + R) * [Y > 0] "
                           "plus the BatchNorm-backward partial rows (sum dz, sum dz*Cm) per 64 output rows (tuber_gemm_nt_stat_rows) -- "
                           "tuber_gemm_nt(epi 0, +R) followed by tuber_block_out_bwd without dx reaching HBM (autograd of "

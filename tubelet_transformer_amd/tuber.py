@@ -274,8 +274,9 @@ class DETR(nn.Module):
             xs = T.temporal_max(tp, feat, B, Tp, hw)
         else:                                   # mid-frame slice (backbone_builder.py:79-80)
             xs = T.mid_frame(tp, feat, B, Tp, hw)
-        m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]          # [B,h,w] (backbone_builder.py:85)
-        kpm = m.reshape(B, hw).to(torch.uint8).contiguous()
+        kpm = torch.empty(B, hw, dtype=torch.uint8, device=dev)                       # [B,h*w] key-padding mask (backbone_builder.py:85)
+        mk = mask if mask.dtype in (torch.bool, torch.uint8) else mask != 0
+        lib.call("tuber_mask_resize", mk.contiguous(), kpm, B, mask.shape[-2], mask.shape[-1], h, w)
         pos = torch.empty(B * hw, E, dtype=BF, device=dev)
         lib.call("tuber_posenc", kpm, pos, B, 1, h, w, E)
 
