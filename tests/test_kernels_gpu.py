@@ -784,3 +784,57 @@ def test_gemm_nt_join_equals_dgrad_then_block_out_bwd(dev, M, N, K, res):
     close("join dz vs torch", dz1, ref)
     close("join sum dz", b0.sum(0), a0.sum(0), abs_=1e-4 * float(dz0.float().abs().sum(0).max()))
     close("join sum dz*c4", b1.sum(0), a1.sum(0), abs_=1e-4 * float((dz0.float() * C4.float()).abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("B,H,W,h,w", [(2, 256, 340, 16, 22), (2, 288, 384, 18, 24), (3, 64, 96, 4, 6), (1, 224, 224, 14, 14), (2, 250, 333, 16, 21)])
+def test_mask_resize_matches_interpolate_nearest(dev, B, H, W, h, w):
+    """tuber_mask_resize == F.interpolate(mask[None].float(), size=(h, w)).to(bool)[0] (backbone_builder.py:85-86) for ragged padding masks"""
+    g = torch.Generator().manual_seed(B * H + W)
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    for b in range(B):
+        hh, ww = int(torch.randint(H // 2, H + 1, (1,), generator=g)), int(torch.randint(W // 2, W + 1, (1,), generator=g))
+        mask[b, hh:, :] = True
+        mask[b, :, ww:] = True
+    mask = mask.to(dev)
+    out = torch.empty(B, h * w, dtype=torch.uint8, device=dev)
+    lib.call("tuber_mask_resize", mask, out, B, H, W, h, w)
+    ref = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0].reshape(B, h * w)
+    assert torch.equal(out.bool(), ref)
+
+
+@pytest.mark.parametrize("ava", [True, False])
+def test_class_error_kernel(dev, ava):
+    g = torch.Generator().manual_seed(3)
+    B, Q, C, Tmax = 3, 15, (80 if ava else 22), 8
+    logits = torch.randn(B, Q, C, generator=g).to(dev)
+    match = torch.full((B, Tmax), -1, dtype=torch.int32)
+    counts = [3, 0, 5]
+    for b, n in enumerate(counts):
+        match[b, :n] = torch.randperm(Q, generator=g)[:n].int()
+    match = match.to(dev)
+    if ava:
+        tl = (torch.rand(B, Tmax, C, generator=g) < 0.06).float()
+        tl[:, :, 11] = 1.0
+        # make some rows exactly right: labels = top-k of the matched query
+        for b, t in ((0, 0), (2, 1), (2, 3)):
+            k = int(tl[b, t].sum())
+            top = logits[b, int(match[b, t])].topk(k).indices.cpu()
+            tl[b, t] = 0
+            tl[b, t, top] = 1.0
+        tl = tl.to(dev)
+        rows = torch.gather(logits, 1, match.clamp(min=0).long()[:, :, None].expand(-1, -1, C))
+        lab = tl > 0.5
+        lo = torch.where(lab, rows, rows.new_full((), float("inf"))).amin(-1)
+        hi = torch.where(lab, rows.new_full((), float("-inf")), rows).amax(-1)
+        ok = (lo > hi) & (match >= 0)
+    else:
+        tl = torch.randint(0, C - 1, (B, Tmax), generator=g).float()
+        for b, t in ((0, 1), (2, 0), (2, 4)):
+            tl[b, t] = float(logits[b, int(match[b, t])].argmax())
+        tl = tl.to(dev)
+        rows = torch.gather(logits, 1, match.clamp(min=0).long()[:, :, None].expand(-1, -1, C))
+        ok = (rows.argmax(-1) == tl.long()) & (match >= 0)
+    want = 100.0 - 100.0 * float(ok.sum()) / max(int((match >= 0).sum()), 1)
+    out = torch.empty(1, device=dev)
+    lib.call("tuber_class_error", logits, match, tl, B, Q, C, Tmax, 1 if ava else 0, out)
+    assert abs(float(out) - want) < 1e-4 and int(ok.sum()) == 3, (float(out), want)

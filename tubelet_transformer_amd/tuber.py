@@ -15,7 +15,6 @@ Row orders used internally (all row-wise ops are order-agnostic; attention gets 
 import copy
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import lib
