@@ -42,10 +42,8 @@ class WgradQueue:
     def __init__(self, store):
         self.store, self.q = store, []
         self.enabled = not os.environ.get("TUBER_NO_WGRAD_GROUPS")        # A/B switch: one tuber_gemm_tn launch per weight gradient
-        # the grouped launches can run on a second HIP stream next to the data-gradient chain (fork at the launch, join before the
-        # deferred reductions): ~25 fork points per step instead of the 300 per-GEMM ones round 1 measured as a loss
-        self.side = bool(os.environ.get("TUBER_WGRAD_SIDE_STREAM"))
-        self.stream, self.dirty, self.inflight = None, False, []
+        # (measured and rejected: running the grouped launches on a second HIP stream next to the data-gradient chain -- ~35 fork /
+        #  join points per step inside the hipGraph cost +1.9 ms/step, 18.65 -> 20.53: cross-queue edges serialise the replay)
         self.max = lib.query("tuber_gemm_tn_group_max")
         if lib.query("tuber_gemm_tn_args_bytes") != ctypes.sizeof(TnArgs):
             raise RuntimeError("TuberGemmTNArgs layout drift between engine.py and libtuber_hip.so")
@@ -61,27 +59,15 @@ class WgradQueue:
         if len(self.q) >= self.max:
             self.flush()
 
-    def flush(self, join=False):
+    def flush(self):
         q, self.q = self.q, []
-        if q:
-            arr = (TnArgs * len(q))(*[e[0] for e in q])
-            if self.side:
-                if self.stream is None:
-                    self.stream = torch.cuda.Stream(device=self.store.device)
-                self.stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.stream):
-                    lib.call("tuber_gemm_tn_group", arr, len(q))
-                self.inflight.extend(e[1] for e in q)      # operands stay allocated until the join (no reuse under the side stream)
-                self.dirty = True
-            else:
-                lib.call("tuber_gemm_tn_group", arr, len(q))
-            for _, _, defers in q:
-                for d in defers:
-                    self.store.defer.add(*d)
-        if join and self.dirty:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.dirty = False
-            self.inflight.clear()
+        if not q:
+            return
+        arr = (TnArgs * len(q))(*[e[0] for e in q])
+        lib.call("tuber_gemm_tn_group", arr, len(q))
+        for _, _, defers in q:
+            for d in defers:
+                self.store.defer.add(*d)
 
 
 class DeferredReduce:
@@ -232,7 +218,7 @@ class ParamStore:
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.defer = DeferredReduce(self.device)
         self.wq = WgradQueue(self)
-        self.defer.pre_flush = lambda: self.wq.flush(join=True)
+        self.defer.pre_flush = self.wq.flush
 
     @staticmethod
     def _is_gemm_weight(name, p):

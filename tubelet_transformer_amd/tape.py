@@ -101,7 +101,7 @@ class Tape:
                 self.put(t, g)
         for fn in reversed(self.ops):
             fn()
-        self.store.wq.flush(join=True)
+        self.store.wq.flush()
         self.clear()
 
     def clear(self):
@@ -541,7 +541,7 @@ def backbone(tp, runner, clips, bn_train):
         def bwd():
             g = tp.take(f2)
             if g is not None:
-                tp.store.wq.flush(join=getattr(tp.store, "reducer", None) is not None)   # transformer / head weight gradients: launched (and, under a reducer, complete) before the body backward
+                tp.store.wq.flush()          # transformer / head weight gradients: launched before the reducer is told they are final
                 runner.backward(saved, g.contiguous())
         tp.rec(bwd)
     return f2
