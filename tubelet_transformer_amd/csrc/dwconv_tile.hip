@@ -79,14 +79,14 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     }
     const long plane_elems = (long)g.H * g.W * g.C;
     const bf16* in_n = a.in + (long)n * g.T * plane_elems;
-    uint2 regs[NLD];
-    auto fetch = [&](int t) {                      // input plane t -> registers (zeros outside the volume)
+    uint2 regs[NLD], regs_a[NLD], regs_b[NLD];     // regs: the steady-state prefetch set; _a / _b: the two extra planes of the prologue
+    auto fetch = [&](int t, uint2 (&regs)[NLD]) {  // input plane t -> registers (zeros outside the volume)
         const bool tok = t >= 0 && t < g.T;
         const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) regs[i] = (tok && s_ok[i]) ? *(const uint2*)(p + s_off[i]) : make_uint2(0, 0);
     };
-    auto park = [&](int t) {                       // registers -> activated fp32 in ring slot t mod 3
+    auto park = [&](int t, const uint2 (&regs)[NLD]) {   // registers -> activated fp32 in ring slot t mod 3
         const bool tok = t >= 0 && t < g.T;
         float* dst = smem + ((t + 3) % 3) * PLANE;
 #pragma unroll
@@ -106,6 +106,12 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
             *(float4*)(dst + s_lds[i]) = o;
         }
     };
+
+    // ---- all three planes of the prologue go out together (one memory latency instead of three dependent fetch -> park rounds:
+    // the short-T stages run one output plane per workgroup, so the prologue IS the kernel) ----
+    fetch(t0 - 1, regs_a);
+    fetch(t0, regs_b);
+    fetch(t0 + 1, regs);
 
     // ---- filter taps of this thread's 4 channels (bwd data: flipped) ----
     // filter taps [27][64] stay in LDS behind the ring (bwd data: flipped); every lane group reads its quad as a broadcast --
@@ -130,14 +136,13 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: planes t0-1 and t0 parked, t0+1 in flight ----
-    fetch(t0 - 1); park(t0 - 1);
-    fetch(t0); park(t0);
-    fetch(t0 + 1);
+    park(t0 - 1, regs_a);
+    park(t0, regs_b);
     const int ho = h0 + row, wo0 = w0 + cg * 4;
     const bool row_ok = ho < g.H;
     for (int t = t0; t < t1; ++t) {
-        park(t + 1);
-        if (t + 1 < t1) fetch(t + 2);
+        park(t + 1, regs);
+        if (t + 1 < t1) fetch(t + 2, regs);
         // side inputs of this output plane (global, 8 B per column): bwd data: x;  wgrad: gout
         uint2 side[4];
         const long obase = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
