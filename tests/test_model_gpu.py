@@ -484,3 +484,39 @@ def test_two_rank_bench_captures_the_graph_step(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["launch_mode"] == "hipgraph" and j["config"]["global_batch"] == 4
     assert j["value"] > 0 and math.isfinite(j["final_loss"])
+
+
+@pytest.mark.gpu
+def test_single_frame_false_matches_oracle(dev):
+    """SINGLE_FRAME: False (backbone_builder.py:70,81-86; no published config uses it): no temporal pooling, the DETR encoder attends
+    over all T' x h x w tokens with the 3-D positional encoding and the padding mask repeated over T'.  Eval forward against the
+    oracle with the bf16-rounded-oracle yardstick, ragged batch; and a training step whose gradients reach the stem."""
+    from parity_util import output_errors, run_oracle
+    cfg = load_cfg(os.path.join(ROOT, "configuration", "TubeR_CSN152_AVA21.yaml"))
+    cfg.CONFIG.MODEL.SINGLE_FRAME = False
+    cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+    model, crit, _ = build_model(cfg)
+    synth.load_name_hashed(model)
+    synth.zero_dropout(model)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    crit.to(dev)
+    clips = synth.synthetic_clips(2, 32, 0, 0, seed=5, sizes=[(64, 96), (48, 80)])
+    want, _ = run_oracle(cfg, state, clips, train=False)
+    rnd, _ = run_oracle(cfg, state, clips, train=False, rounded=True)
+    with torch.no_grad():
+        got = model([c.to(dev) for c in clips])
+    errs = output_errors(got, want, rnd)
+    print("SINGLE_FRAME False: hip / rounded oracle vs fp32: %s" % {k: "%.2e / %.2e" % v for k, v in errs.items()})
+    for kind, (eh, eb) in errs.items():
+        assert eh <= (1e-2 if kind == "pred_boxes" else 5e-2) and eh <= 2 * eb + (1e-3 if kind == "pred_boxes" else 4e-3), (kind, eh, eb)
+    model.train()
+    crit.train()
+    store, _ = model.engine()
+    store.zero_grad()
+    full = synth.synthetic_clips(2, 32, 64, 96, seed=6, device=dev)
+    targets = synth.synthetic_targets(2, "ava", 80, seed=6, device=dev, hw=(64, 96))
+    ld = crit(model(full), targets)
+    sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict).backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(store.gflat).all()) and float(model.backbone.body.conv1.weight.grad.abs().max()) > 0

@@ -259,9 +259,10 @@ class DETR(nn.Module):
         B, Tp, h, w, C = runner.last_shape
         hw = h * w
         strat = self.backbone.temporal_ds_strategy
-        if not self.backbone.ds:
-            raise NotImplementedError("SINGLE_FRAME: False is not used by any published config")
-        if strat == "avg":
+        Tm = 1                                   # temporal slots of the encoder memory
+        if not self.backbone.ds:                 # SINGLE_FRAME: False (backbone_builder.py:70,81-86): no temporal pooling, the encoder
+            xs, Tm = feat, Tp                    # sees all T' x h x w tokens (rows (b, t, hw) are already the flatten(2) order)
+        elif strat == "avg":
             if Tp != self.backbone.pool_len:
                 raise ValueError("TEMPORAL_DS_STRATEGY 'avg' needs T/8 == TEMP_LEN/DS_RATE (got %d vs %d)" % (Tp, self.backbone.pool_len))
             xs = T.gather_sum(tp, feat, (B, 1, hw, Tp, Tp * hw, 0, 1, hw, 1.0 / Tp), (B, Tp, hw, 1, hw, 0, 1, 0, 1.0 / Tp))
@@ -276,14 +277,17 @@ class DETR(nn.Module):
         kpm = torch.empty(B, hw, dtype=torch.uint8, device=dev)                       # [B,h*w] key-padding mask (backbone_builder.py:85)
         mk = mask if mask.dtype in (torch.bool, torch.uint8) else mask != 0
         lib.call("tuber_mask_resize", mk.contiguous(), kpm, B, mask.shape[-2], mask.shape[-1], h, w)
-        pos = torch.empty(B * hw, E, dtype=BF, device=dev)
-        lib.call("tuber_posenc", kpm, pos, B, 1, h, w, E)
+        if Tm > 1:                                                                    # mask.unsqueeze(1).repeat(1, T', 1, 1) (:86)
+            kpm = kpm[:, None, :].expand(B, Tm, hw).contiguous().view(B, Tm * hw)
+        Lm = Tm * hw
+        pos = torch.empty(B * Lm, E, dtype=BF, device=dev)
+        lib.call("tuber_posenc", kpm, pos, B, Tm, h, w, E)
 
         # ---- DETR encoder / decoder (transformer.py:49-64) ----
-        src = T.linear(tp, xs, "input_proj.weight", "input_proj.bias")             # rows (b, hw)
+        src = T.linear(tp, xs, "input_proj.weight", "input_proj.bias")             # rows (b, [t,] hw)
         for i in range(self.transformer.encoder.num_layers):
             L = "transformer.encoder.layers.%d" % i
-            a = self._mha_self(tp, src, T.add_const(tp, src, pos), L + ".self_attn", B, hw, kpm, pattn)
+            a = self._mha_self(tp, src, T.add_const(tp, src, pos), L + ".self_attn", B, Lm, kpm, pattn)
             src = T.layer_norm(tp, a, src, L + ".norm1", drop=pdrop)
             src = T.layer_norm(tp, self._ffn(tp, src, L, pdrop), src, L + ".norm2", drop=pdrop)
         memory = src
@@ -301,7 +305,7 @@ class DETR(nn.Module):
             q = T.linear(tp, T.add(tp, tgt, qpos), P + ".in_proj_weight", P + ".in_proj_bias", rows=(0, E))
             k = T.linear(tp, mem_pos, P + ".in_proj_weight", P + ".in_proj_bias", rows=(E, 2 * E))
             v = T.linear(tp, memory, P + ".in_proj_weight", P + ".in_proj_bias", rows=(2 * E, 3 * E))
-            a = T.attention(tp, ((0, 0), (1, 0), (2, 0)), (B, H, Q, hw, (1, Q, 0, 1), (1, hw, 0, 1)), kpm, pattn, q, k, v)
+            a = T.attention(tp, ((0, 0), (1, 0), (2, 0)), (B, H, Q, Lm, (1, Q, 0, 1), (1, Lm, 0, 1)), kpm, pattn, q, k, v)
             a = T.linear(tp, a, P + ".out_proj.weight", P + ".out_proj.bias")
             tgt = T.layer_norm(tp, a, tgt, L + ".norm2", drop=pdrop)
             tgt = T.layer_norm(tp, self._ffn(tp, tgt, L, pdrop), tgt, L + ".norm3", drop=pdrop)
