@@ -838,3 +838,36 @@ def test_class_error_kernel(dev, ava):
     out = torch.empty(1, device=dev)
     lib.call("tuber_class_error", logits, match, tl, B, Q, C, Tmax, 1 if ava else 0, out)
     assert abs(float(out) - want) < 1e-4 and int(ok.sum()) == 3, (float(out), want)
+
+
+@pytest.mark.parametrize("M,C,R", [(5632, 1024, 88), (5632, 256, 88), (2816, 2048, 44), (1000, 128, 7), (2816, 512, 128)])
+def test_bn_bwd_one_launch_matches_finalize_plus_apply(dev, M, C, R):
+    """tuber_bn_bwd_fa (finalize + apply in one launch, short partial lists) against tuber_bn_bwd_finalize + tuber_bn_bwd_apply:
+    same fp64 arithmetic in another fixed summation order -> dx equal up to one bf16 ulp on rare elements, dgamma / dbeta to 1e-6 rel"""
+    dz = rnd(M, C, dev=dev, seed=1).to(BF)
+    x = rnd(M, C, dev=dev, seed=2).to(BF)
+    gamma = 1 + 0.1 * rnd(C, dev=dev, seed=3)
+    mean, invstd = 0.1 * rnd(C, dev=dev, seed=4), 1 + 0.2 * torch.rand(C, device=dev)
+    # partial rows: R row blocks of the true sums
+    dch, xch = dz.float().chunk(R, 0), x.float().chunk(R, 0)
+    b0 = torch.stack([c.sum(0) for c in dch]).contiguous()
+    b1 = torch.stack([(c * d).sum(0) for c, d in zip(dch, xch)]).contiguous()
+    R = b0.shape[0]
+    cA, cB, cC = (torch.zeros(C, device=dev) for _ in range(3))
+    dg0, db0 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
+    lib.call("tuber_bn_bwd_finalize", b0, b1, R, C, float(M), gamma, mean, invstd, cA, cB, cC, dg0, db0, 1)
+    dx0 = torch.empty(M, C, device=dev, dtype=BF)
+    lib.call("tuber_bn_bwd_apply", dz, x, cA, cB, cC, dx0, M, C)
+    dg1, db1 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
+    dx1 = torch.full((M, C), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, dg1, db1, dz, x, dx1, M)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx1.float()).all())
+    diff = (dx0.float() - dx1.float()).abs()
+    assert float((diff > 0).float().mean()) < 1e-3 and float(diff.max()) <= 2 ** -7 * float(dx0.float().abs().max())
+    close("fa dgamma", dg1, dg0, rel=1e-5)
+    close("fa dbeta", db1, db0, rel=1e-5)
+    # frozen BatchNorm: no dgamma / dbeta
+    dx2 = torch.empty(M, C, device=dev, dtype=BF)
+    lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, None, None, dz, x, dx2, M)
+    assert torch.equal(dx2, dx1)

@@ -22,9 +22,7 @@ from . import lib
 from .engine import TnArgs, WgradQueue
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
-# measured on MI355X: one fused finalize+apply launch per layer3/4 BatchNorm (R <= 128) is 0.5 ms/step SLOWER than the two launches
-# (1024-thread workgroups on 64-byte row segments, coefficients re-derived by every row chunk) -- off; A/B with the env variable
-BN_FUSED_MAX_ROWS = int(os.environ.get("TUBER_BN_FUSED_MAX_ROWS", "0"))
+BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
@@ -175,6 +173,7 @@ class CSNRunner:
                     d["bnd"] = mk_bn(p + "down_sample.1", blk.down_sample[1])
                 self.blocks.append(d)
         self._ws = {}
+        self._fa_max = lib.query("tuber_bn_bwd_fa_max_rows")
         # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
         body = [store.offsets[n] + (q.numel() + 63) // 64 * 64 for n, q in zip(store.names, store.params) if n.startswith(prefix)]
         self.body_end = max(body)
@@ -331,6 +330,12 @@ class CSNRunner:
         (Forming dx inside the consuming GEMMs instead -- tuber_gemm_nt amode 2 / tuber_gemm_tn G2 -- removes this kernel and
         7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
         not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
+        if apply and BN_BWD_ONE_LAUNCH and R <= self._fa_max and bn.C % 128 == 0:
+            # short partial lists (layer3 / layer4): every workgroup of the apply derives its strip's coefficients itself -- one launch
+            dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
+            lib.call("tuber_bn_bwd_fa", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd,
+                     bn.dgamma if train else None, bn.dbeta if train else None, dz, x, dx, M)
+            return dx
         st0, st1, R = self._stat_rows(st0, st1, R, bn.C)
         lib.call("tuber_bn_bwd_finalize", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.cA, bn.cB, bn.cC,
                  bn.dgamma if train else None, bn.dbeta if train else None, 1)

@@ -12,6 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_bn_bwd_fa": "tuber_bn_bwd_finalize + tuber_bn_bwd_apply in ONE launch for short partial lists (layer3 / layer4 of the CSN body): every workgroup "
+                       "derives the coefficients of its 128-channel strip from the R partial rows (fp64) and applies dx = cA*dz + cB*x + cC to its rows; "
+                       "dgamma / dbeta accumulated by the first row chunk (NULL: frozen BatchNorm). autograd of nn.BatchNorm3d (ir_CSN_152.py:46,56,64,154).",
+    "tuber_bn_bwd_fa_max_rows": "largest R tuber_bn_bwd_fa accepts.",
     "tuber_class_error": "class_error of the matched queries of one decoder layer, on the device: 100 - exact-set accuracy (AVA, utils/misc.py:497-518 "
                          "via models/criterion.py:76-78) or top-1 accuracy (JHMDB, utils/misc.py:521-539 via criterion.py:258-260).",
     "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "

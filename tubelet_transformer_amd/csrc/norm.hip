@@ -273,6 +273,86 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 
+// BatchNorm backward for SHORT partial-statistics lists (layer3 / layer4: R <= 128 rows): finalize + apply in ONE launch.
+// A dependent launch costs ~5 us + a ~1.7 us gap on this GPU whatever it computes, and the finalize kernel is exactly that; here
+// every workgroup derives the coefficients of ITS 128-channel strip itself -- R x 128 x 2 floats from L2, one dependent round
+// trip, 8 row groups of float4 loads all in flight, fp64 sums -- and goes straight on to dx = cA*dz + cB*x + cC over its
+// 128 rows x 128 channels (256-byte row segments).  Row chunk 0 of each strip also writes dgamma / dbeta (+=).  The summation order over
+// the partial rows is fixed (deterministic) but differs from bn_bwd_finalize's, so results agree with the two-launch path to fp64
+// rounding, not bit for bit.  (Round 1's one-launch variant used 32-channel strips = 64-byte segments and 1024-thread workgroups and
+// lost 0.5 ms/step.)
+#define FA_CS 128          // channels per strip
+#define FA_ROWS 128        // rows per workgroup
+__global__ __launch_bounds__(256) void bn_bwd_fa_kernel(
+    const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta,
+    const bf16* __restrict__ dz, const bf16* __restrict__ x, bf16* __restrict__ dx, long M) {
+    __shared__ double red[2][8][FA_CS];
+    __shared__ float coef[3][FA_CS];
+    const int c0 = blockIdx.y * FA_CS;
+    const int tid = threadIdx.x;
+    // ---- derive: thread = (row group rg of 8, channel quad q of 32) ----
+    {
+        const int q = tid & 31, rg = tid >> 5;
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        const float* p0 = st0 + c0 + q * 4;
+        const float* p1 = st1 + c0 + q * 4;
+        int r = rg;
+        for (; r + 24 < R; r += 32) {
+            float4 u[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { u[k] = *(const float4*)(p0 + (long)(r + 8 * k) * C); v[k] = *(const float4*)(p1 + (long)(r + 8 * k) * C); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[0] += u[k].x; a[1] += u[k].y; a[2] += u[k].z; a[3] += u[k].w;
+                b[0] += v[k].x; b[1] += v[k].y; b[2] += v[k].z; b[3] += v[k].w;
+            }
+        }
+        for (; r < R; r += 8) {
+            const float4 u = *(const float4*)(p0 + (long)r * C), v = *(const float4*)(p1 + (long)r * C);
+            a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+            b[0] += v.x; b[1] += v.y; b[2] += v.z; b[3] += v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][rg][q * 4 + e] = a[e]; red[1][rg][q * 4 + e] = b[e]; }
+    }
+    __syncthreads();
+    if (tid < FA_CS) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += red[0][k][tid]; b += red[1][k][tid]; }
+        const int c = c0 + tid;
+        const double mu = mean[c], rr = invstd[c], g = gamma[c];
+        const double sum_dz = a, sum_dz_xhat = (b - mu * a) * rr;
+        const double m1 = sum_dz / count, m2 = sum_dz_xhat / count;
+        coef[0][tid] = (float)(g * rr);
+        coef[1][tid] = (float)(-g * rr * rr * m2);
+        coef[2][tid] = (float)(g * rr * rr * m2 * mu - g * rr * m1);
+        if (blockIdx.x == 0 && dgamma) {
+            dgamma[c] += (float)sum_dz_xhat;
+            dbeta[c] += (float)sum_dz;
+        }
+    }
+    __syncthreads();
+    // ---- apply: thread = (row slot of 16, 8-channel group of 16) ----
+    const int cg = tid & 15, rs = tid >> 4;
+    float ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = coef[0][cg * 8 + e]; cb[e] = coef[1][cg * 8 + e]; cc[e] = coef[2][cg * 8 + e]; }
+    const long r0 = (long)blockIdx.x * FA_ROWS;
+    const long r1 = min(M, r0 + FA_ROWS);
+    for (long row = r0 + rs; row < r1; row += 16) {
+        const long off = row * C + c0 + cg * 8;
+        const bf16x8 d = as_bf16x8(*(const uint4*)(dz + off));
+        const bf16x8 xx = as_bf16x8(*(const uint4*)(x + off));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(ca[e], bf2f(d[e]), fmaf(cb[e], bf2f(xx[e]), cc[e])));
+        *(uint4*)(dx + off) = as_uint4(o);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm(x + res) over the last dim E (256 or 2048), eps 1e-5, one wave per row.
 // reference: nn.LayerNorm in models/transformer/transformer.py:163-167,229-247 (post-norm).
@@ -639,6 +719,19 @@ int tuber_relu_bn_bwd_reduce(const void* g, const void* x, const float* sc, cons
     if (!chan_ok(C)) return TUBER_EINVAL;
     hipLaunchKernelGGL(relu_bn_bwd_reduce_kernel, dim3(tuber_rowblock_count(M, C)), dim3(256), 0, stream, (const bf16*)g,
                        (const bf16*)x, sc, sh, (bf16*)dz, st0, st1, M, C, rows_per_block(M, C));
+    TUBER_RETURN_LAUNCH();
+}
+
+// BatchNorm backward, finalize + apply in one launch, for short partial lists (R <= tuber_bn_bwd_fa_max_rows(), C % 128 == 0):
+// dx = cA*dz + cB*x + cC with the coefficients derived per workgroup from the partial rows; dgamma / dbeta are ACCUMULATED (+=) unless
+// NULL (frozen BatchNorm).  Same arithmetic as tuber_bn_bwd_finalize + tuber_bn_bwd_apply (fp64 sums, another fixed order).
+int tuber_bn_bwd_fa_max_rows(void) { return 128; }
+int tuber_bn_bwd_fa(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* mean,
+                    const float* invstd, float* dgamma, float* dbeta, const void* dz, const void* x, void* dx, long M,
+                    hipStream_t stream) {
+    if (R <= 0 || R > 128 || C <= 0 || (C % FA_CS) || M <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_fa_kernel, dim3(ceil_div(M, FA_ROWS), C / FA_CS), dim3(256), 0, stream, st0, st1, R, C, count, gamma, mean,
+                       invstd, dgamma, dbeta, (const bf16*)dz, (const bf16*)x, (bf16*)dx, M);
     TUBER_RETURN_LAUNCH();
 }
 
