@@ -836,7 +836,22 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblo
     constexpr int GS = 4;
     uint4 rg[GS][2], ra[GS][2];
     bool rok[GS][2];
+    // full 64-row steps of dense operands (every step of the backbone shapes: M and the slab length are multiples of 64) skip the
+    // per-row predicates and form their addresses from per-thread base pointers + a step offset that is uniform (scalar unit)
+    const bool dense = !p.gather && g_col_ok && a_col_ok;
+    const bf16* gb0 = p.G + (long)(m_begin + r) * p.ldg + n0 + c * 8;
+    const bf16* ab0 = p.A + (long)(m_begin + r) * p.lda + k0 + c * 8;
+    const long g32 = 32 * p.ldg, a32 = 32 * p.lda;
     auto load_step = [&](int ms, uint4 (&xg)[2], uint4 (&xa)[2], bool (&ok)[2]) {
+        if (dense && ms + 64 <= m_end) {
+            const long so = (long)(ms - m_begin);
+            const bf16* gq = gb0 + so * p.ldg;
+            const bf16* aq = ab0 + so * p.lda;
+            xg[0] = *(const uint4*)gq; xg[1] = *(const uint4*)(gq + g32);
+            xa[0] = *(const uint4*)aq; xa[1] = *(const uint4*)(aq + a32);
+            ok[0] = ok[1] = true;
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = ms + r + 32 * h;
@@ -945,7 +960,7 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblo
 }
 
 template <int AMODE>
-__global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_body<AMODE>(p, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256, 3) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_body<AMODE>(p, blockIdx.x, gridDim.x); }
 
 // Several weight-gradient GEMMs in ONE launch: the conv weight gradients of a bottleneck (conv4, conv1, down_sample) feed nothing
 // until the optimizer, so they are queued and launched together -- one launch gap instead of 2-3 per bottleneck, and for the
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_body
 // The argument blocks travel BY VALUE in the kernel argument segment (a captured hipGraph bakes them in like any other launch).
 #define TN_GROUP_MAX 8
 struct GemmTNGroup { GemmTN p[TN_GROUP_MAX]; int begin[TN_GROUP_MAX + 1]; int n; };
-__global__ __launch_bounds__(256) void gemm_tn2_group_kernel(GemmTNGroup g) {
+__global__ __launch_bounds__(256, 3) void gemm_tn2_group_kernel(GemmTNGroup g) {
     int e = 0;
 #pragma unroll
     for (int i = 1; i < TN_GROUP_MAX; ++i)
