@@ -456,11 +456,7 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__
 // cross attentions (Lq = 15 against 352 / 1408 keys) are faster there too even with one active wave per 64-query block
 #define MFMA_MIN_LQ 32
 #define MFMA_MIN_LK 128
-static bool attn_force_scalar() {
-    static int v = -1;
-    if (v < 0) v = getenv("TUBER_ATTN_SCALAR") ? 1 : 0;      // A/B switch for profiling
-    return v == 1;
-}
+static bool attn_force_scalar() { return false; }
 
 extern "C" {
 

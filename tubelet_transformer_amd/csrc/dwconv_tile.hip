@@ -285,7 +285,6 @@ TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
         // its workgroups ends with a 108-accumulator reduction and a 6.9 KB partial)
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && wgrad)) { best_cost = cost; tc = c; }
     }
-    { const char* e = getenv("TUBER_DW_TC"); if (e && atoi(e) > 0) tc = atoi(e) > T ? T : atoi(e); }     // experiments only
     g.tc = (int)tc;
     g.tchunks = (T + g.tc - 1) / g.tc;
     return g;

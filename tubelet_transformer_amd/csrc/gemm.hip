@@ -1021,10 +1021,7 @@ static int tn_slabs_wanted(int M, int N, int K) {
     long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);
     if (cap < 1) cap = 1;
     if (S > cap) S = cap;
-    static int mult = -1;
-    if (mult < 0) { const char* e = getenv("TUBER_TN_SLAB_MULT"); mult = e ? atoi(e) : 1; }     // experiments only
-    S *= mult;
-    const long maxS = ceil_div(M, mult > 1 ? 128 : 256);
+    const long maxS = ceil_div(M, 256);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     return (int)S;
@@ -1038,7 +1035,6 @@ int tuber_gemm_tn_slabs(int M, int N, int K) { return ceil_div(M, tn_rows_per_sl
 //   2: yes, S = tuber_gemm_tn_slabs > 1: bias_grad must point to S*N floats and receives one partial row per slab (reduce them with
 //      tuber_reduce_rows(bias_grad, dbias, S, N, 1) or a tuber_multi_reduce entry).
 int tuber_gemm_tn_fuses_bias(int M, int N, int K, long ldg, long lda) {
-    if (getenv("TUBER_TN_REGISTER_TRANSPOSE")) return 0;
     if (!(tn_tile(N, K) == 64 && !((N | K | ldg | lda) & 7))) return 0;
     return tuber_gemm_tn_slabs(M, N, K) == 1 ? 1 : 2;
 }
@@ -1068,8 +1064,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     dim3 grid(tiles * p.S), block(256);
     const size_t lds = 2 * 2 * T * 128;
 #define LTN(AM, TT, GM) hipLaunchKernelGGL((gemm_tn_kernel<AM, TT, GM>), grid, block, lds, stream, p)
-    static int use_tr = -1;
-    if (use_tr < 0) use_tr = getenv("TUBER_TN_REGISTER_TRANSPOSE") ? 0 : 1;      // A/B switch for profiling
+    const int use_tr = 1;
     p.bias_grad = nullptr;
     if (bias_grad && !tuber_gemm_tn_fuses_bias(M, N, K, ldg, lda)) return TUBER_EINVAL;
     if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7)) {     // LDS transpose-read kernel

@@ -648,9 +648,7 @@ extern "C" {
 
 // [R][C] partial-statistics rows -> [R2][C] (R2 = tuber_stat_rows_reduced(R) < R): cheap first stage before the finalize kernels
 int tuber_stat_rows_reduced(int R) {
-    static int thr = -1;
-    if (thr < 0) { const char* e = getenv("TUBER_STAT_ROWS_DIRECT"); thr = e ? atoi(e) : 512; }
-    return R > thr ? 64 : R;
+    return R > 512 ? 64 : R;
 }
 
 int tuber_stat_rows_reduce(const float* st0, const float* st1, int R, int C, float* out0, float* out1, hipStream_t stream) {
