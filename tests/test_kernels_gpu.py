@@ -871,3 +871,40 @@ def test_bn_bwd_one_launch_matches_finalize_plus_apply(dev, M, C, R):
     dx2 = torch.empty(M, C, device=dev, dtype=BF)
     lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, None, None, dz, x, dx2, M)
     assert torch.equal(dx2, dx1)
+
+
+@pytest.mark.parametrize("M,N,K,add_cols", [(704, 768, 256, 512), (30, 768, 256, 512), (30, 256, 256, 256), (704, 512, 256, 256), (2816, 768, 256, 512)])
+def test_gemm_nt_addproj_and_its_weight_gradient(dev, M, N, K, add_cols):
+    """packed in-projection with the positional embedding folded in: columns [0, add_cols) see bf16(x + pos), the rest x -- bit-identical to
+    add kernel + two GEMM launches; and the dW GEMM with the A + A2 operand formed on load (tuber_gemm_tn_group entry with A2)"""
+    from tubelet_transformer_amd.engine import TnArgs
+    x = rnd(M, K, dev=dev, seed=1).to(BF)
+    pos = rnd(M, K, dev=dev, seed=2).to(BF)
+    W = rnd(N, K, dev=dev, seed=3, scale=K ** -0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=4)
+    y = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt_addproj", x, K, pos, K, add_cols, W, K, y, N, M, N, K, bias)
+    xs = torch.empty_like(x)
+    lib.call("tuber_axpby", x, pos, xs, x.numel(), 1.0, 1.0)
+    y0 = torch.empty(M, N, device=dev, dtype=BF)
+    for (c0, c1, a) in ((0, add_cols, xs), (add_cols, N, x)):
+        if c1 > c0:
+            out = torch.empty(M, c1 - c0, device=dev, dtype=BF)
+            lib.call("tuber_gemm_nt", a, K, W[c0:c1].contiguous(), K, out, c1 - c0, M, c1 - c0, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     0, bias[c0:c1].contiguous(), None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+            y0[:, c0:c1] = out
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    # weight gradient of the first row block: G = g[:, :add_cols] (ld N), A = x + pos formed on load
+    g = rnd(M, N, dev=dev, seed=5).to(BF)
+    S = lib.query("tuber_gemm_tn_slabs", M, add_cols, K)
+    dW = torch.zeros(add_cols, K, device=dev)
+    db = torch.zeros(max(S, 1) * add_cols, device=dev)
+    part = torch.zeros(max(S, 1) * add_cols * K, device=dev)
+    arr = (TnArgs * 1)(TnArgs(g.data_ptr(), N, x.data_ptr(), K, part.data_ptr() if S > 1 else None, dW.data_ptr(), 2 if S > 1 else 1, M, add_cols, K,
+                              0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None, db.data_ptr(), pos.data_ptr(), K))
+    lib.call("tuber_gemm_tn_group", arr, 1)
+    got = part.view(S, add_cols, K).sum(0) if S > 1 else dW
+    gb = db.view(max(S, 1), add_cols).sum(0)
+    close("addproj dW", got, g[:, :add_cols].float().t() @ xs.float(), rel=4e-3)
+    close("addproj dbias", gb, g[:, :add_cols].float().sum(0), abs_=2e-3 * float(g.float().abs().sum(0).max()))

@@ -24,7 +24,10 @@
 
 #include "common.h"
 
-enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2 };     // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply)
+enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
+// A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
+// A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
+//           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3 };
 // EPI_JOIN: the data-gradient GEMM of one bottleneck's conv1 fused with the join backward of the bottleneck below it:
 //   dz = (acc + R) * [Ym > 0]   (R = identity-shortcut gradient, Ym = the lower block's output y = relu(bn4(c4) + x))
@@ -36,7 +39,8 @@ struct GemmNT {
     void* C; long ldc;
     int M, N, K;
     const float* a_scale; const float* a_shift;   // A_BN_RELU (scale, shift) / A_BN_BWD (cA, cB)
-    const bf16* A2; long lda2; const float* a_coef2;   // A_BN_BWD: second operand (the BN input x) and cC
+    const bf16* A2; long lda2; const float* a_coef2;   // A_BN_BWD: second operand (the BN input x) and cC;  A_ADD: the addend
+    int add_ncols;                                     // A_ADD: output columns [0, add_ncols) use A + A2 (multiple of the tile width)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss; // row gather (strided 1x1x1 conv)
     const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     // ---- staging assignment: chunk c = tid + 256*i -> (row = c>>3, q = c&7) ----
     const int q = tid & 7;
     const bf16* a_ptr[CA];
-    const bf16* a2_ptr[AMODE == A_BN_BWD ? CA : 1];
+    constexpr bool TWO = AMODE == A_BN_BWD || AMODE == A_ADD;      // second A operand
+    const bf16* a2_ptr[TWO ? CA : 1];
     bool a_ok[CA];
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             src = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)h * p.ss) * p.Wi + (long)w * p.ss;
         }
         a_ptr[i] = p.A + src * p.lda + q * 8;
-        if (AMODE == A_BN_BWD) a2_ptr[i] = p.A2 + (long)m * p.lda2 + q * 8;
+        if (TWO) a2_ptr[i] = p.A2 + (long)m * p.lda2 + q * 8;
     }
     const bf16* b_ptr[CB];
     bool b_ok[CB];
@@ -109,11 +114,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     // group instead of one per tile -- these GEMMs have K <= 2048, often only 1-4 tiles), then each tile goes
     // registers -> (BN prologue) -> LDS -> MFMA.
     uint4 ra[G][CA], rb[G][CB];
-    uint4 ra2[AMODE == A_BN_BWD ? G : 1][CA];
+    uint4 ra2[TWO ? G : 1][CA];
+    const bool add_on = AMODE == A_ADD && n0 < p.add_ncols;         // uniform per workgroup
 #pragma unroll
     for (int j = 0; j < G; ++j) {                 // fully defined on every path, so the arrays stay in registers
 #pragma unroll
-        for (int i = 0; i < CA; ++i) { ra[j][i] = make_uint4(0, 0, 0, 0); if (AMODE == A_BN_BWD) ra2[j][i] = make_uint4(0, 0, 0, 0); }
+        for (int i = 0; i < CA; ++i) { ra[j][i] = make_uint4(0, 0, 0, 0); if (TWO) ra2[j][i] = make_uint4(0, 0, 0, 0); }
 #pragma unroll
         for (int i = 0; i < CB; ++i) rb[j][i] = make_uint4(0, 0, 0, 0);
     }
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         const int k0 = (kl * KS + kg) * 64;
 #pragma unroll
         for (int i = 0; i < CA; ++i) xa[i] = *(const uint4*)(a_ptr[i] + k0);
-        if (AMODE == A_BN_BWD) {
+        if (AMODE == A_BN_BWD || (AMODE == A_ADD && add_on)) {
 #pragma unroll
             for (int i = 0; i < CA; ++i) xa2[i] = *(const uint4*)(a2_ptr[i] + k0);
         }
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             const float4 c0 = c4[0], c1 = c4[1];
             s2[0] = c0.x; s2[1] = c0.y; s2[2] = c0.z; s2[3] = c0.w; s2[4] = c1.x; s2[5] = c1.y; s2[6] = c1.z; s2[7] = c1.w;
         }
-        if (AMODE != A_PLAIN) {
+        if (AMODE == A_BN_RELU || AMODE == A_BN_BWD) {
             const float4* s4 = (const float4*)(lsc + kt * 64 + q * 8);
             const float4* h4 = (const float4*)(lsh + kt * 64 + q * 8);
             const float4 s0 = s4[0], s1 = s4[1], h0 = h4[0], h1 = h4[1];
@@ -163,6 +169,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                 bf16x8 y;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaf(bf2f(x[e]), sc[e], fmaf(bf2f(x2[e]), sh[e], s2[e])));
+                v = as_uint4(y);
+            }
+            if (AMODE == A_ADD && add_on) {
+                const bf16x8 x = as_bf16x8(v), x2 = as_bf16x8(xa2[i]);
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = f2bf(bf2f(x[e]) + bf2f(x2[e]));       // = the bf16 sum the stand-alone add kernel stored
                 v = as_uint4(y);
             }
             *(uint4*)(sa + row * 128 + ((q ^ swz_act(row)) << 4)) = v;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
 #pragma unroll
     for (int j = 0; j < G; ++j)
-        if (j < nk) load_tile(j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
+        if (j < nk) load_tile(j, ra[j], rb[j], ra2[TWO ? j : 0]);
     constexpr bool SIDE = EPI == EPI_BWD || EPI == EPI_JOIN;
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
     uint4 sidey[EPI == EPI_JOIN ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
     }
-    if (AMODE != A_PLAIN) {
+    if (AMODE == A_BN_RELU || AMODE == A_BN_BWD) {
         for (int i = threadIdx.x; i < p.K; i += 256 * KS) {
             lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i];
             if (AMODE == A_BN_BWD) lsc2[i] = p.a_coef2[i];
@@ -245,8 +258,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         for (int j = 0; j < G; ++j) {
             if (g0 + j < nk_max) {
                 const bool have = g0 + j < nk;           // (odd tile counts: the second group idles through its last barrier)
-                if (have) store_tile(g0 + j, buf, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
-                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[AMODE == A_BN_BWD ? j : 0]);
+                if (have) store_tile(g0 + j, buf, ra[j], rb[j], ra2[TWO ? j : 0]);
+                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[TWO ? j : 0]);
                 __syncthreads();
                 if (have) compute(buf);
                 buf ^= 1;
@@ -426,6 +439,9 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
             else if (epi == EPI_JOIN) return TUBER_EINVAL;
             else LNT(A_BN_RELU, EPI_BWD);
+        } else if (amode == A_ADD) {
+            if (epi != EPI_PLAIN) return TUBER_EINVAL;
+            LNT(A_ADD, EPI_PLAIN);
         } else {
             return TUBER_EINVAL;                          // A_BN_BWD prologue: measured slower than the separate apply kernel, not built
         }
@@ -485,7 +501,7 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7)) return TUBER_EINVAL;
     if (amode != A_PLAIN && (!a_scale || !a_shift)) return TUBER_EINVAL;
     if (amode == A_BN_BWD && (!A2 || !a_coef2 || (lda2 & 7) || gather || epi == EPI_STATS)) return TUBER_EINVAL;
-    if (amode < 0 || amode > 2) return TUBER_EINVAL;
+    if (amode < 0 || amode > 2) return TUBER_EINVAL;                  // (A_ADD has its own entry point: tuber_gemm_nt_addproj)
     if (epi == EPI_BWD && !Cm) return TUBER_EINVAL;
     if (epi != EPI_PLAIN && out_f32) return TUBER_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && epi != EPI_PLAIN)) return TUBER_EINVAL;
@@ -499,8 +515,24 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
-    p.Ym = nullptr; p.ldym = 0;
+    p.Ym = nullptr; p.ldym = 0; p.add_ncols = 0;
     return nt_dispatch(p, amode, epi, stream);
+}
+
+// Packed attention in-projection with the positional embedding folded in (nn.MultiheadAttention's in_proj on with_pos_embed(x, pos),
+// models/transformer/transformer.py:150-159,215-240):  C[M,N] = f(A)[M,K] . B[N,K]^T + bias,  f(A) = A + A2 for the output columns
+// [0, add_ncols) (the q / k rows of in_proj_weight) and f(A) = A for the rest (the v rows).  add_ncols % 128 == 0.  Replaces one add
+// kernel and two GEMM launches; the bf16 sum A + A2 is exactly what the add kernel would have stored.
+int tuber_gemm_nt_addproj(const void* A, long lda, const void* A2, long lda2, int add_ncols, const void* B, long ldb, void* C, long ldc,
+                          int M, int N, int K, const float* bias, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (lda2 & 7) || (ldb & 7) || !A2 || add_ncols < 0 || (add_ncols & 127)) return TUBER_EINVAL;   // any tile width (64 / 128) divides it
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.A2 = (const bf16*)A2; p.lda2 = lda2; p.add_ncols = add_ncols;
+    return nt_dispatch(p, A_ADD, EPI_PLAIN, stream);
 }
 
 // Conv1 data gradient of one bottleneck FUSED with the join backward of the bottleneck below it (whose output y is this conv's input):
@@ -556,6 +588,7 @@ struct GemmTN {
     float* bias_grad;            // gemm_tn2, single slab: dbias[n] += sum_m G[m][n] from the LDS image (no separate column-sum launch)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss;  // row gather on A (G is dense over output rows)
     int amode;                   // grouped launches: A_PLAIN / A_BN_RELU per problem
+    const bf16* A2; long lda2;   // transpose-read kernel: A := A + A2 (bf16 sum) -- the with_pos_embed operand of a packed in-projection
 };
 
 // transposed staging: the 64 x 128 tile (m x col) is cut in 4x4 blocks; thread -> block
@@ -838,10 +871,17 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblo
     bool rok[GS][2];
     // full 64-row steps of dense operands (every step of the backbone shapes: M and the slab length are multiples of 64) skip the
     // per-row predicates and form their addresses from per-thread base pointers + a step offset that is uniform (scalar unit)
-    const bool dense = !p.gather && g_col_ok && a_col_ok;
+    const bool dense = !p.gather && g_col_ok && a_col_ok && !p.A2;
     const bf16* gb0 = p.G + (long)(m_begin + r) * p.ldg + n0 + c * 8;
     const bf16* ab0 = p.A + (long)(m_begin + r) * p.lda + k0 + c * 8;
     const long g32 = 32 * p.ldg, a32 = 32 * p.lda;
+    auto add8 = [](uint4 a, uint4 b) {                     // bf16(a + b) per element: the sum the stand-alone add kernel would store
+        const bf16x8 x = as_bf16x8(a), y = as_bf16x8(b);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+        return as_uint4(o);
+    };
     auto load_step = [&](int ms, uint4 (&xg)[2], uint4 (&xa)[2], bool (&ok)[2]) {
         if (dense && ms + 64 <= m_end) {
             const long so = (long)(ms - m_begin);
@@ -865,6 +905,7 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblo
             }
             xg[h] = (ok[h] && g_col_ok) ? *(const uint4*)(p.G + (long)m * p.ldg + n0 + c * 8) : make_uint4(0, 0, 0, 0);
             xa[h] = (ok[h] && a_col_ok) ? *(const uint4*)(p.A + arow * p.lda + k0 + c * 8) : make_uint4(0, 0, 0, 0);
+            if (p.A2 && ok[h] && a_col_ok) xa[h] = add8(xa[h], *(const uint4*)(p.A2 + (long)m * p.lda2 + k0 + c * 8));
         }
     };
     auto store_step = [&](int buf, const uint4 (&xg)[2], const uint4 (&xa)[2], const bool (&ok)[2]) {
@@ -1059,6 +1100,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     p.G2 = (const bf16*)G2; p.ldg2 = ldg2; p.gA = gA; p.gB = gB; p.gC = gC;
     p.gather = gather; p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
     p.amode = amode;
+    p.A2 = nullptr; p.lda2 = 0;
     const int T = tn_tile(N, K);
     const int tiles = ceil_div(N, T) * ceil_div(K, T);
     dim3 grid(tiles * p.S), block(256);
@@ -1092,6 +1134,7 @@ struct TuberGemmTNArgs {
     int accumulate, M, N, K, amode, gather, To, Ho, Wo, Ti, Hi, Wi, st, ss;
     const float* a_scale; const float* a_shift;
     float* bias_grad;            // optional, as in tuber_gemm_tn: dbias[N] (single slab, accumulated) or [slabs][N] partial rows
+    const void* A2; long lda2;   // optional: A := A + A2 (no gather then)
 };
 int tuber_gemm_tn_args_bytes(void) { return (int)sizeof(TuberGemmTNArgs); }
 int tuber_gemm_tn_group_max(void) { return TN_GROUP_MAX; }
@@ -1121,6 +1164,8 @@ int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
         if (!p.P) return TUBER_EINVAL;
         p.a_scale = x.a_scale; p.a_shift = x.a_shift;
         p.G2 = nullptr; p.ldg2 = 0; p.gA = p.gB = p.gC = nullptr; p.bias_grad = x.bias_grad;
+        if (x.A2 && (x.gather || (x.lda2 & 7) || x.lda2 < x.K || x.amode != A_PLAIN)) return TUBER_EINVAL;
+        p.A2 = (const bf16*)x.A2; p.lda2 = x.lda2;
         p.gather = x.gather; p.To = x.To; p.Ho = x.Ho; p.Wo = x.Wo; p.Ti = x.Ti; p.Hi = x.Hi; p.Wi = x.Wi; p.st = x.st; p.ss = x.ss;
         p.amode = x.amode;
         g.begin[i] = total;

@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
+    "tuber_gemm_nt_addproj": "packed attention in-projection with the positional embedding folded in: C = f(A).B^T + bias with f(A) = A + A2 for the output "
+                             "columns [0, add_ncols) (q / k rows of in_proj_weight: with_pos_embed, models/transformer/transformer.py:150-159,215-240) and "
+                             "f(A) = A for the v rows -- one GEMM instead of an add kernel and two GEMM launches. add_ncols % 128 == 0.",
     "tuber_bn_bwd_fa": "tuber_bn_bwd_finalize + tuber_bn_bwd_apply in ONE launch for short partial lists (layer3 / layer4 of the CSN body): every workgroup "
                        "derives the coefficients of its 128-channel strip from the R partial rows (fp64) and applies dx = cA*dz + cB*x + cC to its rows; "
                        "dgamma / dbeta accumulated by the first row chunk (NULL: frozen BatchNorm). autograd of nn.BatchNorm3d (ir_CSN_152.py:46,56,64,154).",
@@ -27,7 +30,7 @@ DOC = {
     "tuber_gemm_tn_group": "n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly one tuber_gemm_tn: dW = G^T f(A) of a 1x1x1 conv, "
                            "autograd of models/backbones/ir_CSN_152.py:41,58,155-161) in ONE launch; args_host = HOST array of struct TuberGemmTNArgs "
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
-                           "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift; float* bias_grad;} with the meaning of the tuber_gemm_tn arguments. "
+                           "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift; float* bias_grad; const void* A2; long lda2;} (A2: optional addend, A := A + A2) with the meaning of the tuber_gemm_tn arguments. "
                            "Transpose-read kernel shapes only (N, K, ld multiples of 8, 64x64 tiles); several slabs need accumulate = 2 (the caller reduces them).",
     "tuber_gemm_tn_args_bytes": "sizeof(struct TuberGemmTNArgs) as compiled (host-side layout check).",
     "tuber_gemm_tn_group_max": "largest n tuber_gemm_tn_group accepts (the argument blocks travel by value in the kernel argument segment).",

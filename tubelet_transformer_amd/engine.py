@@ -30,7 +30,8 @@ class TnArgs(ctypes.Structure):
     _fields_ = [("G", ctypes.c_void_p), ("ldg", ctypes.c_long), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
                 ("partial", ctypes.c_void_p), ("out", ctypes.c_void_p)] + \
                [(k, ctypes.c_int) for k in ("accumulate", "M", "N", "K", "amode", "gather", "To", "Ho", "Wo", "Ti", "Hi", "Wi", "st", "ss")] + \
-               [("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p)]
+               [("a_scale", ctypes.c_void_p), ("a_shift", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p), ("A2", ctypes.c_void_p),
+                ("lda2", ctypes.c_long)]
 
 
 class WgradQueue:

@@ -231,6 +231,102 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
     return y
 
 
+def in_proj(tp, x, addend, wname, bname, rows, add_cols):
+    """Packed attention in-projection with the positional embedding folded in (``with_pos_embed``, transformer.py:150-159,215-240):
+        y[:, :add_cols] = (x + addend) @ W[r0:r0+add_cols]^T + b,      y[:, add_cols:] = x @ W[r0+add_cols:r1]^T + b
+    as ONE GEMM (tuber_gemm_nt_addproj) -- the reference's q / k see x + pos, its v sees x; here that was an add kernel and two GEMM
+    launches.  ``addend`` may carry a gradient (the decoder's query_pos) or not (the sine encoding).  Backward: weight + bias gradients
+    as two queued dW GEMMs on disjoint row blocks (the first with the A + A2 operand formed on load), ONE data-gradient GEMM for x over all
+    N columns, and one over the first add_cols columns for the addend when it needs a gradient."""
+    st = tp.store
+    M, K = x.shape
+    r0, r1 = rows
+    N = r1 - r0
+    dev = x.device
+    assert N % 64 == 0 and add_cols % 128 == 0 and 0 < add_cols <= N and tuple(addend.shape) == (M, K)
+    wb = st.shadow.data_ptr() + 2 * (st.offsets[wname] + r0 * K)
+    bias = st.flat.data_ptr() + 4 * (st.offsets[bname] + r0)
+    y = torch.empty(M, N, dtype=BF, device=dev)
+    lib.call("tuber_gemm_nt_addproj", x, K, addend, K, add_cols, wb, K, y, N, M, N, K, bias)
+    if not tp.train:
+        return y
+    wreq, breq = st.trainable(wname), st.trainable(bname)
+    xreq, areq = tp.needs(x), tp.needs(addend)
+    if not (wreq or breq or xreq or areq):
+        return y
+    tp.mark(y)
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        assert g.dtype == BF and g.is_contiguous()
+        ws = lambda k, n: workspace(dev, k, n)
+        gw = st.gflat.data_ptr() + 4 * (st.offsets[wname] + r0 * K)
+        gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0)
+        # weight / bias gradients: row block [0, add_cols) against x + addend, row block [add_cols, N) against x
+        blocks = [(0, add_cols, addend)] + ([(add_cols, N, None)] if add_cols < N else [])
+        for c0, c1, a2 in blocks:
+            n = c1 - c0
+            gptr = g.data_ptr() + 2 * c0
+            if wreq:
+                S = lib.query("tuber_gemm_tn_slabs", M, n, K)
+                fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, n, K, N, K) if breq else 0
+                assert fuse_b, "in-projection shapes are transpose-read shapes"
+                part, acc = st.partial("tn", S * n * K, ws) if S > 1 else (None, 1)
+                bpart = st.partial("cs", S * n, ws)[0] if fuse_b == 2 else None
+                bptr = (gbias + 4 * c0) if fuse_b == 1 else bpart
+                out = gw + 4 * c0 * K
+                defers = []
+                if acc == 2:
+                    defers.append((part, out, n * K, n * K, S, 0 if S <= 16 else 1))
+                    if fuse_b == 2:
+                        defers.append((bpart, gbias + 4 * c0, n, n, S, 1))
+                ptr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+                args = TnArgs(gptr, N, x.data_ptr(), K, ptr(part), out, acc, M, n, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None, ptr(bptr),
+                              ptr(a2), K if a2 is not None else 0)
+                if st.wq.enabled and (S == 1 or acc == 2):
+                    st.wq.add(args, (g, x, a2), defers)
+                else:
+                    arr = (TnArgs * 1)(args)
+                    lib.call("tuber_gemm_tn_group", arr, 1)
+                    for d in defers:
+                        st.defer.add(*d)
+                    if fuse_b == 2 and acc != 2:
+                        lib.call("tuber_reduce_rows", bpart, gbias + 4 * c0, S, n, 1)
+            elif breq:
+                nbc = lib.query("tuber_colsum_blocks", M)
+                part, acc = st.partial("cs", nbc * n, ws) if nbc > 1 else (None, 1)
+                lib.call("tuber_colsum", gptr, part, gbias + 4 * c0, acc, M, n, N)
+                if acc == 2:
+                    st.defer.add(part, gbias + 4 * c0, n, n, nbc, 1)
+        # data gradients
+        toff, _, _, ldt = st.tinfo[wname]
+        wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
+        plain = lambda ncols, res, out: lib.call("tuber_gemm_nt", g, N, wt, ldt, out, K, M, K, ncols, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                 0, None, res, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+        if xreq:
+            tx = tp.target(x)
+            dx = torch.empty(M, K, dtype=BF, device=dev)
+            r = None
+            if id(tx) not in tp.stack:
+                r = tp.g.pop(id(tx), None)
+                if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous()):
+                    tp.g[id(tx)] = r
+                    r = None
+            plain(N, r, dx)                                  # an existing gradient of x is accumulated by the GEMM's residual input
+            tp.put(tx, dx)
+        if areq:
+            if xreq and add_cols == N:
+                tp.put(addend, dx)                           # same columns, same gradient
+            else:
+                da = torch.empty(M, K, dtype=BF, device=dev)
+                plain(add_cols, None, da)
+                tp.put(addend, da)
+    tp.rec(bwd)
+    return y
+
+
 def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
     """LayerNorm(Dropout_p(x) + res).  ``out`` = (base, row0, col0): write into base[row0:row0+M, col0:col0+E] (the consumer reads
     ``base``; the gradient is read from the same window of base's gradient) -- returns base then."""

@@ -210,12 +210,12 @@ class DETR(nn.Module):
                 p.requires_grad = False
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _mha_self(self, tp, x, qk_in, prefix, B, L, kpm, p):
-        """self-attention with q = k = qk_in, v = x (rows (b, l)); returns out_proj(attn).  p = attention-weight dropout."""
+    def _mha_self(self, tp, x, pos, prefix, B, L, kpm, p):
+        """self-attention with q = k = x + pos, v = x (rows (b, l)); returns out_proj(attn).  p = attention-weight dropout.
+        The packed in-projection is ONE GEMM: its q / k rows see x + pos (added while the operand is staged), its v rows x."""
         E = self.hidden_dim
-        qk = T.linear(tp, qk_in, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(0, 2 * E))
-        v = T.linear(tp, x, prefix + ".in_proj_weight", prefix + ".in_proj_bias", rows=(2 * E, 3 * E))
-        a = T.attention(tp, ((0, 0), (0, E), (1, 0)), (B, 8, L, L, (1, L, 0, 1), (1, L, 0, 1)), kpm, p, qk, v)
+        qkv = T.in_proj(tp, x, pos, prefix + ".in_proj_weight", prefix + ".in_proj_bias", (0, 3 * E), 2 * E)
+        a = T.attention(tp, ((0, 0), (0, E), (0, 2 * E)), (B, 8, L, L, (1, L, 0, 1), (1, L, 0, 1)), kpm, p, qkv)
         return T.linear(tp, a, prefix + ".out_proj.weight", prefix + ".out_proj.bias")
 
     def _ffn(self, tp, x, prefix, p):
@@ -287,11 +287,10 @@ class DETR(nn.Module):
         src = T.linear(tp, xs, "input_proj.weight", "input_proj.bias")             # rows (b, [t,] hw)
         for i in range(self.transformer.encoder.num_layers):
             L = "transformer.encoder.layers.%d" % i
-            a = self._mha_self(tp, src, T.add_const(tp, src, pos), L + ".self_attn", B, Lm, kpm, pattn)
+            a = self._mha_self(tp, src, pos, L + ".self_attn", B, Lm, kpm, pattn)
             src = T.layer_norm(tp, a, src, L + ".norm1", drop=pdrop)
             src = T.layer_norm(tp, self._ffn(tp, src, L, pdrop), src, L + ".norm2", drop=pdrop)
         memory = src
-        mem_pos = T.add_const(tp, memory, pos)
         Q = self.query_embed.num_embeddings
         qpos = T.param_rows(tp, "query_embed.weight", B)                            # rows (b, q)
         tgt = torch.zeros(B * Q, E, dtype=BF, device=dev)
@@ -299,13 +298,12 @@ class DETR(nn.Module):
         hs = torch.empty(lay_n * B * Q, E, dtype=BF, device=dev)                    # rows (layer, b, q)
         for i in range(lay_n):
             L = "transformer.decoder.layers.%d" % i
-            a = self._mha_self(tp, tgt, T.add(tp, tgt, qpos), L + ".self_attn", B, Q, None, pattn)
+            a = self._mha_self(tp, tgt, qpos, L + ".self_attn", B, Q, None, pattn)
             tgt = T.layer_norm(tp, a, tgt, L + ".norm1", drop=pdrop)
             P = L + ".multihead_attn"
-            q = T.linear(tp, T.add(tp, tgt, qpos), P + ".in_proj_weight", P + ".in_proj_bias", rows=(0, E))
-            k = T.linear(tp, mem_pos, P + ".in_proj_weight", P + ".in_proj_bias", rows=(E, 2 * E))
-            v = T.linear(tp, memory, P + ".in_proj_weight", P + ".in_proj_bias", rows=(2 * E, 3 * E))
-            a = T.attention(tp, ((0, 0), (1, 0), (2, 0)), (B, H, Q, Lm, (1, Q, 0, 1), (1, Lm, 0, 1)), kpm, pattn, q, k, v)
+            q = T.in_proj(tp, tgt, qpos, P + ".in_proj_weight", P + ".in_proj_bias", (0, E), E)                  # (tgt + query_pos) W_q
+            kv = T.in_proj(tp, memory, pos, P + ".in_proj_weight", P + ".in_proj_bias", (E, 3 * E), E)          # [(memory + pos) W_k | memory W_v]
+            a = T.attention(tp, ((0, 0), (1, 0), (1, E)), (B, H, Q, Lm, (1, Q, 0, 1), (1, Lm, 0, 1)), kpm, pattn, q, kv)
             a = T.linear(tp, a, P + ".out_proj.weight", P + ".out_proj.bias")
             tgt = T.layer_norm(tp, a, tgt, L + ".norm2", drop=pdrop)
             tgt = T.layer_norm(tp, self._ffn(tp, tgt, L, pdrop), tgt, L + ".norm3", drop=pdrop)
