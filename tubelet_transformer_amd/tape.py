@@ -305,6 +305,7 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
         wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
         plain = lambda ncols, res, out: lib.call("tuber_gemm_nt", g, N, wt, ldt, out, K, M, K, ncols, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                                  0, None, res, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+        shared = False
         if xreq:
             tx = tp.target(x)
             dx = torch.empty(M, K, dtype=BF, device=dev)
@@ -316,8 +317,9 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
                     r = None
             plain(N, r, dx)                                  # an existing gradient of x is accumulated by the GEMM's residual input
             tp.put(tx, dx)
+            shared = r is None and add_cols == N             # dx is the bare product g.W over the addend's columns
         if areq:
-            if xreq and add_cols == N:
+            if shared:
                 tp.put(addend, dx)                           # same columns, same gradient
             else:
                 da = torch.empty(M, K, dtype=BF, device=dev)
