@@ -42,11 +42,6 @@ def alg_cost(name, a):
         tile, occ = {0: ("128,128,2,2,2", 2), 2: ("64,64,2,2,4", 4), 7: ("64,128,1,4,2", 3), 12: ("64,64,2,2,4", 3), 13: ("64,64,2,2,2", 4),
                      17: ("64,128,1,4,2", 4)}[cfg]
         return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, occ), by, 2 * M * N * K
-    if name == "tuber_gemm_nt_joinfwd":
-        M, N, K = a[12], a[13], a[14]
-        cfg = lib.query("tuber_gemm_nt_cfg", M, N, K)
-        tile, occ = {0: ("64,128,1,4,2", 3), 7: ("64,128,1,4,2", 3), 13: ("64,64,2,2,2", 4)}.get(cfg, ("64,64,2,2,2", 4))
-        return "gemm_nt_kernel<%s,4,%d,%d>" % (tile, 1 if a[15] is not None else 0, occ), 2 * (3 * M * K + N * K + M * N), 2 * M * N * K
     if name == "tuber_gemm_nt_join":
         M, N, K = a[6], a[7], a[8]
         cfg = lib.query("tuber_gemm_nt_cfg", M, N, K)
@@ -98,8 +93,6 @@ def alg_cost(name, a):
 def shape_of(name, a):
     if name == "tuber_gemm_nt":
         return "M%d N%d K%d amode%d epi%d" % (a[6], a[7], a[8], a[9], a[21])
-    if name == "tuber_gemm_nt_joinfwd":
-        return "M%d N%d K%d joinfwd" % (a[12], a[13], a[14])
     if name == "tuber_gemm_nt_join":
         return "M%d N%d K%d join" % (a[6], a[7], a[8])
     if name == "tuber_gemm_tn":

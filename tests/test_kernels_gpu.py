@@ -908,28 +908,3 @@ def test_gemm_nt_addproj_and_its_weight_gradient(dev, M, N, K, add_cols):
     gb = db.view(max(S, 1), add_cols).sum(0)
     close("addproj dW", got, g[:, :add_cols].float().t() @ xs.float(), rel=4e-3)
     close("addproj dbias", gb, g[:, :add_cols].float().sum(0), abs_=2e-3 * float(g.float().abs().sum(0).max()))
-
-
-@pytest.mark.parametrize("M,N,K,stats", [(5632, 256, 1024, True), (44032, 128, 512, True), (2816, 512, 2048, False), (1000, 64, 256, True)])
-def test_gemm_nt_joinfwd_equals_block_out_then_conv1(dev, M, N, K, stats):
-    """tuber_gemm_nt_joinfwd == tuber_block_out_fwd followed by tuber_gemm_nt (epi 1 / 0): y, the conv output and the partial
-    statistics are bit-identical"""
-    c4 = rnd(M, K, dev=dev, seed=1).to(BF)
-    x = rnd(M, K, dev=dev, seed=2).to(BF)
-    s4, h4 = 1 + 0.1 * rnd(K, dev=dev, seed=3), 0.1 * rnd(K, dev=dev, seed=4)
-    W = rnd(N, K, dev=dev, seed=5, scale=K ** -0.5).to(BF)
-    y0 = torch.empty(M, K, device=dev, dtype=BF)
-    lib.call("tuber_block_out_fwd", c4, s4, h4, x, None, None, y0, M, K)
-    R = lib.query("tuber_gemm_nt_stat_rows", M, N)
-    a0, a1 = torch.zeros(R, N, device=dev), torch.zeros(R, N, device=dev)
-    C0 = torch.empty(M, N, device=dev, dtype=BF)
-    lib.call("tuber_gemm_nt", y0, K, W, K, C0, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 if stats else 0, None, None, 0, 0, 0,
-             a0 if stats else None, a1 if stats else None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
-    y1 = torch.full((M, K), float("nan"), device=dev, dtype=BF)
-    C1 = torch.full((M, N), float("nan"), device=dev, dtype=BF)
-    b0, b1 = torch.zeros(R, N, device=dev), torch.zeros(R, N, device=dev)
-    lib.call("tuber_gemm_nt_joinfwd", c4, K, s4, h4, x, K, y1, K, W, K, C1, N, M, N, K, b0 if stats else None, b1 if stats else None)
-    torch.cuda.synchronize()
-    assert torch.equal(y0, y1) and torch.equal(C0, C1)
-    if stats:
-        assert torch.equal(a0, b0) and torch.equal(a1, b1)

@@ -23,7 +23,6 @@ from .engine import TnArgs, WgradQueue
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
 BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
-JOIN_FWD_FUSION = not os.environ.get("TUBER_NO_JOIN_FWD_FUSION")   # A/B switch: the residual join as the next conv1's operand prologue
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
@@ -244,27 +243,12 @@ class CSNRunner:
         lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
         saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": []}
         Ti, Hi, Wi = T, Hp, Wp
-        pend = None       # (c4, bn4, residual x, y) of the block below whose join y = relu(bn4(c4) + x) this block's conv1 forms on load
-        nblk = len(self.blocks)
-        for bi, d in enumerate(self.blocks):
+        for d in self.blocks:
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
             c1 = torch.empty(Min, P, dtype=BF, device=dev)
-            if pend is not None:
-                # conv1 with the join of the block below as its operand prologue; the first column tile also writes that block's y
-                pc4, pb4, px, py = pend
-                pend = None
-                if train:
-                    R = lib.query("tuber_gemm_nt_stat_rows", Min, P)
-                    st0, st1 = self.ws("st0", R * P), self.ws("st1", R * P)
-                    lib.call("tuber_gemm_nt_joinfwd", pc4, cin, pb4.scale, pb4.shift, px, cin, py, cin, d["w1"], cin, c1, P, Min, P, cin, st0, st1)
-                    self._bn_train(d["bn1"], st0, st1, R, Min)
-                else:
-                    lib.call("tuber_gemm_nt_joinfwd", pc4, cin, pb4.scale, pb4.shift, px, cin, py, cin, d["w1"], cin, c1, P, Min, P, cin, None, None)
-                    self._bn_eval(d["bn1"])
-            else:
-                self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
+            self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
             c3 = torch.empty(Mout, P, dtype=BF, device=dev)
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED        # LDS-staged kernels for the stride-1 blocks (47 of 50)
@@ -291,8 +275,6 @@ class CSNRunner:
                 gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
                 self._gemm_stats(x, cin, d["wd"], cin, cd, Mout, 4 * P, cin, 0, None, None, gather, d["bnd"], train)
                 lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, cd, d["bnd"].scale, d["bnd"].shift, y, Mout, 4 * P)
-            elif JOIN_FWD_FUSION and bi + 1 < nblk:
-                pend = (c4, b4, x, y)          # identity block: y is produced by the next block's conv1 (tuber_gemm_nt_joinfwd)
             else:
                 lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, x, None, None, y, Mout, 4 * P)
             if train:

@@ -24,10 +24,7 @@
 
 #include "common.h"
 
-enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3, A_JOIN = 4 };
-// A_JOIN:   a = relu(A * scale[k] + shift[k] + A2): the residual join of the bottleneck BELOW (y = relu(bn4(c4) + x), ir_CSN_152.py:86-89)
-//           formed while this block's conv1 stages its operand; the column-tile-0 workgroups also write y (saved for the backward pass and
-//           for the next join) -- the block_out_fwd launch and one activation-sized read disappear
+enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
@@ -44,7 +41,6 @@ struct GemmNT {
     const float* a_scale; const float* a_shift;   // A_BN_RELU (scale, shift) / A_BN_BWD (cA, cB)
     const bf16* A2; long lda2; const float* a_coef2;   // A_BN_BWD: second operand (the BN input x) and cC;  A_ADD: the addend
     int add_ncols;                                     // A_ADD: output columns [0, add_ncols) use A + A2 (multiple of the tile width)
-    bf16* Yout; long ldy;                              // A_JOIN: side output of the joined activation (written by the tile_n == 0 workgroups)
     int gather; int To, Ho, Wo, Ti, Hi, Wi, st, ss; // row gather (strided 1x1x1 conv)
     const float* bias; const bf16* R; long ldr; int relu; int out_f32;   // EPI_PLAIN
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
@@ -84,8 +80,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     // ---- staging assignment: chunk c = tid + 256*i -> (row = c>>3, q = c&7) ----
     const int q = tid & 7;
     const bf16* a_ptr[CA];
-    constexpr bool TWO = AMODE == A_BN_BWD || AMODE == A_ADD || AMODE == A_JOIN;      // second A operand
-    constexpr bool AFFINE = AMODE == A_BN_RELU || AMODE == A_BN_BWD || AMODE == A_JOIN;   // per-k scale / shift staged in LDS
+    constexpr bool TWO = AMODE == A_BN_BWD || AMODE == A_ADD;      // second A operand
     const bf16* a2_ptr[TWO ? CA : 1];
     bool a_ok[CA];
 #pragma unroll
@@ -135,7 +130,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         const int k0 = (kl * KS + kg) * 64;
 #pragma unroll
         for (int i = 0; i < CA; ++i) xa[i] = *(const uint4*)(a_ptr[i] + k0);
-        if (AMODE == A_BN_BWD || AMODE == A_JOIN || (AMODE == A_ADD && add_on)) {
+        if (AMODE == A_BN_BWD || (AMODE == A_ADD && add_on)) {
 #pragma unroll
             for (int i = 0; i < CA; ++i) xa2[i] = *(const uint4*)(a2_ptr[i] + k0);
         }
@@ -152,7 +147,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             const float4 c0 = c4[0], c1 = c4[1];
             s2[0] = c0.x; s2[1] = c0.y; s2[2] = c0.z; s2[3] = c0.w; s2[4] = c1.x; s2[5] = c1.y; s2[6] = c1.z; s2[7] = c1.w;
         }
-        if (AFFINE) {
+        if (AMODE == A_BN_RELU || AMODE == A_BN_BWD) {
             const float4* s4 = (const float4*)(lsc + kt * 64 + q * 8);
             const float4* h4 = (const float4*)(lsh + kt * 64 + q * 8);
             const float4 s0 = s4[0], s1 = s4[1], h0 = h4[0], h1 = h4[1];
@@ -182,14 +177,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = f2bf(bf2f(x[e]) + bf2f(x2[e]));       // = the bf16 sum the stand-alone add kernel stored
                 v = as_uint4(y);
-            }
-            if (AMODE == A_JOIN) {
-                const bf16x8 x = as_bf16x8(v), x2 = as_bf16x8(xa2[i]);
-                bf16x8 y;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sc[e], sh[e]) + bf2f(x2[e]), 0.f));   // = block_out_fwd's arithmetic
-                v = as_uint4(y);
-                if (tile_n == 0 && a_ok[i]) *(uint4*)(p.Yout + (long)(m0 + row) * p.ldy + kt * 64 + q * 8) = v;
             }
             *(uint4*)(sa + row * 128 + ((q ^ swz_act(row)) << 4)) = v;
         }
@@ -256,7 +243,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
     }
-    if (AFFINE) {
+    if (AMODE == A_BN_RELU || AMODE == A_BN_BWD) {
         for (int i = threadIdx.x; i < p.K; i += 256 * KS) {
             lsc[i] = p.a_scale[i]; lsh[i] = p.a_shift[i];
             if (AMODE == A_BN_BWD) lsc2[i] = p.a_coef2[i];
@@ -427,7 +414,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 template <int BM, int BN, int WM, int WN, int G, int OCC>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    const size_t lds = 2 * (BM + BN) * 128 + ((amode == A_BN_RELU || amode == A_JOIN) ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
+    const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
     dim3 grid(tiles), block(256);
 #define LNT(AM, EP)                                                                                                   \
     do {                                                                                                              \
@@ -455,10 +442,6 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         } else if (amode == A_ADD) {
             if (epi != EPI_PLAIN) return TUBER_EINVAL;
             LNT(A_ADD, EPI_PLAIN);
-        } else if (amode == A_JOIN) {
-            if (epi == EPI_PLAIN) LNT(A_JOIN, EPI_PLAIN);
-            else if (epi == EPI_STATS) LNT(A_JOIN, EPI_STATS);
-            else return TUBER_EINVAL;
         } else {
             return TUBER_EINVAL;                          // A_BN_BWD prologue: measured slower than the separate apply kernel, not built
         }
@@ -534,26 +517,6 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
     p.Ym = nullptr; p.ldym = 0; p.add_ncols = 0;
     return nt_dispatch(p, amode, epi, stream);
-}
-
-// conv1 of a bottleneck fused with the residual join of the bottleneck below it (whose output y is this conv's input):
-//   y = relu(c4 * s4[k] + h4[k] + x)   (bn4 apply + identity shortcut + ReLU, ir_CSN_152.py:84-89), written to Y by the first column tile,
-//   C[M,N] = y . B[N,K]^T  (+ partial (sum, sum^2) rows per 64 output rows when stat0 is given: bn1 of this block)
-// i.e. tuber_block_out_fwd followed by tuber_gemm_nt(epi 1) in one launch; results are bit-identical to the pair.
-int tuber_gemm_nt_joinfwd(const void* c4, long ldc4, const float* s4, const float* h4, const void* x, long ldx, void* Y, long ldy,
-                          const void* B, long ldb, void* C, long ldc, int M, int N, int K, float* stat0, float* stat1,
-                          hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (ldc4 & 7) || (ldx & 7) || (ldy & 7) || (ldb & 7) || !c4 || !x || !Y || !s4 || !h4) return TUBER_EINVAL;
-    if ((stat0 == nullptr) != (stat1 == nullptr)) return TUBER_EINVAL;
-    GemmNT p;
-    memset(&p, 0, sizeof p);
-    p.alpha = 1.f; p.drop_inv_keep = 1.f;
-    p.A = (const bf16*)c4; p.lda = ldc4; p.a_scale = s4; p.a_shift = h4;
-    p.A2 = (const bf16*)x; p.lda2 = ldx; p.Yout = (bf16*)Y; p.ldy = ldy;
-    p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
-    p.M = M; p.N = N; p.K = K;
-    p.stat0 = stat0; p.stat1 = stat1;
-    return nt_dispatch(p, A_JOIN, stat0 ? EPI_STATS : EPI_PLAIN, stream);
 }
 
 // Packed attention in-projection with the positional embedding folded in (nn.MultiheadAttention's in_proj on with_pos_embed(x, pos),

@@ -12,10 +12,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
-    "tuber_gemm_nt_joinfwd": "conv1 of a bottleneck (ir_CSN_152.py:72) fused with the residual join of the bottleneck below it (:84-89): the A operand is "
-                             "y = relu(c4*s4[k] + h4[k] + x) formed while it is staged, the first column tile of workgroups also writes y (saved for the backward "
-                             "pass / the next join); with stat0/stat1 the bn1 partial statistics are produced like tuber_gemm_nt(epi 1). Replaces "
-                             "tuber_block_out_fwd + tuber_gemm_nt, bit-identical.",
     "tuber_gemm_nt_addproj": "packed attention in-projection with the positional embedding folded in: C = f(A).B^T + bias with f(A) = A + A2 for the output "
                              "columns [0, add_ncols) (q / k rows of in_proj_weight: with_pos_embed, models/transformer/transformer.py:150-159,215-240) and "
                              "f(A) = A for the v rows -- one GEMM instead of an add kernel and two GEMM launches. add_ncols % 128 == 0.",
