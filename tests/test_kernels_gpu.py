@@ -908,28 +908,3 @@ def test_gemm_nt_addproj_and_its_weight_gradient(dev, M, N, K, add_cols):
     gb = db.view(max(S, 1), add_cols).sum(0)
     close("addproj dW", got, g[:, :add_cols].float().t() @ xs.float(), rel=4e-3)
     close("addproj dbias", gb, g[:, :add_cols].float().sum(0), abs_=2e-3 * float(g.float().abs().sum(0).max()))
-
-
-@pytest.mark.parametrize("N,T,H,W,C,n", [(2, 8, 16, 22, 256, 4), (2, 4, 16, 22, 512, 8), (1, 5, 9, 20, 64, 3)])
-def test_dwconv_tile_wgrad_group_is_bit_identical_to_single_launches(dev, N, T, H, W, C, n):
-    """tuber_dwconv_tile_bwd_weight_group: the depthwise weight gradients of n bottlenecks of one stage in one launch == n single launches"""
-    import ctypes
-    assert n <= lib.query("tuber_dwconv_tile_group_max")
-    nb = lib.query("tuber_dwconv_tile_wgrad_blocks", N, T, H, W, C)
-    keep, singles, ptrs = [], [], {k: [] for k in "gxabp"}
-    for i in range(n):
-        x = rnd(N * T * H * W, C, dev=dev, seed=10 + i).to(BF)
-        g = rnd(N * T * H * W, C, dev=dev, seed=50 + i).to(BF)
-        sc, sh = 1 + 0.2 * rnd(C, dev=dev, seed=90 + i), 0.3 * rnd(C, dev=dev, seed=130 + i)
-        p0 = torch.full((nb * 27 * C,), float("nan"), device=dev)
-        dw = torch.zeros(C, 27, device=dev)
-        lib.call("tuber_dwconv_tile_bwd_weight", g, x, sc, sh, p0, dw, 2, N, T, H, W, C)
-        p1 = torch.full((nb * 27 * C,), float("nan"), device=dev)
-        keep.append((x, g, sc, sh, p0, p1))
-        for k, t in zip("gxabp", (g, x, sc, sh, p1)):
-            ptrs[k].append(t.data_ptr())
-    arr = {k: (ctypes.c_void_p * n)(*v) for k, v in ptrs.items()}
-    lib.call("tuber_dwconv_tile_bwd_weight_group", arr["g"], arr["x"], arr["a"], arr["b"], arr["p"], n, N, T, H, W, C)
-    torch.cuda.synchronize()
-    for x, g, sc, sh, p0, p1 in keep:
-        assert bool(torch.isfinite(p0).all()) and torch.equal(p0, p1)

@@ -13,7 +13,6 @@ Forward schedule per bottleneck (ir_CSN_152.py:70-90), all BN statistics fused i
     cd = gemm_nt(gather(x), Wd)    [+stats]   -> bn_finalize(down_sample.1)      (first block of a stage)
     y  = relu(bn4(c4) + (bn_d(cd) | x))
 """
-import ctypes
 import os
 
 import torch
@@ -24,7 +23,6 @@ from .engine import TnArgs, WgradQueue
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
 BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
-DW_WGRAD_GROUPS = not os.environ.get("TUBER_NO_DW_WGRAD_GROUPS")  # A/B switch: depthwise weight gradients of a stage launched in groups
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
@@ -176,11 +174,6 @@ class CSNRunner:
                 self.blocks.append(d)
         self._ws = {}
         self._fa_max = lib.query("tuber_bn_bwd_fa_max_rows")
-        # queued depthwise weight gradients (same idea as engine.WgradQueue): flushed in groups that fill the chip, and before every
-        # deferred reduction
-        self._dwq, self._dw_max = [], lib.query("tuber_dwconv_tile_group_max")
-        prev = store.defer.pre_flush
-        store.defer.pre_flush = (lambda: (prev(), self.flush_dw())) if prev is not None else self.flush_dw
         # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
         body = [store.offsets[n] + (q.numel() + 63) // 64 * 64 for n, q in zip(store.names, store.params) if n.startswith(prefix)]
         self.body_end = max(body)
@@ -372,29 +365,6 @@ class CSNRunner:
     def flush_wgrads(self):
         self.store.wq.flush()
 
-    def _dw_wgrad(self, geom, dc3, c1, bn, g3, nb):
-        """stride-1 depthwise weight gradient: queued; a group of them (one geometry) runs as ONE launch -- in layer3 / layer4 a single
-        problem is 64 / 32 workgroups (one per CU by LDS), a quarter of the chip for 16 us on every bottleneck's critical path"""
-        B, Ti, Hi, Wi, P = geom
-        part = self.store.defer.alloc(nb * 27 * P)
-        if self._dwq and self._dwq[0][0] != geom:
-            self.flush_dw()
-        self._dwq.append((geom, dc3, c1, bn.scale, bn.shift, part, g3 if isinstance(g3, int) else g3.data_ptr(), nb))
-        wgs = nb * (P // 64)
-        if len(self._dwq) >= max(1, min(self._dw_max, 256 // max(wgs, 1))):
-            self.flush_dw()
-
-    def flush_dw(self):
-        q, self._dwq = self._dwq, []
-        if not q:
-            return
-        n = len(q)
-        B, Ti, Hi, Wi, P = q[0][0]
-        arr = lambda k: (ctypes.c_void_p * n)(*[(e[k] if isinstance(e[k], int) else e[k].data_ptr()) for e in q])
-        lib.call("tuber_dwconv_tile_bwd_weight_group", arr(1), arr(2), arr(3), arr(4), arr(5), n, B, Ti, Hi, Wi, P)
-        for e in q:
-            self.store.defer.add(e[5], e[6], 27 * P, 27 * P, e[7], 1, P)
-
     def backward(self, saved, dfeat):
         """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients of the TRAINABLE tensors are
         accumulated into the ParamStore's flat gradient buffer; the chain stops at the lowest block with a trainable tensor."""
@@ -446,9 +416,7 @@ class CSNRunner:
                 dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
-            if f["w3"] and tile and DW_WGRAD_GROUPS and self.store.defer.enabled:
-                self._dw_wgrad((B, Ti, Hi, Wi, P), dc3, c1, b1, d["g3"], lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P))
-            elif f["w3"]:
+            if f["w3"]:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
                 if tile:
@@ -507,7 +475,6 @@ class CSNRunner:
             # layer3 / layer4 ones are short: up to 8 (four bottlenecks) share a launch
             if d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
                 self.flush_wgrads()
-                self.flush_dw()
             if red is not None:
                 self.store.defer.flush()         # the slice handed to RCCL must include the deferred second-stage reductions
                 red.notify(d["off0"])
@@ -519,7 +486,6 @@ class CSNRunner:
                 # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem
                 hook(d["off0"])
         self.flush_wgrads()
-        self.flush_dw()
         if not stem_plan["any"]:
             return
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient (implicit GEMM over the clip)

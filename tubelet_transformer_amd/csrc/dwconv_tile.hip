@@ -13,7 +13,6 @@
 // Modes: forward (+ partial statistics of bn3), data gradient (flipped taps; fused with the backward of relu(bn1(.)) and
 // bn1's partial statistics), weight gradient (27 x 4 accumulators per thread, one partial [27][64] per workgroup).
 #include <cstdlib>
-#include <cstring>
 
 #include "common.h"
 
@@ -46,13 +45,13 @@ struct TileArgs {
 };
 
 template <int MODE>
-__device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx) {
+__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
     const TileGeom g = a.g;
     const int tid = threadIdx.x;
     const int cl = tid & 15, slot = tid >> 4, row = slot >> 2, cg = slot & 3;
     const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
-    int b = bx;
+    int b = blockIdx.x;
     const int wt = b % g.wtiles; b /= g.wtiles;
     const int ht = b % g.htiles; b /= g.htiles;
     const int tk = b % g.tchunks; const int n = b / g.tchunks;
@@ -253,7 +252,7 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
 #pragma unroll
             for (int wv8 = 0; wv8 < 8; ++wv8) s += red[wv8 * 27 * 64 + i];
             const int tap = i >> 6, cc = i & 63;
-            a.P[((long)bx * 27 + tap) * g.C + c0 + cc] = s;
+            a.P[((long)blockIdx.x * 27 + tap) * g.C + c0 + cc] = s;
         }
     } else if (a.st0) {
 #pragma unroll
@@ -264,22 +263,9 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 32; ++k) s += red[(which * 32 + k) * 64 + cc];
-            (which ? a.st1 : a.st0)[(long)bx * g.C + c0 + cc] = s;
+            (which ? a.st1 : a.st0)[(long)blockIdx.x * g.C + c0 + cc] = s;
         }
     }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE>(a, (int)blockIdx.x); }
-
-// Several depthwise WEIGHT gradients of one geometry in ONE launch.  A weight gradient feeds nothing until the optimizer, and in
-// layer3 / layer4 one problem is only 64 / 32 workgroups (one resident per CU: 145 KB of LDS) -- a quarter of the chip, 16 us on the
-// critical path of every bottleneck's backward.  The backbone queues them and four at a time run as one grid (256 workgroups).
-#define DW_GROUP_MAX 8
-struct TileGroup { TileArgs a[DW_GROUP_MAX]; int n, per; };
-__global__ __launch_bounds__(512) void dwconv_tile_wgrad_group_kernel(TileGroup g) {
-    const int e = (int)blockIdx.x / g.per;
-    dwconv_tile_body<M_BWD_WEIGHT>(g.a[e], (int)blockIdx.x - e * g.per);
 }
 
 TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
@@ -362,33 +348,6 @@ int tuber_dwconv_tile_bwd_weight(const void* gout, const void* x, const float* s
     const int rc = launch_tile<M_BWD_WEIGHT>(a, stream);
     if (rc || accumulate == 2) return rc;      // accumulate == 2: partial blocks reduced later by tuber_multi_reduce
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
-}
-
-// n <= tuber_dwconv_tile_group_max() weight gradients of ONE geometry (N, T, H, W, C) in one launch: host arrays gout[i], x[i], sc[i],
-// sh[i], partial[i] (each partial holds tuber_dwconv_tile_wgrad_blocks * 27 * C floats, reduced by the caller: tuber_dw_wgrad_reduce or a
-// tuber_multi_reduce entry, exactly as tuber_dwconv_tile_bwd_weight with accumulate = 2 leaves them).
-int tuber_dwconv_tile_group_max(void) { return DW_GROUP_MAX; }
-int tuber_dwconv_tile_bwd_weight_group(const void* const* gout, const void* const* x, const float* const* sc, const float* const* sh,
-                                       float* const* partial, int n, int N, int T, int H, int W, int C, hipStream_t stream) {
-    if (n <= 0 || n > DW_GROUP_MAX || (C & 63) || !gout || !x || !sc || !sh || !partial) return TUBER_EINVAL;
-    TileGroup g;
-    memset(&g, 0, sizeof g);
-    const TileGeom geom = make_geom(N, T, H, W, C, true);
-    g.n = n;
-    g.per = geom.N * geom.tchunks * geom.htiles * geom.wtiles;
-    for (int i = 0; i < n; ++i) {
-        if (!gout[i] || !x[i] || !sc[i] || !sh[i] || !partial[i]) return TUBER_EINVAL;
-        g.a[i].in = (const bf16*)x[i]; g.a[i].sc = sc[i]; g.a[i].sh = sh[i]; g.a[i].aux = (const bf16*)gout[i]; g.a[i].P = partial[i];
-        g.a[i].g = geom;
-    }
-    const size_t lds = (3 * PLANE + 27 * 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)dwconv_tile_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(dwconv_tile_wgrad_group_kernel, dim3(g.per * n, C / 64), dim3(512), lds, stream, g);
-    TUBER_RETURN_LAUNCH();
 }
 
 }  // extern "C"

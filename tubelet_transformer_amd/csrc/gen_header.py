@@ -12,10 +12,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 DOC = {
-    "tuber_dwconv_tile_bwd_weight_group": "n depthwise weight gradients of ONE geometry (the stride-1 conv3 of n bottlenecks of a stage, ir_CSN_152.py:48-51) in one "
-                                          "launch; HOST arrays of device pointers gout[i], x[i], sc[i], sh[i], partial[i]; partials reduced by the caller as with "
-                                          "tuber_dwconv_tile_bwd_weight(accumulate = 2).",
-    "tuber_dwconv_tile_group_max": "largest n tuber_dwconv_tile_bwd_weight_group accepts.",
     "tuber_gemm_nt_addproj": "packed attention in-projection with the positional embedding folded in: C = f(A).B^T + bias with f(A) = A + A2 for the output "
                              "columns [0, add_ncols) (q / k rows of in_proj_weight: with_pos_embed, models/transformer/transformer.py:150-159,215-240) and "
                              "f(A) = A for the v rows -- one GEMM instead of an add kernel and two GEMM launches. add_ncols % 128 == 0.",
