@@ -16,6 +16,7 @@ NT_SHAPES = [  # (M, N, K, amode, epi, residual)
     (348160, 64, 256, 0, 1, 0), (348160, 256, 64, 1, 1, 0), (348160, 64, 256, 0, 2, 0), (348160, 256, 64, 0, 0, 0),
     (704, 512, 2048, 0, 1, 0), (704, 2048, 512, 1, 1, 0), (704, 256, 256, 0, 0, 0), (30, 256, 256, 0, 0, 0),
     (16896, 2048, 512, 0, 0, 0),
+    (30, 256, 2048, 0, 0, 0), (704, 256, 2048, 0, 0, 0), (30, 256, 2048, 0, 2, 0), (704, 256, 2048, 0, 2, 0), (30, 2048, 256, 0, 0, 0), (704, 2048, 256, 0, 0, 0),
 ]
 
 
