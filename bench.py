@@ -421,13 +421,19 @@ def main():
                                   "mfma_frac_of_alg_flops": round(981e9 * total_clips / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12 * world), 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, hw, dataset, batch=args.batch)
+    # RCCL prints its banner through C stdio, which a pipe holds back until exit: tear the communicators down and drain every rank's
+    # C buffers first, so that the JSON line is the last line this job writes to stdout.
+    red = getattr(model.engine()[0], "reducer", None)
+    if red is not None and red.comm is not None:
+        red.comm.close()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        red = getattr(model.engine()[0], "reducer", None)
-        if red is not None and red.comm is not None:
-            red.comm.close()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
