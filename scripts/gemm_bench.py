@@ -144,7 +144,38 @@ def bench_attn():
         print("attention B%d Lq%d Lk%d: fwd %.1f us (%.1f TF/s), bwd %.1f us (%.1f TF/s)" % (B, Lq, Lk, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
 
 
+def bench_stem():
+    B, T, H, W = 2, 32, 256, 340
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    M, Mp = B * T * Ho * Wo, B * T * Hp * Wp
+    clip = torch.randn(B, 3, T, H, W, device=dev)
+    wp = torch.zeros(64, 512, device=dev, dtype=BF)
+    lib.call("tuber_stem_pack_weight", torch.randn(64, 441, device=dev) / 21, wp)
+    R = lib.query("tuber_stem_conv_blocks", B, T, H, W)
+    c0 = torch.empty(M, 64, device=dev, dtype=BF)
+    st0, st1 = torch.empty(4096, 64, device=dev), torch.empty(4096, 64, device=dev)
+    g = torch.randn(M, 64, device=dev).to(BF)
+    part = torch.empty(lib.query("tuber_stem_conv_wgrad_blocks", B, T, H, W) * 512 * 64, device=dev)
+    dw = torch.zeros(64, 441, device=dev)
+    sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    out = torch.empty(Mp, 64, device=dev, dtype=BF)
+    arg = torch.empty(Mp, 64, device=dev, dtype=torch.uint8)
+    gp = torch.randn(Mp, 64, device=dev).to(BF)
+    dz = torch.empty(M, 64, device=dev, dtype=BF)
+    t = [time_it(lambda: lib.call("tuber_stem_conv_fwd", clip, wp, c0, st0, st1, B, T, H, W), iters=5),
+         time_it(lambda: lib.call("tuber_stem_conv_bwd_weight", clip, g, part, dw, 0, B, T, H, W), iters=5),
+         time_it(lambda: lib.call("tuber_stem_pool_fwd", c0, sc, sh, out, arg, B * T, Ho, Wo, Hp, Wp), iters=5),
+         time_it(lambda: lib.call("tuber_stem_pool_bwd", gp, arg, c0, sc, sh, dz, st0, st1, B * T, Ho, Wo, Hp, Wp), iters=5)]
+    alg = [4 * clip.numel() + 2 * M * 64, 4 * clip.numel() + 2 * M * 64, 2 * M * 64 + 3 * Mp * 64, 4 * M * 64 + 3 * Mp * 64]
+    for n, us, by in zip(["conv fwd", "conv wgrad (+reduce)", "pool fwd", "pool bwd"], t, alg):
+        print("stem %-22s %8.1f us   alg %.0f MB -> %.0f GB/s" % (n, us, by / 1e6, by / us / 1e3), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stem":
+        bench_stem()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         bench_attn()
         sys.exit(0)

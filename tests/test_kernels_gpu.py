@@ -597,7 +597,7 @@ def test_attention_dropout_backward(dev, Lq, Lk):
     close("attention+dropout bwd dv", dv, back(vh, Lk), rel=2 ** -5)
 
 
-@pytest.mark.parametrize("N,T,H,W", [(1, 4, 30, 38), (2, 3, 64, 340)])
+@pytest.mark.parametrize("N,T,H,W", [(1, 4, 30, 38), (2, 3, 64, 340), (2, 8, 96, 150)])
 def test_stem(dev, N, T, H, W):
     clip = rnd(N, 3, T, H, W, dev=dev, seed=1)
     w = rnd(64, 3, 3, 7, 7, dev=dev, seed=2, scale=441 ** -0.5)
@@ -618,7 +618,7 @@ def test_stem(dev, N, T, H, W):
     wr = bfr(w).clone().requires_grad_(True)
     F.conv3d(bfr(clip), wr, stride=(1, 2, 2), padding=(1, 3, 3)).backward(gg.float().view(N, T, Ho, Wo, 64).permute(0, 4, 1, 2, 3))
     dwt = torch.zeros(64, 441, device=dev)
-    part = torch.empty(min(R, 256) * 512 * 64, device=dev)
+    part = torch.empty(lib.query("tuber_stem_conv_wgrad_blocks", N, T, H, W) * 512 * 64, device=dev)
     lib.call("tuber_stem_conv_bwd_weight", clip, gg, part, dwt, 0, N, T, H, W)
     close("stem conv implicit dW", dwt, wr.grad.view(64, 441), rel=2e-3)
     # pool fwd

@@ -499,5 +499,5 @@ class CSNRunner:
         dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0, train=stem_plan["bn"], apply=stem_plan["w"])
         if stem_plan["w"]:
             H, W = clips.shape[-2:]
-            nwg = min(lib.query("tuber_stem_conv_blocks", B, T, H, W), 256)
+            nwg = lib.query("tuber_stem_conv_wgrad_blocks", B, T, H, W)
             lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)

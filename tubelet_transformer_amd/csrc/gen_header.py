@@ -115,7 +115,8 @@ DOC = {
     "tuber_stem_conv_fwd": "stem Conv3d(3,64,(3,7,7),s=(1,2,2),p=(1,3,3)) (ir_CSN_152.py:109-115) as an implicit MFMA GEMM from the fp32 NCDHW clip to NDHWC bf16, "
                            "with the partial statistics of the following BatchNorm; Wp = tuber_stem_pack_weight(conv1.weight).",
     "tuber_stem_conv_bwd_weight": "weight gradient of the stem conv ([64][441] fp32) as an implicit MFMA GEMM (no patch matrix in HBM).",
-    "tuber_stem_conv_blocks": "persistent grid size of the stem conv kernels = partial-stat rows of the forward.",
+    "tuber_stem_conv_blocks": "persistent grid size of the stem conv forward = its partial-stat rows.",
+    "tuber_stem_conv_wgrad_blocks": "workgroups (= [512][64] fp32 partial slabs) of tuber_stem_conv_bwd_weight.",
     "tuber_stem_pack_weight": "conv1.weight [64][441] fp32 -> [64][512] bf16 with k' = (c,kt,kh)*8 + kw (zero padded).",
     "tuber_stem_pool_fwd": "relu(bn1(.)) + MaxPool3d((1,3,3),s=(1,2,2),p=(0,1,1)) (ir_CSN_152.py:119-122) on NDHWC bf16, C=64; saves the argmax tap.",
     "tuber_stem_pool_bwd": "backward of the pool + relu(bn1(.)): dz and the BN-backward partial statistics.",

@@ -53,24 +53,28 @@ __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const bf16* __restri
 
 // gradient back through pool + relu(bn): for every stem position gather the pooled gradients whose
 // argmax points at it, mask by relu, write dz and the BN-backward partial statistics.
+// One workgroup = `rows_per_block` consecutive positions; 8 lanes x 8 channels per position, 32 positions per pass.  All index
+// arithmetic is 32-bit (positions < 2^31 / 64 is checked by the host) -- the 64-bit div/mod per position of the first version was
+// a large part of its time.
 __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restrict__ gpool, const uint8_t* __restrict__ arg,
                                                             const bf16* __restrict__ x, const float* __restrict__ sc,
                                                             const float* __restrict__ sh, bf16* __restrict__ dz,
                                                             float* __restrict__ st0, float* __restrict__ st1, int NT, int Hs,
-                                                            int Ws, int Hp, int Wp, long rows_per_block) {
+                                                            int Ws, int Hp, int Wp, int rows_per_block) {
     __shared__ float red[2][32][64];
     const int cg = threadIdx.x & 7, rs = threadIdx.x >> 3;
     float a[8], b[8], s0[8], s1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = sc[cg * 8 + e]; b[e] = sh[cg * 8 + e]; s0[e] = 0.f; s1[e] = 0.f; }
-    const long total = (long)NT * Hs * Ws;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(total, r0 + rows_per_block);
-    for (long p = r0 + rs; p < r1; p += 32) {
-        const int wi = (int)(p % Ws); long r = p / Ws;
-        const int hi = (int)(r % Hs); const long nt = r / Hs;
+    const int total = NT * Hs * Ws;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(total, r0 + rows_per_block);
+    for (int p = r0 + rs; p < r1; p += 32) {
+        const int wi = p % Ws; const int r = p / Ws;
+        const int hi = r % Hs; const int nt = r / Hs;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const bf16x8 xv = as_bf16x8(*(const uint4*)(x + (long)p * 64 + cg * 8));
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
             const int hn = hi + 1 - dh;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restri
                 if (wn < 0 || (wn & 1)) continue;
                 const int wp = wn >> 1;
                 if (wp >= Wp) continue;
-                const long q = ((nt * Hp + hp) * Wp + wp) * 64 + cg * 8;
+                const long q = (long)((nt * Hp + hp) * Wp + wp) * 64 + cg * 8;
                 const bf16x8 g = as_bf16x8(*(const uint4*)(gpool + q));
                 const uint2 ai = *(const uint2*)(arg + q);
                 const int tap = dh * 3 + dw;
@@ -94,7 +98,6 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restri
                 }
             }
         }
-        const bf16x8 xv = as_bf16x8(*(const uint4*)(x + p * 64 + cg * 8));
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const bf16* __restri
             o[e] = f2bf(v);
             s0[e] += v; s1[e] += v * xf;
         }
-        *(uint4*)(dz + p * 64 + cg * 8) = as_uint4(o);
+        *(uint4*)(dz + (long)p * 64 + cg * 8) = as_uint4(o);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[0][rs][cg * 8 + e] = s0[e]; red[1][rs][cg * 8 + e] = s1[e]; }
@@ -129,13 +132,18 @@ int tuber_stem_pool_fwd(const void* x, const float* sc, const float* sh, void* o
     TUBER_RETURN_LAUNCH();
 }
 
-int tuber_stem_pool_bwd_stat_rows(long positions) { long nb = (positions + 1023) / 1024; return (int)(nb > 1024 ? 1024 : nb); }
+int tuber_stem_pool_bwd_stat_rows(long positions) {
+    static const int cap = getenv("TUBER_STEM_POOL_WG") ? atoi(getenv("TUBER_STEM_POOL_WG")) : 2048;
+    long nb = (positions + 255) / 256;
+    return (int)(nb > cap ? cap : nb);
+}
 
 int tuber_stem_pool_bwd(const void* gpool, const void* arg, const void* x, const float* sc, const float* sh, void* dz, float* st0,
                         float* st1, int NT, int Hs, int Ws, int Hp, int Wp, hipStream_t stream) {
     const long total = (long)NT * Hs * Ws;
+    if (total <= 0 || total >= (1L << 31) / 64) return TUBER_EINVAL;
     const int nb = tuber_stem_pool_bwd_stat_rows(total);
-    const long rpb = (total + nb - 1) / nb;
+    const int rpb = (int)((total + nb - 1) / nb);
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)x,
                        sc, sh, (bf16*)dz, st0, st1, NT, Hs, Ws, Hp, Wp, rpb);
     TUBER_RETURN_LAUNCH();
