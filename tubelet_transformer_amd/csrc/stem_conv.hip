@@ -166,33 +166,30 @@ __global__ __launch_bounds__(256, 3) void stem_conv_fwd_kernel(const float* __re
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // MFMA column li of m-tile mt is output column 4*li + mt: the operand fragment P[run][2w .. 2w+7] of those four columns
-        // are dwords mt .. mt+3 of ONE 7-dword LDS read (28 B per lane and k-step instead of 4 x 16 B)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const uint32_t* p = (const uint32_t*)&P[buf][ks * 4 + gq][8 * li];
-            const uint4 a = *(const uint4*)p;
-            const uint2 b = *(const uint2*)(p + 4);
-            const uint32_t d[7] = {a.x, a.y, a.z, a.w, b.x, b.y, p[6]};
+            const int run = ks * 4 + gq;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], as_bf16x8(make_uint4(d[mt], d[mt + 1], d[mt + 2], d[mt + 3])), acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint32_t* p = (const uint32_t*)&P[buf][run][2 * (mt * 16 + li)];         // P[run][2w .. 2w+7], w = mt*16 + li
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], as_bf16x8(make_uint4(p[0], p[1], p[2], p[3])), acc[mt], 0, 0, 0);
+            }
         }
         // park the next patch BEFORE the output stores: vmcnt counts loads and stores in order, so waiting for a load that was issued
         // before a store never waits for the store's acknowledgement, the other order does
         if (next < wk.end) stem_park<4>(P[buf ^ 1], pre, meta, L, wv);
-        // D[i = channel][j = column]: lane holds column 4*li + mt, channels wave*16 + gq*4 + 0..3
+        // D[i = channel][j = column]: lane holds column mt*16 + li, channels wave*16 + gq*4 + 0..3
         const StemTile st = stem_tile(g, tile);
         const int wt = st.wt;
         const long row0 = st.row0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int w = wt * SW + 4 * li + mt;
+            const int w = wt * SW + mt * 16 + li;
             if (w < g.Wo) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { o[r] = f2bf(acc[mt][r]); s0[r] += acc[mt][r]; s1[r] += acc[mt][r] * acc[mt][r]; }
-                *(uint2*)(out + (row0 + 4 * li + mt) * 64 + wave * 16 + gq * 4) = as_uint2(o);
+                *(uint2*)(out + (row0 + mt * 16 + li) * 64 + wave * 16 + gq * 4) = as_uint2(o);
             }
         }
         __syncthreads();
@@ -361,7 +358,7 @@ extern "C" {
 
 // persistent grid of both kernels (= partial-statistics rows of the forward, slabs of the weight gradient)
 int tuber_stem_conv_blocks(int B, int T, int H, int W) {
-    static const int cap = getenv("TUBER_STEM_FWD_WG") ? atoi(getenv("TUBER_STEM_FWD_WG")) : 768;      // 168 VGPRs: three workgroups per CU
+    static const int cap = getenv("TUBER_STEM_FWD_WG") ? atoi(getenv("TUBER_STEM_FWD_WG")) : 768;      // 159 VGPRs: three workgroups per CU
     const StemGeom g = stem_geom(B, T, H, W);
     return g.ntiles < cap ? g.ntiles : cap;
 }
