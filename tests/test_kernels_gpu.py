@@ -490,8 +490,11 @@ def attn_ref(q, k, v, kpm, scale):
 
 
 @pytest.mark.parametrize("B,Lq,Lk,masked", [(2, 352, 352, True), (2, 15, 352, True), (12, 15, 1408, False), (3, 200, 77, False),
-                                            (40, 4, 4, False)])
+                                            (40, 4, 4, False), (40, 100, 130, True), (2, 100, 700, True), (33, 40, 1000, False)])
 def test_attention(dev, B, Lq, Lk, masked):
+    """MFMA kernels in both work splits (64-row workgroups when ceil(Lq/64)*H*B >= 256: (40,100,130); 16-row workgroups whose four
+    waves split the tiles of the other operand otherwise, incl. fewer tiles than waves, ragged last tiles and Lq != Lk -- the forward
+    / dQ split follows Lq, the dK/dV split Lk: (33,40,1000) mixes them), and the scalar kernels for (40,4,4)."""
     H, E = 8, 256
     # token-major packed layout (l, b, E): row(l,b) = l*B + b
     q = rnd(Lq, B, E, dev=dev, seed=1).to(BF)

@@ -13,6 +13,16 @@
 //   dQ      : S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
 //   dK, dV  : S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
 // Dropout regenerates the forward mask from (seed, salt, ((b*H+h)*Lq+q)*Lk+k) like the scalar kernels of attention.hip.
+//
+// Two work splits of the same inner loops (template parameter SPLIT):
+//   SPLIT = false: workgroup = 64 rows (16 per wave), the four waves share each staged 64-row tile of the other operand
+//                  (class branch: 384 (b, h) pairs x 6 tiles fill the chip).
+//   SPLIT = true : workgroup = 16 rows; all four waves own the SAME 16 rows and take every fourth tile of the loop, each staging
+//                  its tiles in a wave-private LDS image (no workgroup barrier inside the loop); the partial results -- online-
+//                  softmax states (m, l, O) in the forward, plain sums in the backward -- are merged through LDS at the end.
+//                  For the DETR encoder / decoder of a 2-clip batch (16 (b, h) pairs; 96 resp. 16 workgroups of 64 rows) the
+//                  kernel time is one wave's dependent chain over 6 key tiles; this cuts the chain to 2 tiles and puts 352 instead
+//                  of 96 workgroups on the 256 CUs.
 #include "attention.h"
 
 namespace {
@@ -52,17 +62,39 @@ __device__ __forceinline__ bf16x8 frag_tr_rm(const bf16 (*src)[RP], int d0, int 
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
+// SPLIT staging: one wave stages a whole 64-row tile (lane = row, four 16-byte chunks) into its private image
+struct WaveTile { uint4 c[4]; };
+__device__ __forceinline__ WaveTile wave_fetch(const bf16* base, const TokMap& m, int b, int h, int r0, int L) {
+    const int r = r0 + (threadIdx.x & 63);
+    WaveTile t;
+    if (r < L) {
+        const uint4* p = (const uint4*)(base + trow(m, r, b) * m.ld + h * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t.c[c] = p[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t.c[c] = make_uint4(0, 0, 0, 0);
+    }
+    return t;
+}
+__device__ __forceinline__ void wave_park(bf16 (*dst)[RP], const WaveTile& t) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(uint4*)&dst[threadIdx.x & 63][c * 8] = t.c[c];
+}
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
 
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 vs[TL][RP];
-    __shared__ uint8_t msk[TL];
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    constexpr int NI = SPLIT ? 4 : 1;                     // staged images (one per wave when the waves split the key tiles)
+    __shared__ __attribute__((aligned(16))) bf16 ks[NI][TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 vs[NI][TL][RP];
+    __shared__ uint8_t msk[NI][TL];
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (SPLIT ? 16 : 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-    const int qi = q0 + wave * 16 + li;
+    const int im = SPLIT ? wave : 0;
+    const int qi = q0 + (SPLIT ? 0 : wave * 16) + li;
     const bool qok = qi < a.Lq;
     const int qc = qok ? qi : a.Lq - 1;
     const bf16x8 qf = as_bf16x8(*(const uint4*)(a.Q + trow(a.mq, qc, b) * a.mq.ld + h * 32 + g * 8));
@@ -71,27 +103,40 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     float mx = -INFINITY, l = 0.f;
-    uint4 kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk), vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk);
-    for (int k0 = 0; k0 < a.Lk; k0 += TL) {
-        __syncthreads();
-        park_rm(ks, kr);
-        park_rm(vs, vr);
-        if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
-        if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
-        __syncthreads();
+    const int kfirst = SPLIT ? wave * TL : 0, kstep = SPLIT ? 4 * TL : TL;
+    uint4 kr, vr;
+    WaveTile kw, vw;
+    if (SPLIT) { if (kfirst < a.Lk) { kw = wave_fetch(a.K, a.mk, b, h, kfirst, a.Lk); vw = wave_fetch(a.V, a.mv, b, h, kfirst, a.Lk); } }
+    else { kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk); }
+    for (int k0 = kfirst; k0 < a.Lk; k0 += kstep) {
+        if (SPLIT) {
+            // wave-private images: the LDS queue keeps one wave's reads and writes in order, no workgroup barrier
+            wave_park(ks[im], kw);
+            wave_park(vs[im], vw);
+            msk[im][lane] = (k0 + lane >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + lane]);
+            if (k0 + kstep < a.Lk) { kw = wave_fetch(a.K, a.mk, b, h, k0 + kstep, a.Lk); vw = wave_fetch(a.V, a.mv, b, h, k0 + kstep, a.Lk); }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+            park_rm(ks[0], kr);
+            park_rm(vs[0], vr);
+            if (threadIdx.x < TL) msk[0][threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
+            if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
+            __syncthreads();
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int c0 = sub * 32;
             f32x4 s[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) s[t] = mfma(frag_rm(ks, c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int t = 0; t < 2; ++t) s[t] = mfma(frag_rm(ks[im], c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
             float p[8];
             float cmax = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool dead = msk[c0 + t * 16 + g * 4 + r];
+                    const bool dead = msk[im][c0 + t * 16 + g * 4 + r];
                     p[t * 4 + r] = dead ? -INFINITY : s[t][r] * a.scale;
                     cmax = fmaxf(cmax, p[t * 4 + r]);
                 }
@@ -114,9 +159,35 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
             mx = mnew;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            o0 = mfma(frag_tr_rm(vs, 0, c0, li, g), pf, o0);
-            o1 = mfma(frag_tr_rm(vs, 16, c0, li, g), pf, o1);
+            o0 = mfma(frag_tr_rm(vs[im], 0, c0, li, g), pf, o0);
+            o1 = mfma(frag_tr_rm(vs[im], 16, c0, li, g), pf, o1);
         }
+        if (SPLIT) __builtin_amdgcn_wave_barrier();
+    }
+    if (SPLIT) {
+        // merge the four waves' online-softmax states of the same 16 queries: m = max m_w, l = sum l_w e^(m_w - m), O likewise
+        __syncthreads();
+        float* cmb = (float*)&ks[0][0][0];                 // [4 waves][64 lanes][10]: 10 KB of the 20 KB the images occupy
+        float* mine = cmb + (wave * 64 + lane) * 10;
+        mine[0] = mx; mine[1] = l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mine[2 + r] = o0[r]; mine[6 + r] = o1[r]; }
+        __syncthreads();
+        if (wave != 0) return;
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, cmb[(w * 64 + lane) * 10]);
+        l = 0.f;
+        o0 = f32x4{0.f, 0.f, 0.f, 0.f}; o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* o = cmb + (w * 64 + lane) * 10;
+            const float f = o[0] == -INFINITY ? 0.f : __expf(o[0] - m);
+            l += o[1] * f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] += o[2 + r] * f; o1[r] += o[6 + r] * f; }
+        }
+        mx = m;
     }
     if (qok) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -132,13 +203,16 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // dQ (and delta = dO . O for the dK/dV kernel): workgroup = 64 queries of one (b, h), loop over key tiles
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 vs[TL][RP];
-    __shared__ uint8_t msk[TL];
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    constexpr int NI = SPLIT ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) bf16 ks[NI][TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 vs[NI][TL][RP];
+    __shared__ uint8_t msk[NI][TL];
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (SPLIT ? 16 : 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-    const int qi = q0 + wave * 16 + li;
+    const int im = SPLIT ? wave : 0;
+    const int qi = q0 + (SPLIT ? 0 : wave * 16) + li;
     const bool qok = qi < a.Lq;
     const int qc = qok ? qi : a.Lq - 1;
     const bf16x8 qf = as_bf16x8(*(const uint4*)(a.Q + trow(a.mq, qc, b) * a.mq.ld + h * 32 + g * 8));
@@ -152,39 +226,65 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
         delta = group_sum(d);
     }
     const float lse = a.lse[((long)b * a.H + h) * a.Lq + qc];
-    if (qok && g == 0) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
+    if (qok && g == 0 && (!SPLIT || wave == 0)) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
     const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
     const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-    uint4 kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk), vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk);
-    for (int k0 = 0; k0 < a.Lk; k0 += TL) {
-        __syncthreads();
-        park_rm(ks, kr);
-        park_rm(vs, vr);
-        if (threadIdx.x < TL) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
-        if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
-        __syncthreads();
+    const int kfirst = SPLIT ? wave * TL : 0, kstep = SPLIT ? 4 * TL : TL;
+    uint4 kr, vr;
+    WaveTile kw, vw;
+    if (SPLIT) { if (kfirst < a.Lk) { kw = wave_fetch(a.K, a.mk, b, h, kfirst, a.Lk); vw = wave_fetch(a.V, a.mv, b, h, kfirst, a.Lk); } }
+    else { kr = tile_fetch(a.K, a.mk, b, h, 0, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, 0, a.Lk); }
+    for (int k0 = kfirst; k0 < a.Lk; k0 += kstep) {
+        if (SPLIT) {
+            wave_park(ks[im], kw);
+            wave_park(vs[im], vw);
+            msk[im][lane] = (k0 + lane >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + lane]);
+            if (k0 + kstep < a.Lk) { kw = wave_fetch(a.K, a.mk, b, h, k0 + kstep, a.Lk); vw = wave_fetch(a.V, a.mv, b, h, k0 + kstep, a.Lk); }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+            park_rm(ks[0], kr);
+            park_rm(vs[0], vr);
+            if (threadIdx.x < TL) msk[0][threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
+            if (k0 + TL < a.Lk) { kr = tile_fetch(a.K, a.mk, b, h, k0 + TL, a.Lk); vr = tile_fetch(a.V, a.mv, b, h, k0 + TL, a.Lk); }
+            __syncthreads();
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int c0 = sub * 32;
             bf16x8 dsf;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const f32x4 s = mfma(frag_rm(ks, c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
-                const f32x4 dp = mfma(frag_rm(vs, c0 + t * 16, li, g), dof, f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 s = mfma(frag_rm(ks[im], c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 dp = mfma(frag_rm(vs[im], c0 + t * 16, li, g), dof, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kl = c0 + t * 16 + g * 4 + r;
-                    const float p = msk[kl] ? 0.f : __expf(s[r] * a.scale - lse);
+                    const float p = msk[im][kl] ? 0.f : __expf(s[r] * a.scale - lse);
                     float dpv = dp[r];
                     if (a.pdrop > 0.f) dpv = dropout_keep(seed, rbase + k0 + kl, a.thresh) ? dpv * inv_keep : 0.f;
                     dsf[t * 4 + r] = f2bf(p * (dpv - delta) * a.scale);
                 }
             }
-            dq0 = mfma(frag_tr_rm(ks, 0, c0, li, g), dsf, dq0);
-            dq1 = mfma(frag_tr_rm(ks, 16, c0, li, g), dsf, dq1);
+            dq0 = mfma(frag_tr_rm(ks[im], 0, c0, li, g), dsf, dq0);
+            dq1 = mfma(frag_tr_rm(ks[im], 16, c0, li, g), dsf, dq1);
         }
+        if (SPLIT) __builtin_amdgcn_wave_barrier();
+    }
+    if (SPLIT) {                                           // sum the four waves' partial dQ of the same 16 queries
+        __syncthreads();
+        float* cmb = (float*)&ks[0][0][0];                 // [4][64][8]
+        float* mine = cmb + (wave * 64 + lane) * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mine[r] = dq0[r]; mine[4 + r] = dq1[r]; }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dq0[r] += cmb[(w * 64 + lane) * 8 + r]; dq1[r] += cmb[(w * 64 + lane) * 8 + 4 + r]; }
     }
     if (qok) {
         bf16* orow = a.dQ + trow(a.mdq, qi, b) * a.mdq.ld + h * 32;
@@ -197,13 +297,16 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
 }
 
 // dK, dV: workgroup = 64 keys of one (b, h), loop over query tiles
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 qs[TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 dos[TL][RP];
-    __shared__ float lse_s[TL], del_s[TL];
-    const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x * 64;
+    constexpr int NI = SPLIT ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) bf16 qs[NI][TL][RP];
+    __shared__ __attribute__((aligned(16))) bf16 dos[NI][TL][RP];
+    __shared__ float lse_s[NI][TL], del_s[NI][TL];
+    const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x * (SPLIT ? 16 : 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-    const int ki = kb + wave * 16 + li;
+    const int im = SPLIT ? wave : 0;
+    const int ki = kb + (SPLIT ? 0 : wave * 16) + li;
     const bool kin = ki < a.Lk;
     const int kc = kin ? ki : a.Lk - 1;
     const bool kdead = !kin || (a.kpm && a.kpm[(long)b * a.Lk + kc]);
@@ -213,33 +316,50 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
     const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t bh = (uint64_t)(b * a.H + h);
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
-    uint4 qr = tile_fetch(a.Q, a.mq, b, h, 0, a.Lq), dr = tile_fetch(a.dO, a.mdo, b, h, 0, a.Lq);
+    const int qfirst = SPLIT ? wave * TL : 0, qstep = SPLIT ? 4 * TL : TL;
+    const int srow = SPLIT ? lane : (int)threadIdx.x;      // which row of the tile this thread carries lse / delta for
+    uint4 qr, dr;
+    WaveTile qw, dw;
     float lr = 0.f, er = 0.f;
-    if (threadIdx.x < TL && threadIdx.x < a.Lq) { lr = a.lse[bh * a.Lq + threadIdx.x]; er = a.delta[bh * a.Lq + threadIdx.x]; }
-    for (int q0 = 0; q0 < a.Lq; q0 += TL) {
-        __syncthreads();
-        park_rm(qs, qr);
-        park_rm(dos, dr);
-        if (threadIdx.x < TL) { lse_s[threadIdx.x] = lr; del_s[threadIdx.x] = er; }
-        if (q0 + TL < a.Lq) {
-            qr = tile_fetch(a.Q, a.mq, b, h, q0 + TL, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, q0 + TL, a.Lq);
-            const int qn = q0 + TL + threadIdx.x;
-            if (threadIdx.x < TL) { lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f; }
+    if (SPLIT) { if (qfirst < a.Lq) { qw = wave_fetch(a.Q, a.mq, b, h, qfirst, a.Lq); dw = wave_fetch(a.dO, a.mdo, b, h, qfirst, a.Lq); } }
+    else { qr = tile_fetch(a.Q, a.mq, b, h, 0, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, 0, a.Lq); }
+    if (srow < TL && qfirst + srow < a.Lq) { lr = a.lse[bh * a.Lq + qfirst + srow]; er = a.delta[bh * a.Lq + qfirst + srow]; }
+    for (int q0 = qfirst; q0 < a.Lq; q0 += qstep) {
+        if (SPLIT) {
+            wave_park(qs[im], qw);
+            wave_park(dos[im], dw);
+            lse_s[im][lane] = lr; del_s[im][lane] = er;
+            if (q0 + qstep < a.Lq) {
+                qw = wave_fetch(a.Q, a.mq, b, h, q0 + qstep, a.Lq); dw = wave_fetch(a.dO, a.mdo, b, h, q0 + qstep, a.Lq);
+                const int qn = q0 + qstep + lane;
+                lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+            park_rm(qs[0], qr);
+            park_rm(dos[0], dr);
+            if (threadIdx.x < TL) { lse_s[0][threadIdx.x] = lr; del_s[0][threadIdx.x] = er; }
+            if (q0 + TL < a.Lq) {
+                qr = tile_fetch(a.Q, a.mq, b, h, q0 + TL, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, q0 + TL, a.Lq);
+                const int qn = q0 + TL + threadIdx.x;
+                if (threadIdx.x < TL) { lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int c0 = sub * 32;
             bf16x8 pf, dsf;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const f32x4 s = mfma(frag_rm(qs, c0 + t * 16, li, g), kf, f32x4{0.f, 0.f, 0.f, 0.f});      // S[q][key li]
-                const f32x4 dp = mfma(frag_rm(dos, c0 + t * 16, li, g), vf, f32x4{0.f, 0.f, 0.f, 0.f});    // dP[q][key li]
+                const f32x4 s = mfma(frag_rm(qs[im], c0 + t * 16, li, g), kf, f32x4{0.f, 0.f, 0.f, 0.f});      // S[q][key li]
+                const f32x4 dp = mfma(frag_rm(dos[im], c0 + t * 16, li, g), vf, f32x4{0.f, 0.f, 0.f, 0.f});    // dP[q][key li]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = c0 + t * 16 + g * 4 + r, qq = q0 + ql;
                     const bool live = !kdead && qq < a.Lq;
-                    const float p = live ? __expf(s[r] * a.scale - lse_s[ql]) : 0.f;
+                    const float p = live ? __expf(s[r] * a.scale - lse_s[im][ql]) : 0.f;
                     float pd = p, dpv = dp[r];
                     if (a.pdrop > 0.f) {
                         const bool keep = dropout_keep(seed, (bh * a.Lq + (uint64_t)(live ? qq : 0)) * (uint64_t)a.Lk + kc, a.thresh);
@@ -247,13 +367,29 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
                         dpv = keep ? dpv * inv_keep : 0.f;
                     }
                     pf[t * 4 + r] = f2bf(pd);
-                    dsf[t * 4 + r] = f2bf(p * (dpv - del_s[ql]) * a.scale);
+                    dsf[t * 4 + r] = f2bf(p * (dpv - del_s[im][ql]) * a.scale);
                 }
             }
-            dv0 = mfma(frag_tr_rm(dos, 0, c0, li, g), pf, dv0);
-            dv1 = mfma(frag_tr_rm(dos, 16, c0, li, g), pf, dv1);
-            dk0 = mfma(frag_tr_rm(qs, 0, c0, li, g), dsf, dk0);
-            dk1 = mfma(frag_tr_rm(qs, 16, c0, li, g), dsf, dk1);
+            dv0 = mfma(frag_tr_rm(dos[im], 0, c0, li, g), pf, dv0);
+            dv1 = mfma(frag_tr_rm(dos[im], 16, c0, li, g), pf, dv1);
+            dk0 = mfma(frag_tr_rm(qs[im], 0, c0, li, g), dsf, dk0);
+            dk1 = mfma(frag_tr_rm(qs[im], 16, c0, li, g), dsf, dk1);
+        }
+        if (SPLIT) __builtin_amdgcn_wave_barrier();
+    }
+    if (SPLIT) {                                           // sum the four waves' partial dK / dV of the same 16 keys
+        __syncthreads();
+        float* cmb = (float*)&qs[0][0][0];                 // [4][64][16] = 16 KB of the 20 KB
+        float* mine = cmb + (wave * 64 + lane) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mine[r] = dk0[r]; mine[4 + r] = dk1[r]; mine[8 + r] = dv0[r]; mine[12 + r] = dv1[r]; }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float* o = cmb + (w * 64 + lane) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dk0[r] += o[r]; dk1[r] += o[4 + r]; dv0[r] += o[8 + r]; dv1[r] += o[12 + r]; }
         }
     }
     if (kin) {
@@ -271,13 +407,21 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
 
 }  // namespace
 
-// entry points used by tuber_attn_fwd / tuber_attn_bwd (attention.hip) for Lq >= 32; `args` is an AttnArgs
+// entry points used by tuber_attn_fwd / tuber_attn_bwd (attention.hip) for Lq >= 32; `args` is an AttnArgs.
+// The wave-split kernels take over when the 64-row workgroups would leave most of the 256 CUs idle.
+static bool attn_split(int rows, int H, int B) {
+    static const int lim = getenv("TUBER_ATTN_SPLIT_BELOW") ? atoi(getenv("TUBER_ATTN_SPLIT_BELOW")) : 256;
+    return (long)ceil_div(rows, 64) * H * B < lim;
+}
 extern "C" void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
+    if (attn_split(a.Lq, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_fwd_kernel<true>, dim3(ceil_div(a.Lq, 16), a.H, a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_mfma_fwd_kernel<false>, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
 }
 extern "C" void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel, dim3(ceil_div(a.Lk, 64), a.H, a.B), dim3(256), 0, stream, a);
+    if (attn_split(a.Lq, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<true>, dim3(ceil_div(a.Lq, 16), a.H, a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<false>, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
+    if (attn_split(a.Lk, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel<true>, dim3(ceil_div(a.Lk, 16), a.H, a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel<false>, dim3(ceil_div(a.Lk, 64), a.H, a.B), dim3(256), 0, stream, a);
 }
