@@ -362,9 +362,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 #define WT_MAX 8
 __device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes sharing a head
-    v = quad16_sum(v);
-    v += __shfl_xor(v, 16);
-    return v;
+    return xor16_sum(quad16_sum(v));
 }
 __device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
     const bf16x8 t = as_bf16x8(*(const uint4*)p);

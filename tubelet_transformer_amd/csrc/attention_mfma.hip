@@ -81,8 +81,8 @@ __device__ __forceinline__ void wave_park(bf16 (*dst)[RP], const WaveTile& t) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) *(uint4*)&dst[threadIdx.x & 63][c * 8] = t.c[c];
 }
-__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float group_max(float v) { return xor32_max(xor16_max(v)); }
+__device__ __forceinline__ float group_sum(float v) { return xor32_sum(xor16_sum(v)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool SPLIT>

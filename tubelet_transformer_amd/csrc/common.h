@@ -50,6 +50,7 @@ __device__ __forceinline__ float dpp_f32(float v) {
 #define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
 #define DPP_HALF_MIRROR 0x141  /* after xor1+xor2: acts as xor 4 */
 #define DPP_MIRROR 0x140       /* after xor1+xor2+xor4: acts as xor 8 */
+#define DPP_ROR8 0x128         /* row_ror:8 = lane ^ 8 inside the 16-lane row, for arbitrary values */
 
 // sum over the 16 lanes that share (lane >> 4); every lane gets the total
 __device__ __forceinline__ float quad16_sum(float v) {
@@ -66,18 +67,28 @@ __device__ __forceinline__ float quad16_max(float v) {
     v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-    v = quad16_sum(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// Exchange ACROSS the 16-lane rows: the gfx950 row swaps (v_permlane16_swap / v_permlane32_swap: VALU, no LDS).  Given two copies of
+// v, the swap leaves {own row pair's even row} in one and {odd row} in the other for every lane, so their sum / max is what
+// v (+|max) __shfl_xor(v, 16 | 32) computes -- bit-identical (the operands are the same two values), without the two ds_bpermute
+// round trips that sat in the dependent chain of every softmax column maximum.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
 }
-__device__ __forceinline__ float wave_max(float v) {
-    v = quad16_max(v);
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
 }
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(quad16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(quad16_max(v))); }
 
 // Counter-based RNG for dropout: one 32-bit hash per (seed, element index).  Deterministic and
 // stateless so the backward pass regenerates the forward mask instead of storing it.

@@ -326,8 +326,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[t][e];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v = xor32_sum(xor16_sum(v));
             if ((threadIdx.x & 63) < 16) red[wave][t][cl * 4 + e] = v;
         }
     __syncthreads();

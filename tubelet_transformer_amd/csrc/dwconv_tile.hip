@@ -242,8 +242,7 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = wacc[t][e >> 1][e & 1];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
+                v = xor32_sum(xor16_sum(v));
                 if ((tid & 63) < 16) red[(wave * 27 + t) * 64 + cl * 4 + e] = v;
             }
         __syncthreads();

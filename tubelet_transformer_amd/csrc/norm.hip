@@ -45,7 +45,8 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) { a[e] += __shfl_xor(a[e], off, 64); b[e] += __shfl_xor(b[e], off, 64); }
+        a[e] = xor32_sum(xor16_sum(a[e] + dpp_f32<DPP_ROR8>(a[e])));
+        b[e] = xor32_sum(xor16_sum(b[e] + dpp_f32<DPP_ROR8>(b[e])));
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < 8) {
