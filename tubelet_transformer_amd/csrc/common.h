@@ -71,22 +71,24 @@ __device__ __forceinline__ float quad16_max(float v) {
 // v, the swap leaves {own row pair's even row} in one and {odd row} in the other for every lane, so their sum / max is what
 // v (+|max) __shfl_xor(v, 16 | 32) computes -- bit-identical (the operands are the same two values), without the two ds_bpermute
 // round trips that sat in the dependent chain of every softmax column maximum.
-__device__ __forceinline__ float xor16_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+// (The two results are copied into scalars before the bit cast: __builtin_bit_cast applied to the vector ELEMENT r[1] read element 0
+// with this compiler, which made every such reduction x + x -- found by the depthwise weight-gradient test.)
+__device__ __forceinline__ void row_swap16(float v, float& x, float& y) {
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    x = __builtin_bit_cast(float, r0); y = __builtin_bit_cast(float, r1);
 }
-__device__ __forceinline__ float xor32_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+__device__ __forceinline__ void row_swap32(float v, float& x, float& y) {
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    x = __builtin_bit_cast(float, r0); y = __builtin_bit_cast(float, r1);
 }
-__device__ __forceinline__ float xor16_max(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-__device__ __forceinline__ float xor32_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
+__device__ __forceinline__ float xor16_sum(float v) { float x, y; row_swap16(v, x, y); return x + y; }
+__device__ __forceinline__ float xor32_sum(float v) { float x, y; row_swap32(v, x, y); return x + y; }
+__device__ __forceinline__ float xor16_max(float v) { float x, y; row_swap16(v, x, y); return fmaxf(x, y); }
+__device__ __forceinline__ float xor32_max(float v) { float x, y; row_swap32(v, x, y); return fmaxf(x, y); }
 __device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(quad16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(quad16_max(v))); }
 

@@ -44,7 +44,6 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, c
     // 128 row groups -> 16 (one per wave) via shuffles over the lanes sharing qd (lane bits 3..5), then LDS
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-#pragma unroll
         a[e] = xor32_sum(xor16_sum(a[e] + dpp_f32<DPP_ROR8>(a[e])));
         b[e] = xor32_sum(xor16_sum(b[e] + dpp_f32<DPP_ROR8>(b[e])));
     }
