@@ -236,6 +236,13 @@ def cpu_baseline(cfg, hw, dataset, batch=2, warm=1, timed=3):
                       "fp32, dropout off; %.1f s/step (steps: %s)" % (warm, timed, batch, hw[0], hw[1], dt, " ".join("%.1f" % t for t in times))}
 
 
+def lib_md5():
+    """checksum of the HIP library this process loaded -- recorded so that a number can be tied to the build it was measured on"""
+    import hashlib
+    from tubelet_transformer_amd import lib
+    return hashlib.md5(open(lib.LIBPATH, "rb").read()).hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,7 +380,8 @@ def main():
         "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights%s"
                                % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1],
                                   ", stem+layer1+layer2 frozen (pretrained recipe)" if args.pretrained_freeze else ""),
-                   "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce on an own communicator + stream, under the layer2/1/stem backward)" % world if world > 1 else "dp1", "launch_mode": mode},
+                   "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce on an own communicator + stream, under the layer2/1/stem backward)" % world if world > 1 else "dp1", "launch_mode": mode,
+                   "lib_md5": lib_md5()},
         "final_loss": round(float(loss.detach()), 4) if loss is not None else None,
         "alg_gflop_per_clip_fwd_bwd": alg_gflop,
         "readme_implied_gflops": round(total_clips / dt * 120.0, 1),
