@@ -106,6 +106,51 @@ def test_gemm_nt_forced_tile_configs(dev, cfg, M, N, K):
         lib.call("tuber_gemm_nt_set_cfg", -1)
 
 
+@pytest.mark.parametrize("M,N,K", [(5632, 256, 1024), (704, 256, 2048), (30, 256, 2048), (2816, 512, 2048), (700, 130, 1088), (64, 64, 1024)])
+def test_gemm_nt_wave_split_k(dev, M, N, K):
+    """the wave split-K form of the 64x64 kernel (taken automatically for plain A, >= 16 k-tiles, <= 512 tiles: every wave computes the
+    whole tile for every fourth k-tile, the partial tiles are summed through LDS) with all four epilogues, against fp32 and against
+    the shared-tile kernel (forced cfg 13) -- same products, a different summation order: agreement to accumulation rounding.
+    Ragged M / N (700 x 130) and a k-tile count (17) that is not a multiple of the four waves included."""
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3)
+    R = rnd(M, N, dev=dev, seed=4).to(BF)
+    Cm = rnd(M, N, dev=dev, seed=7).to(BF)
+    Y = rnd(M, N, dev=dev, seed=8).to(BF)
+    ref = A.float() @ B.float().t()
+
+    def run_all():
+        out = {}
+        out["plain"] = gemm_nt(A, B, M, N, K, bias=bias, R=R, relu=1)[0]
+        out["stats"] = gemm_nt(A, B, M, N, K, epi=1)
+        out["bwd"] = gemm_nt(A, B, M, N, K, epi=2, Cm=Cm)
+        rows = lib.query("tuber_gemm_nt_stat_rows", M, N)
+        dz, b0, b1 = torch.empty(M, N, device=dev, dtype=BF), torch.zeros(rows, N, device=dev), torch.zeros(rows, N, device=dev)
+        lib.call("tuber_gemm_nt_join", A, K, B, K, dz, N, M, N, K, R, N, Y, N, Cm, N, b0, b1)
+        out["join"] = (dz, b0, b1)
+        return out
+    got = run_all()                                       # automatic choice: wave split-K
+    lib.call("tuber_gemm_nt_set_cfg", 13)
+    try:
+        base = run_all()                                  # shared-tile kernel
+    finally:
+        lib.call("tuber_gemm_nt_set_cfg", -1)
+    close("wsk plain", got["plain"], (ref + bias + R.float()).relu())
+    close("wsk plain vs shared tile", got["plain"], base["plain"], rel=2 ** -8)
+    close("wsk stats out", got["stats"][0], ref)
+    close("wsk stats sum", got["stats"][1].sum(0), ref.sum(0), abs_=2e-3 * float(ref.abs().sum(0).max()))
+    close("wsk stats sumsq", got["stats"][2].sum(0), (ref * ref).sum(0), rel=2e-3)
+    close("wsk stats rows vs shared tile", got["stats"][1], base["stats"][1], rel=1e-4, abs_=1e-3 * float(base["stats"][1].abs().max()))
+    refm = ref * (Cm.float() > 0)
+    close("wsk masked out", got["bwd"][0], refm)
+    close("wsk masked sum dz*c", got["bwd"][2].sum(0), (refm * Cm.float()).sum(0), abs_=2e-3 * float((refm * Cm.float()).abs().sum(0).max()))
+    refj = bfr(ref + R.float()) * (Y.float() > 0)
+    close("wsk join dz", got["join"][0], refj)
+    close("wsk join vs shared tile", got["join"][0], base["join"][0], rel=2 ** -8)
+    close("wsk join sum dz*c", got["join"][2].sum(0), (refj * Cm.float()).sum(0), abs_=2e-3 * float((refj * Cm.float()).abs().sum(0).max()))
+
+
 def test_gemm_nt_gather(dev):
     n, Ti, Hi, Wi, K, N = 2, 8, 15, 21, 256, 512
     st, ss = 2, 2

@@ -57,8 +57,14 @@ __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3)
 // OCC = waves per SIMD the register allocation is held to (= workgroups per CU: a workgroup is one wave per SIMD).  It must not
 // exceed what the LDS allows anyway -- 2*(BM+BN)*128 B per workgroup of the 160 KB: 64x64 -> 4-5, 64x128 -> 3, 128x128 -> 2 --
 // or the compiler spills the prefetch registers to scratch inside the k-loop for occupancy the kernel can never reach.
-template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC>
+// WSK = 1 ("wave split-K", 64x64 tiles, plain A only): the four waves do NOT tile the output -- each computes the WHOLE 64x64 tile for
+// every fourth k-tile, staged in a wave-private LDS image (no workgroup barrier per k-tile), and the four partial tiles are summed
+// through LDS in wave order before the common epilogue.  For the shapes whose time is their k-loop (layer3 / layer4 1x1x1 convs with
+// K >= 1024 on 352 workgroups, the FFN GEMMs with K = 2048 on 11 .. 44): a k-tile costs ~0.24 us of barriers and exposed latency in
+// the shared-tile loop whatever it computes.
+template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC, int WSK = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
+    static_assert(!WSK || (BM == 64 && BN == 64 && WM == 2 && WN == 2 && AMODE == A_PLAIN), "wave split-K: 64x64 tiles, plain A");
     constexpr int KS = 1, kg = 0;               // (the in-workgroup k-split of round 1 was measured and dropped; the index math keeps its shape)
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
@@ -224,9 +230,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     constexpr int NC = 4 * NT;
     const int nb = n0 + wn * TN + g * NC;
     const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
+    if constexpr (!WSK) {
 #pragma unroll
-    for (int j = 0; j < G; ++j)
-        if (j < nk) load_tile(j, ra[j], rb[j], ra2[TWO ? j : 0]);
+        for (int j = 0; j < G; ++j)
+            if (j < nk) load_tile(j, ra[j], rb[j], ra2[TWO ? j : 0]);
+    }
     constexpr bool SIDE = EPI == EPI_BWD || EPI == EPI_JOIN;
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
     uint4 sidey[EPI == EPI_JOIN ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
@@ -250,19 +258,110 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         }
         __syncthreads();
     }
-    // software pipeline over k-tiles: register set j holds tile g0+j; as soon as it has been written to LDS the same
-    // registers are re-armed with tile g0+G+j, so G tiles of global loads stay in flight behind the MFMA work.
-    int buf = 0;
-    for (int g0 = 0; g0 < nk_max; g0 += G) {
+    if constexpr (WSK) {
+        // ---- wave split-K: this wave owns k-tiles wave, wave+4, ...; image = A 64 x 128 B | B 64 x 128 B, private to the wave ----
+        char* const sa = smem + wave * 16384;
+        char* const sb = sa + 8192;
+        const int lq = lane & 7, lr = lane >> 3;                 // chunk c = lane + 64 i -> row lr + 8 i, 16-byte chunk lq
+        const bf16* pa[8];
+        const bf16* pb[8];
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (g0 + j < nk_max) {
-                const bool have = g0 + j < nk;           // (odd tile counts: the second group idles through its last barrier)
-                if (have) store_tile(g0 + j, buf, ra[j], rb[j], ra2[TWO ? j : 0]);
-                if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[TWO ? j : 0]);
-                __syncthreads();
-                if (have) compute(buf);
-                buf ^= 1;
+        for (int i = 0; i < 8; ++i) {
+            pa[i] = p.A + (long)min(m0 + lr + 8 * i, p.M - 1) * p.lda + lq * 8;
+            pb[i] = p.B + (long)min(n0 + lr + 8 * i, p.N - 1) * p.ldb + lq * 8;
+        }
+        uint4 xa[8], xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xa[i] = make_uint4(0, 0, 0, 0); xb[i] = make_uint4(0, 0, 0, 0); }     // defined on every path: stays in VGPRs
+        auto fetch = [&](int kt, uint4 (&ya)[8], uint4 (&yb)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ya[i] = *(const uint4*)(pa[i] + kt * 64); yb[i] = *(const uint4*)(pb[i] + kt * 64); }
+        };
+        f32x4 acc4[2][2][MT][NT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc4[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave < nkt) fetch(wave, xa, xb);
+        for (int kt = wave; kt < nkt; kt += 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = lr + 8 * i;
+                *(uint4*)(sa + row * 128 + ((lq ^ swz_act(row)) << 4)) = xa[i];
+                *(uint4*)(sb + row * 128 + ((lq ^ swz_wgt<NT>(row)) << 4)) = xb[i];
+            }
+            if (kt + 4 < nkt) fetch(kt + 4, xa, xb);
+            __builtin_amdgcn_wave_barrier();                      // one wave's LDS writes and reads stay in order: no workgroup barrier
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int qq = ks * 4 + g;
+                bf16x8 fa[2][MT], fb[2][NT];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int r = a * TM + i * 16 + li;
+                        fa[a][i] = as_bf16x8(*(const uint4*)(sa + r * 128 + ((qq ^ swz_act(r)) << 4)));
+                    }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int r = b * TN + (li >> 2) * (4 * NT) + j * 4 + (li & 3);
+                        fb[b][j] = as_bf16x8(*(const uint4*)(sb + r * 128 + ((qq ^ swz_wgt<NT>(r)) << 4)));
+                    }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc4[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b][j], fa[a][i], acc4[a][b][i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- sum the four partial tiles: every wave parks all four sub-tiles in ITS OWN image (16 KB: nobody else reads or writes it
+        // before the barrier), then wave (wm, wn) adds the four copies of its sub-tile in wave order ----
+        f32x4* mine = (f32x4*)sa;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mine[(((a * 2 + b) * MT + i) * NT + j) * 64 + lane] = acc4[a][b][i][j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += ((const f32x4*)(smem + w * 16384))[(((wm * 2 + wn) * MT + i) * NT + j) * 64 + lane];
+                acc[i][j] = t;
+            }
+    } else {
+    // software pipeline over k-tiles: register set j holds tile g0+j; as soon as it has been written to LDS the same
+        // registers are re-armed with tile g0+G+j, so G tiles of global loads stay in flight behind the MFMA work.
+        int buf = 0;
+        for (int g0 = 0; g0 < nk_max; g0 += G) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (g0 + j < nk_max) {
+                    const bool have = g0 + j < nk;           // (odd tile counts: the second group idles through its last barrier)
+                    if (have) store_tile(g0 + j, buf, ra[j], rb[j], ra2[TWO ? j : 0]);
+                    if (g0 + G + j < nk) load_tile(g0 + G + j, ra[j], rb[j], ra2[TWO ? j : 0]);
+                    __syncthreads();
+                    if (have) compute(buf);
+                    buf ^= 1;
+                }
             }
         }
     }
@@ -450,6 +549,27 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     TUBER_RETURN_LAUNCH();
 }
 
+// wave split-K launch (64x64 tiles, plain A): 64 KB of LDS (four private 16 KB images), two workgroups per CU
+static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
+    const int tiles = ceil_div(p.M, 64) * ceil_div(p.N, 64);
+    dim3 grid(tiles), block(256);
+    const size_t lds = 4 * 16384;
+#define LWSK(EP) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, 2, A_PLAIN, EP, 2, 1>), grid, block, lds, s, p)
+    if (epi == EPI_PLAIN) LWSK(EPI_PLAIN);
+    else if (epi == EPI_STATS) LWSK(EPI_STATS);
+    else if (epi == EPI_JOIN) LWSK(EPI_JOIN);
+    else LWSK(EPI_BWD);
+#undef LWSK
+    TUBER_RETURN_LAUNCH();
+}
+// shapes that take it: plain A, no row gather, at least `min_kt` k-tiles, and few enough 64x64 tiles that they are all resident at once
+static bool nt_use_wsk(const GemmNT& p, int amode) {
+    static const int min_kt = getenv("TUBER_NT_WSK_MIN_KT") ? atoi(getenv("TUBER_NT_WSK_MIN_KT")) : 16;      // 0 = never
+    if (min_kt <= 0 || amode != A_PLAIN || p.gather || p.out_f32) return false;
+    const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
+    return p.K / 64 >= min_kt && tiles <= 512;
+}
+
 // tile choice: (cfg 0) 128x128, (1) 128x64, (2) 64x64
 static int g_nt_force = -2;
 static int nt_force_cfg() {
@@ -557,6 +677,7 @@ int tuber_gemm_nt_join(const void* A, long lda, const void* B, long ldb, void* d
 static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) {
     const int M = p.M, N = p.N, K = p.K;
     int cfg = nt_pick_cfg(M, N, K);
+    if (nt_force_cfg() < 0 && cfg == 13 && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
     switch (cfg) {
         case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // A/B only
