@@ -292,6 +292,19 @@ __global__ __launch_bounds__(256) void bn_bwd_fa_kernel(
     __shared__ float coef[3][FA_CS];
     const int c0 = blockIdx.y * FA_CS;
     const int tid = threadIdx.x;
+    // ---- the apply phase's operands go out FIRST (thread = row slot of 16 x 8-channel group of 16; FA_ROWS / 16 = 8 rows per thread):
+    // their latency then runs under the derive phase instead of after it (one exposed memory round trip per workgroup, not two)
+    const int cg = tid & 15, rs = tid >> 4;
+    const long r0 = (long)blockIdx.x * FA_ROWS;
+    const long r1 = min(M, r0 + FA_ROWS);
+    uint4 pd[FA_ROWS / 16], px[FA_ROWS / 16];
+#pragma unroll
+    for (int k = 0; k < FA_ROWS / 16; ++k) {
+        const long row = r0 + rs + 16 * k;
+        const long off = min(row, M - 1) * C + c0 + cg * 8;
+        pd[k] = *(const uint4*)(dz + off);
+        px[k] = *(const uint4*)(x + off);
+    }
     // ---- derive: thread = (row group rg of 8, channel quad q of 32) ----
     {
         const int q = tid & 31, rg = tid >> 5;
@@ -335,21 +348,19 @@ __global__ __launch_bounds__(256) void bn_bwd_fa_kernel(
         }
     }
     __syncthreads();
-    // ---- apply: thread = (row slot of 16, 8-channel group of 16) ----
-    const int cg = tid & 15, rs = tid >> 4;
+    // ---- apply ----
     float ca[8], cb[8], cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ca[e] = coef[0][cg * 8 + e]; cb[e] = coef[1][cg * 8 + e]; cc[e] = coef[2][cg * 8 + e]; }
-    const long r0 = (long)blockIdx.x * FA_ROWS;
-    const long r1 = min(M, r0 + FA_ROWS);
-    for (long row = r0 + rs; row < r1; row += 16) {
-        const long off = row * C + c0 + cg * 8;
-        const bf16x8 d = as_bf16x8(*(const uint4*)(dz + off));
-        const bf16x8 xx = as_bf16x8(*(const uint4*)(x + off));
+#pragma unroll
+    for (int k = 0; k < FA_ROWS / 16; ++k) {
+        const long row = r0 + rs + 16 * k;
+        if (row >= r1) break;
+        const bf16x8 d = as_bf16x8(pd[k]), xx = as_bf16x8(px[k]);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(ca[e], bf2f(d[e]), fmaf(cb[e], bf2f(xx[e]), cc[e])));
-        *(uint4*)(dx + off) = as_uint4(o);
+        *(uint4*)(dx + row * C + c0 + cg * 8) = as_uint4(o);
     }
 }
 
