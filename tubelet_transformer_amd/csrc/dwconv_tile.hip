@@ -136,20 +136,31 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: planes t0-1 and t0 parked, t0+1 in flight ----
-    park(t0 - 1, regs_a);
-    park(t0, regs_b);
     const int ho = h0 + row, wo0 = w0 + cg * 4;
     const bool row_ok = ho < g.H;
+    // side inputs of an output plane (global, 8 B per column): bwd data: x (needed after the taps);  wgrad: gout (needed BEFORE the
+    // taps -- so the weight gradient fetches them one plane ahead, the first ones together with the prologue planes)
+    auto side_fetch = [&](int t, uint2 (&sd)[4]) {
+        const long ob = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            sd[j] = (row_ok && wo0 + j < g.W) ? *(const uint2*)(a.aux + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+    };
+    uint2 side_nx[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+    if constexpr (MODE == M_BWD_WEIGHT) side_fetch(t0, side_nx);
+    park(t0 - 1, regs_a);
+    park(t0, regs_b);
     for (int t = t0; t < t1; ++t) {
         park(t + 1, regs);
         if (t + 1 < t1) fetch(t + 2, regs);
-        // side inputs of this output plane (global, 8 B per column): bwd data: x;  wgrad: gout
         uint2 side[4];
         const long obase = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
-        if (MODE != M_FWD) {
+        if constexpr (MODE == M_BWD_WEIGHT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                side[j] = (row_ok && wo0 + j < g.W) ? *(const uint2*)(a.aux + obase + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+            for (int j = 0; j < 4; ++j) side[j] = side_nx[j];
+            if (t + 1 < t1) side_fetch(t + 1, side_nx);
+        } else if (MODE != M_FWD) {
+            side_fetch(t, side);
         }
         __syncthreads();
         f32x2 acc[4][2];
