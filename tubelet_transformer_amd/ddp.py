@@ -225,6 +225,24 @@ def attach_reducer(store, force=False):
     comm = None
     own = store.device.type == "cuda" and (not ddp or dist.get_backend() == "nccl" or os.environ.get("TUBER_OWN_RCCL"))
     if own and not os.environ.get("TUBER_NO_OWN_RCCL"):
-        comm = RcclComm(store.device)
+        err = None
+        try:
+            comm = RcclComm(store.device)
+        except Exception as e:                      # noqa: BLE001 -- reported below, on every rank
+            if world <= 1:
+                raise
+            err = e
+        if world > 1:
+            # all ranks must end up on the SAME transport: if the directly bound communicator failed anywhere, everybody takes the
+            # process group's (both are RCCL over xGMI; the own communicator only adds its own stream and the graph cut)
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=store.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                import sys
+                print("[tuber ddp] rank %d: own RCCL communicator unavailable (%s); using the torch.distributed process group"
+                      % (dist.get_rank(), err if err is not None else "failed on another rank"), file=sys.stderr, flush=True)
+                if comm is not None:
+                    comm.close()
+                comm = None
     store.reducer = FlatGradReducer(store, world_size=world, comm=comm)
     return store.reducer
