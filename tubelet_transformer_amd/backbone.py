@@ -24,6 +24,7 @@ from .engine import TnArgs, WgradQueue
 BN_EPS = 1e-3       # ir_CSN_152.py:15
 BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
+BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -330,8 +331,11 @@ class CSNRunner:
         (Forming dx inside the consuming GEMMs instead -- tuber_gemm_nt amode 2 / tuber_gemm_tn G2 -- removes this kernel and
         7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
         not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
-        if apply and BN_BWD_ONE_LAUNCH and R <= self._fa_max and bn.C % 128 == 0:
-            # short partial lists (layer3 / layer4): every workgroup of the apply derives its strip's coefficients itself -- one launch
+        fa = apply and BN_BWD_ONE_LAUNCH and bn.C % 128 == 0
+        if fa and R > self._fa_max and BN_BWD_FA_AFTER_REDUCE:
+            st0, st1, R = self._stat_rows(st0, st1, R, bn.C)       # layer1 / layer2: 64 rows after the first stage -> finalize + apply as one launch
+        if fa and R <= self._fa_max:
+            # short partial lists (layer3 / layer4 directly): every workgroup of the apply derives its strip's coefficients itself -- one launch
             dx = torch.empty(M, bn.C, dtype=BF, device=self.dev)
             lib.call("tuber_bn_bwd_fa", st0, st1, R, bn.C, float(count), bn.gamma, bn.mean, bn.invstd,
                      bn.dgamma if train else None, bn.dbeta if train else None, dz, x, dx, M)
