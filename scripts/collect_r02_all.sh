@@ -1,5 +1,5 @@
-bash scripts/collect_profiles_r02.sh r02_x
-O=gpurun_out/r02_x
+bash scripts/collect_profiles_r02.sh r02_z
+O=gpurun_out/r02_z
 timeout 200 python bench.py --steps 20 --warmup 3 --pretrained-freeze --no-cpu-baseline > $O/bench_freeze.json 2>/dev/null
 timeout 200 python bench.py --steps 20 --warmup 3 --config TubeR_CSN50_AVA21.yaml --no-cpu-baseline > $O/bench_cfg2_csn50_decode.json 2>/dev/null
 timeout 200 python bench.py --steps 20 --warmup 3 --config Tuber_CSN152_JHMDB.yaml --height 288 --width 384 --no-cpu-baseline > $O/bench_cfg5_jhmdb.json 2>/dev/null
