@@ -201,7 +201,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, hw, dataset, batch=2, warm=1, timed=3):
+def cpu_baseline(cfg, hw, dataset, batch=2, warm=2, timed=5):
     """CPU oracle (oracle/tuber_oracle.py: stock PyTorch CPU ops, fp32, identical graph and state dict): full training steps
     (forward, criterion, backward, clip, AdamW) on a batch of the benchmark workload, all host cores: ``warm`` untimed + ``timed``
     timed steps (bounded sample: ~1 minute of CPU work)."""
@@ -236,6 +236,60 @@ def cpu_baseline(cfg, hw, dataset, batch=2, warm=1, timed=3):
                       "fp32, dropout off; %.1f s/step (steps: %s)" % (warm, timed, batch, hw[0], hw[1], dt, " ".join("%.1f" % t for t in times))}
 
 
+def timed_with_input_pipeline(step_fn, args, hw, dev, fence):
+    """the same K steps with the input feed inside the timed region: every batch starts as decoded uint8 frames on the HOST
+    (2 clips x 32 frames at 360x480, what datasets/ava_frame.py:133-152 hands to the transforms), goes through the reference's
+    transform sequence as recorded geometry (resize to IMG_RESHAPE 288x384, flip, crop to the clip size, colour jitter, normalise)
+    and ``ClipBatch.to(device)`` -- H2D of the uint8 frames + tuber_frames_resize + tuber_clip_prepare -- on a side stream, one batch
+    ahead of the step that consumes it.  ``step_fn`` is called with the prepared NestedTensor."""
+    import numpy as np
+    from tubelet_transformer_amd import input_pipeline as P
+    rng = np.random.default_rng(0)
+    T, H0, W0 = 32, 360, 480
+    RH, RW = hw[0] + 32, hw[1] + 44
+    frames = [np.ascontiguousarray(rng.integers(0, 256, (T, H0, W0, 3), dtype=np.uint8)) for _ in range(args.batch)]
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+
+    def prepare(i):
+        clips = []
+        for b, f in enumerate(frames):
+            c = P.FrameClip(f)
+            c.resize((RW, RH))
+            if (i + b) % 2:
+                c._hflip()
+            c._crop(16, 22, hw[0], hw[1])
+            c.jitter = (7, -13, 20)
+            clips.append(c)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nt = P.ClipBatch(clips).to(dev)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        nt.tensors.record_stream(main)
+        nt.mask.record_stream(main)
+        return nt, ev
+
+    nxt = prepare(0)
+    for i in range(2):                       # warm-up (allocator, coefficient tables)
+        nt, ev = nxt
+        main.wait_event(ev)
+        step_fn(nt)
+        nxt = prepare(i + 1)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        nt, ev = nxt
+        main.wait_event(ev)
+        step_fn(nt)
+        nxt = prepare(i + 3)
+    fence()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": round(1e3 * dt / args.steps, 3), "seconds": dt,
+            "feed": "uint8 frames %dx%dx%dx%d on the host -> ClipBatch.to(device) on a side stream (H2D %.1f MB + resize to %dx%d + flip/crop/jitter/"
+                    "normalise/collate), one batch ahead" % (args.batch, T, H0, W0, args.batch * T * H0 * W0 * 3 / 1e6, RH, RW)}
+
+
 def lib_md5():
     """checksum of the HIP library this process loaded -- recorded so that a number can be tied to the build it was measured on"""
     import hashlib
@@ -258,6 +312,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraphs")
+    ap.add_argument("--with-input-pipeline", action="store_true", help="after the headline measurement, time the same steps again with every "
+                    "batch fed as uint8 frames through input_pipeline.ClipBatch.to(device) (H2D + resize + flip/crop/jitter/normalise/collate "
+                    "on a side stream, double-buffered) and report both figures")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -306,8 +363,8 @@ def main():
     targets = synth.synthetic_targets(args.batch, dataset, cfg.CONFIG.DATA.NUM_CLASSES, seed=4321 + rank, device=dev, hw=hw)
     max_norm = cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM
 
-    def eager_step():
-        return train_step(model, criterion, optimizer, clips, targets, max_norm)
+    def eager_step(samples=None):
+        return train_step(model, criterion, optimizer, clips if samples is None else samples, targets, max_norm)
 
     mode = "eager"
     step = eager_step
@@ -318,8 +375,8 @@ def main():
             torch.cuda.synchronize()
             mode = "hipgraph"
 
-            def step():
-                return graphed(clips, targets)
+            def step(samples=None):
+                return graphed(clips if samples is None else samples, targets)
         except Exception as e:      # capture is an optimisation, never a requirement
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr, flush=True)
             torch.cuda.synchronize()
@@ -363,6 +420,21 @@ def main():
         torch.cuda.synchronize()
         lib.set_launch_hook(None)
         timed_steps = min(args.steps, 3)
+    red = getattr(model.engine()[0], "reducer", None)
+    comm_info = None
+    if red is not None:
+        # the gradient exchange as it ran in the timed region + a few measured steps (HIP events around the optimizer stream's wait
+        # for the transport = EXPOSED communication time), for the first multi-GPU run to be diagnosable from its one JSON line
+        red.measure = True
+        for _ in range(min(args.steps, 5)):
+            step()
+        fence()
+        comm_info = red.describe()
+        red.measure = False
+        comm_info["launch"] = mode + (" (graph A | all-reduce | graph A2 | all-reduce | graph B2)" if mode == "hipgraph" and not os.environ.get("TUBER_RCCL_IN_GRAPH") else "")
+    pipe_info = None
+    if args.with_input_pipeline:
+        pipe_info = timed_with_input_pipeline(step, args, hw, dev, fence)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -384,6 +456,8 @@ def main():
                    "lib_md5": lib_md5()},
         "final_loss": round(float(loss.detach()), 4) if loss is not None else None,
         "alg_gflop_per_clip_fwd_bwd": alg_gflop,
+        "tolerance": "bf16 path vs the fp32 oracle: err <= 2x the error of a bf16-rounded execution of the oracle + 4e-3 (logits) / 1e-3 (boxes), "
+                     "caps 5e-2 / 1e-2 (DESIGN.md section 4; tests/test_fullsize_gpu.py at this size)",
         "readme_implied_gflops": round(total_clips / dt * 120.0, 1),
     }
     if rank == 0 and timer is not None:
@@ -427,11 +501,15 @@ def main():
         if headline and not args.pretrained_freeze:
             line["end_to_end"] = {"hbm_frac_of_alg_bytes": round(8.4e9 * total_clips / dt / (HBM_PEAK_GBS * 1e9 * world), 4),
                                   "mfma_frac_of_alg_flops": round(981e9 * total_clips / dt / (MFMA_BF16_PEAK_TFLOPS * 1e12 * world), 4)}
+    if comm_info is not None:
+        line["comm"] = comm_info
+    if pipe_info is not None:
+        pipe_info["clips_per_s"] = round(args.batch * world * args.steps / pipe_info.pop("seconds"), 3)
+        line["input_pipeline"] = pipe_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, hw, dataset, batch=args.batch)
     # RCCL prints its banner through C stdio, which a pipe holds back until exit: tear the communicators down and drain every rank's
     # C buffers first, so that the JSON line is the last line this job writes to stdout.
-    red = getattr(model.engine()[0], "reducer", None)
     if red is not None and red.comm is not None:
         red.comm.close()
     import ctypes

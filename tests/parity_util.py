@@ -20,6 +20,33 @@ class RoundBF(torch.autograd.Function):
         return g
 
 
+class rounded_convs:
+    """context: the oracle's conv3d / linear read bf16-rounded operands and round their result (exact accumulation)"""
+
+    def __enter__(self):
+        from oracle import tuber_oracle as O
+        self.O, self.oc, self.ol = O, O.F.conv3d, O.F.linear
+        oc, ol = self.oc, self.ol
+        O.F.conv3d = lambda x, w, *a, **k: RoundBF.apply(oc(RoundBF.apply(x), RoundBF.apply(w), *a, **k))
+        O.F.linear = lambda x, w, b=None: RoundBF.apply(ol(RoundBF.apply(x), RoundBF.apply(w), b))
+        return self
+
+    def __exit__(self, *exc):
+        self.O.F.conv3d, self.O.F.linear = self.oc, self.ol
+        return False
+
+
+def grad_row(h, a, b):
+    """(cos hip, cos rounded, relerr hip, relerr rounded, norm ratio) of a HIP gradient h and a bf16-rounded-oracle gradient b against
+    the fp32 truth a"""
+    a = a.detach().flatten().double().cpu()
+    h = h.detach().float().flatten().double().cpu()
+    b = b.detach().flatten().double().cpu()
+    na = float(a.norm()) + 1e-30
+    return (float(a @ h / (na * (float(h.norm()) + 1e-30))), float(a @ b / (na * (float(b.norm()) + 1e-30))),
+            float((h - a).norm() / na), float((b - a).norm() / na), float(h.norm() / na))
+
+
 def surrogate(out):
     """smooth loss: fixed random linear functional of every output (no Hungarian discontinuity)."""
     g = torch.Generator().manual_seed(5)

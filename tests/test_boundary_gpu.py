@@ -72,9 +72,9 @@ def test_checkpoint_import_after_engine_drives_the_hip_path(dev, tmp_path):
         ck.load_model(dst, cfg)
 
     # DETR initialisation (transformer.*, bbox_embed.*, first QUERY_NUM rows of query_embed) into a live engine
-    detr = {"model": {"detr." + k: v.detach().cpu().clone() for k, v in src.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
+    detr = {"model": {"module." + k: v.detach().cpu().clone() for k, v in src.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
     qe = torch.randn(100, 256, generator=torch.Generator().manual_seed(1))
-    detr["model"]["detr.query_embed.weight"] = qe
+    detr["model"]["module.query_embed.weight"] = qe
     dpath = str(tmp_path / "detr.pth")
     torch.save(detr, dpath)
     m3, _, _ = build_model(cfg)
@@ -195,3 +195,187 @@ def test_ucf_validation_loop_writes_reference_format_and_scores(dev, tmp_path):
     assert abs(sum(vals[4:]) - 1.0) < 1e-4                                  # softmax over the C classes + no-object
     gvals = [float(v) for v in gt[0].split(" [")[1].split("]")[0].split(",")]
     assert len(gvals) == 6 + 21 and sum(gvals[6:]) == 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's own training script, call for call (train_tuber_ava.py:30-84) -- stock torch.optim.AdamW, MultiStepLR
+# ------------------------------------------------------------------------------------------------------------------------------
+class _Writer:
+    def __init__(self):
+        self.tags = {}
+
+    def add_scalar(self, tag, value, it):
+        self.tags.setdefault(tag, []).append((it, float(value)))
+
+
+def _ava_loader(n_batches, H, W, dev_targets="cpu", boxes_in_last=None):
+    from tubelet_transformer_amd.misc import NestedTensor
+    loader = []
+    for i in range(n_batches):
+        clips = synth.synthetic_clips(2, 32, H, W, seed=30 + i)
+        tg = synth.synthetic_targets(2, "ava", 80, seed=40 + i, device=dev_targets, hw=(H, W))
+        for b, t in enumerate(tg):
+            t["image_id"] = ["vid%d,%04d" % (i, 900 + b), 16]
+            t["size"] = torch.tensor([H, W])
+            n = t["boxes"].shape[0]
+            raw = torch.zeros(n, 6)
+            raw[:, 0] = 2 * i + b
+            raw[:, 1] = 16
+            raw[:, 2:] = torch.tensor([4.0, 6.0, 40.0, 50.0])
+            t["raw_boxes"] = raw
+        loader.append((NestedTensor(clips, torch.zeros(2, H, W, dtype=torch.bool)), tg))
+    return loader
+
+
+def _copy_loader(loader):
+    return [(s, [dict(t) for t in tg]) for s, tg in loader]
+
+
+def test_reference_training_script_sequence_with_stock_adamw(dev, tmp_path, monkeypatch):
+    """deploy_model -> torch.optim.AdamW(param_dicts) -> MultiStepLR -> train_tuber_detection(cfg, model, criterion, loader,
+    optimizer, epoch, max_norm, lr_scheduler, writer) -> save_checkpoint -> validate_tuber_detection, through the reference's import
+    paths.  The stock optimizer is adopted (captured hipGraph step by default): parameters after 3 steps equal the FusedClipAdamW
+    runs (graph and eager) to <= 1e-7 relative, the scheduler bound to the USER's optimizer steers the fused step, the six scalars of
+    video_action_recognition.py:215-220 reach the writer, and optimizer.state_dict() in the checkpoint holds the live moments."""
+    from models.tuber_ava import build_model as ref_build_model
+    from utils.model_utils import deploy_model, save_checkpoint
+    from utils.video_action_recognition import train_tuber_detection, validate_tuber_detection
+    from tubelet_transformer_amd.optim import FusedClipAdamW
+    from tubelet_transformer_amd.training import build_optimizer, train_step
+    monkeypatch.delenv("TUBER_EAGER_STEP", raising=False)
+    H, W = 64, 96
+
+    def fresh():
+        cfg = _cfg("TubeR_CSN152_AVA21.yaml", tmp_path)
+        cfg.DDP_CONFIG.GPU, cfg.DDP_CONFIG.GPU_WORLD_RANK = 0, 0
+        cfg.CONFIG.MODEL.PRETRAIN_TRANSFORMER_DIR = ""
+        model, criterion, postprocessors = ref_build_model(cfg)
+        synth.load_name_hashed(model)
+        model = deploy_model(model, cfg, is_tuber=True)
+        criterion = criterion.cuda()
+        model.engine()[0].manual_seed(123)
+        return cfg, model, criterion, postprocessors
+
+    # --- the script, verbatim -------------------------------------------------------------------------------------------
+    cfg, model, criterion, postprocessors = fresh()
+    param_dicts = [
+        {"params": [p for n, p in model.named_parameters() if "backbone" not in n and "class_embed" not in n and "query_embed" not in n and p.requires_grad]},
+        {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": cfg.CONFIG.TRAIN.LR_BACKBONE},
+        {"params": [p for n, p in model.named_parameters() if "class_embed" in n and p.requires_grad], "lr": cfg.CONFIG.TRAIN.LR},
+        {"params": [p for n, p in model.named_parameters() if "query_embed" in n and p.requires_grad], "lr": cfg.CONFIG.TRAIN.LR},
+    ]
+    optimizer = torch.optim.AdamW(param_dicts, lr=cfg.CONFIG.TRAIN.LR, weight_decay=cfg.CONFIG.TRAIN.W_DECAY)
+    lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[1], gamma=0.1)
+    writer = _Writer()
+    train_loader = _ava_loader(3, H, W)
+    max_norm = cfg.CONFIG.LOSS_COFS.CLIPS_MAX_NORM
+    train_tuber_detection(cfg, model, criterion, _copy_loader(train_loader[:2]), optimizer, 0, max_norm, lr_scheduler, writer)
+    lr_scheduler.step()                                             # epoch boundary: lr x 0.1 on the user's optimizer object
+    train_tuber_detection(cfg, model, criterion, _copy_loader(train_loader[2:]), optimizer, 1, max_norm, lr_scheduler, writer)
+    path = save_checkpoint(cfg, 1, model, 0.0, optimizer, lr_scheduler)
+    mAP = validate_tuber_detection(cfg, model, criterion, postprocessors, _copy_loader(train_loader[:1]), 1, writer)
+    assert 0.0 <= mAP <= 1.0
+    torch.cuda.synchronize()
+    fused = optimizer._tuber_fused
+    assert isinstance(fused, FusedClipAdamW) and fused.param_groups is optimizer.param_groups
+    assert len(model.__dict__["_tuber_graphed"]) == 1                # the captured step was the one that ran
+    assert abs(optimizer.param_groups[0]["lr"] - cfg.CONFIG.TRAIN.LR * 0.1) < 1e-12
+    assert torch.allclose(fused.hyper[:, 0].cpu(), torch.tensor([g["lr"] for g in optimizer.param_groups]))
+    for tag in ("train/class_error", "train/totall_loss", "train/loss_bbox", "train/loss_giou", "train/loss_ce", "train/loss_ce_b"):
+        assert tag in writer.tags and all(v == v for _, v in writer.tags[tag]), tag
+    flat_stock = model.engine()[0].flat.detach().clone()
+    saved = torch.load(path, weights_only=False)
+    st = saved["optimizer"]["state"]
+    assert len(st) == sum(len(g["params"]) for g in optimizer.param_groups)
+    assert all(float(s["step"]) == 3.0 for s in st.values())
+    p0 = optimizer.param_groups[0]["params"][0]
+    assert torch.equal(st[0]["exp_avg"].to(dev), optimizer.state[p0]["exp_avg"]) and float(st[0]["exp_avg"].abs().sum()) > 0
+
+    # --- the same three steps through FusedClipAdamW: captured and eager --------------------------------------------------
+    results = {}
+    for mode in ("graph", "eager"):
+        cfg2, model2, criterion2, _ = fresh()
+        opt2 = build_optimizer(model2, cfg2)
+        sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, milestones=[1], gamma=0.1)
+        g = False if mode == "eager" else None
+        train_tuber_detection(cfg2, model2, criterion2, _copy_loader(train_loader[:2]), opt2, 0, max_norm, sched2, None, graphed=g)
+        sched2.step()
+        train_tuber_detection(cfg2, model2, criterion2, _copy_loader(train_loader[2:]), opt2, 1, max_norm, sched2, None, graphed=g)
+        torch.cuda.synchronize()
+        results[mode] = model2.engine()[0].flat.detach().clone()
+        assert (len(model2.__dict__.get("_tuber_graphed", {})) == 1) == (mode == "graph")
+    for mode, flat in results.items():
+        rel = float((flat - flat_stock).abs().max() / flat_stock.abs().max())
+        assert rel <= 1e-7, (mode, rel)
+
+    # --- resume: optimizer.load_state_dict() on the stock object flows back into the flat moments ------------------------------
+    cfg3, model3, criterion3, _ = fresh()
+    opt3 = torch.optim.AdamW([{"params": list(g["params"])} for g in build_optimizer(model3, cfg3).param_groups], lr=1e-4, weight_decay=1e-4)
+    opt3.load_state_dict(saved["optimizer"])
+    from tubelet_transformer_amd.optim import adopt
+    f3 = adopt(opt3, model3)
+    assert f3.t == 3 and torch.equal(f3.exp_avg, fused.exp_avg) and torch.equal(f3.exp_avg_sq, fused.exp_avg_sq)
+
+    # --- an optimizer that is not AdamW: the reference's literal clip_grad_norm_ + optimizer.step() on the gradient views --------
+    cfg4, model4, criterion4, _ = fresh()
+    sgd = torch.optim.SGD([p for p in model4.parameters() if p.requires_grad], lr=1e-3)
+    w0 = model4.class_fc.weight.detach().clone()
+    loss, _ = train_step(model4, criterion4, sgd, train_loader[0][0].to(dev), [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in train_loader[0][1]], max_norm)
+    assert torch.isfinite(loss) and not torch.equal(w0, model4.class_fc.weight.detach())
+    gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model4.parameters() if p.grad is not None))
+    assert float(gn) <= max_norm * 1.001                             # clipped in place, like clip_grad_norm_
+
+
+def test_weight_import_into_a_live_engine_matches_the_reference_loaders(dev, tmp_path, golden_dir):
+    """tests/golden/weight_import.json (the REFERENCE's build_CSN / load_weights, load_model, load_detr_weights run on the seeded files
+    of tests/weight_files.py) against checkpoint.py writing into a model whose engine -- flat parameter store, bf16 shadow,
+    transposed weights -- already exists and has computed: same bytes in the same tensors (read back from the flat store), same
+    tensors untouched, same requires_grad pattern; and the next forward computes with the imported weights."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import weight_files as WF
+    gold = json.load(open(os.path.join(golden_dir, "weight_import.json")))
+    case = "csn152"
+    g = gold[case + "_mat"]
+    cfg = load_cfg(os.path.join(ROOT, "configuration", g["yaml"]))
+    clips = synth.synthetic_clips(1, 32, 64, 96, seed=8, device=dev)
+
+    def live():
+        m, _, _ = build_model(cfg)
+        synth.load_name_hashed(m, salt=1)
+        m.to(dev)
+        out = _outputs(m, clips)                # the engine exists and has run before anything is imported
+        return m, out, m.engine()[0]
+
+    model, out0, store = live()
+    mat = WF.write_csn_mat(str(tmp_path / "w.mat"), g["backbone"], g["seed"])
+    ck.load_csn_mat(model.backbone.body, mat, g["backbone"])
+    assert model.engine()[0] is store and store.valid()
+    snap = WF.snapshot(model)
+    for k, (c, _) in g["body"].items():
+        assert snap[k][0] == c, k
+    assert {n: bool(p.requires_grad) for n, p in model.named_parameters()} == g["requires_grad"]
+    for n, p in model.named_parameters():       # the state_dict view IS the flat store
+        assert p.data_ptr() == store.flat.data_ptr() + 4 * store.offsets[n], n
+    assert not _same(_outputs(model, clips), out0)
+    twin, _, _ = build_model(cfg)                # a model that had these weights from the start computes the same
+    twin.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    twin.to(dev)
+    assert _same(_outputs(model, clips), _outputs(twin, clips))
+
+    gc = gold[case + "_ckpt"]
+    model, _, store = live()
+    cfg.CONFIG.MODEL.PRETRAINED_PATH = WF.write_tuber_checkpoint(str(tmp_path / "c.pth"), {k: v.cpu() for k, v in model.state_dict().items()}, gc["seed"])
+    before = WF.snapshot(model)
+    ck.load_model(model, cfg)
+    after = WF.snapshot(model)
+    assert {k: v for k, v in after.items() if before[k] != v} == gc["changed"] and store.valid()
+    for prefix in ("module", "detr"):
+        gd = gold["%s_detr_%s" % (case, prefix)]
+        model, _, store = live()
+        path = WF.write_detr_checkpoint(str(tmp_path / ("d_%s.pth" % prefix)), {k: v.cpu() for k, v in model.state_dict().items()}, gd["seed"], prefix)
+        before = WF.snapshot(model)
+        ck.load_detr_weights(model, path, cfg)
+        after = WF.snapshot(model)
+        assert {k: v for k, v in after.items() if before[k] != v} == gd["changed"] and store.valid(), prefix

@@ -258,14 +258,14 @@ def test_checkpoint_roundtrip_with_ddp_prefix(tmp_path):
     ck.load_model(m2, cfg)
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2), k1
-    # DETR initialisation: transformer.*, bbox_embed.*, first QUERY_NUM query rows from a 'detr.'-prefixed file
-    detr = {"model": {"detr." + k: v.clone() for k, v in m1.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
-    detr["model"]["detr.query_embed.weight"] = torch.arange(100 * 256, dtype=torch.float32).view(100, 256)
+    # DETR initialisation: transformer.*, bbox_embed.*, first QUERY_NUM query rows from a DDP-saved (module.-prefixed) file
+    detr = {"model": {"module." + k: v.clone() for k, v in m1.state_dict().items() if k.startswith(("transformer.", "bbox_embed."))}}
+    detr["model"]["module.query_embed.weight"] = torch.arange(100 * 256, dtype=torch.float32).view(100, 256)
     p2 = str(tmp_path / "detr.pth")
     torch.save(detr, p2)
     m3, _, _ = build_model(cfg)
     ck.load_detr_weights(m3, p2, cfg)
-    assert torch.equal(m3.query_embed.weight, detr["model"]["detr.query_embed.weight"][:15])
+    assert torch.equal(m3.query_embed.weight, detr["model"]["module.query_embed.weight"][:15])
     assert torch.equal(m3.transformer.decoder.norm.weight, m1.transformer.decoder.norm.weight)
 
 
@@ -391,3 +391,46 @@ def test_spawn_workers_and_reference_call_forms(tmp_path):
     cfg.DDP_CONFIG.GPU, cfg.DDP_CONFIG.GPU_WORLD_RANK = 0, 0
     spawn_workers(_launch_main, cfg, nprocs=1)
     assert open(str(tmp_path / "rank0.txt")).read().split()[0] == "1"
+
+
+# ---------------------------------------------------------------- N1 pinned against the REFERENCE's own loaders --------
+@pytest.mark.parametrize("case", ["csn152", "csn50"])
+def test_weight_import_matches_the_reference_loaders(golden_dir, tmp_path, case):
+    """tests/golden/weight_import.json holds what the reference's build_CSN / load_weights (ir_CSN_152.py:213-318, ir_CSN_50.py),
+    load_model (utils/model_utils.py:66-95) and load_detr_weights (:10-36) produce from the seeded files of tests/weight_files.py
+    (generated by oracle/gen_weight_import_golden.py with the unmodified reference).  checkpoint.py must write the same bytes into
+    the same tensors, leave the same tensors untouched, and leave the same requires_grad pattern behind."""
+    import weight_files as WF
+    from tubelet_transformer_amd import checkpoint as ck
+    from tubelet_transformer_amd.tuber import build_model
+    gold = json.load(open(os.path.join(golden_dir, "weight_import.json")))
+    g = gold[case + "_mat"]
+    cfg = load_cfg(os.path.join(ROOT, "configuration", g["yaml"]))
+    # Caffe2 .mat through build_model (CONFIG.MODEL.PRETRAINED) -- block offsets, _riv -> running_var, freeze pattern
+    cfg.CONFIG.MODEL.PRETRAINED = True
+    cfg.CONFIG.MODEL.PRETRAIN_BACKBONE_DIR = WF.write_csn_mat(str(tmp_path / "w.mat"), g["backbone"], g["seed"])
+    model, _, _ = build_model(cfg)
+    snap = WF.snapshot(model)
+    for k, (c, rg) in g["body"].items():
+        assert snap[k][0] == c, "%s: bytes differ from what the reference's load_weights wrote" % k
+    assert {n: bool(p.requires_grad) for n, p in model.named_parameters()} == g["requires_grad"]
+    # TubeR checkpoint saved from a DDP model
+    cfg.CONFIG.MODEL.PRETRAINED = False
+    model, _, _ = build_model(cfg)
+    gc = gold[case + "_ckpt"]
+    cfg.CONFIG.MODEL.PRETRAINED_PATH = WF.write_tuber_checkpoint(str(tmp_path / "c.pth"), model.state_dict(), gc["seed"])
+    before = WF.snapshot(model)
+    ck.load_model(model, cfg)
+    after = WF.snapshot(model)
+    assert len(after) == gc["total"]
+    assert {k: v for k, v in after.items() if before[k] != v} == {k: v for k, v in gc["changed"].items()}
+    # DETR initialisation files: 'module.' loads transformer / bbox_embed / sliced query_embed, 'detr.' loads nothing
+    for prefix in ("module", "detr"):
+        gd = gold["%s_detr_%s" % (case, prefix)]
+        model, _, _ = build_model(cfg)
+        path = WF.write_detr_checkpoint(str(tmp_path / ("d_%s.pth" % prefix)), model.state_dict(), gd["seed"], prefix)
+        before = WF.snapshot(model)
+        ck.load_detr_weights(model, path, cfg)
+        after = WF.snapshot(model)
+        assert {k: v for k, v in after.items() if before[k] != v} == gd["changed"], prefix
+        assert (len(gd["changed"]) > 0) == (prefix == "module")

@@ -26,7 +26,7 @@ from tubelet_transformer_amd.tuber import build_model
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# absolute caps (bf16 path, BASELINE.md section 4 / SURVEY.md section 8c) and the yardstick factor
+# the build's stated bf16 tolerance (DESIGN.md section 4): yardstick factor + slack against the bf16-rounded oracle, and absolute caps
 CAP = {"pred_logits": 5e-2, "pred_logits_b": 5e-2, "pred_boxes": 1e-2}
 K_ROUNDED, SLACK = 2.0, {"pred_logits": 4e-3, "pred_logits_b": 4e-3, "pred_boxes": 1e-3}
 
@@ -38,10 +38,10 @@ FULL = {
 }
 
 
-def _build(yaml_name, dev, train=False, dropout=False):
+def _build(yaml_name, dev, train=False, dropout=False, residual_gain=None):
     cfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
     model, crit, post = build_model(cfg)
-    synth.load_name_hashed(model)
+    synth.load_name_hashed(model, residual_gain=residual_gain)
     if not dropout:
         synth.zero_dropout(model)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -239,3 +239,180 @@ def test_full_size_training_step_properties(dev, case):
     torch.cuda.synchronize()
     assert math.isfinite(float(loss)) and not torch.equal(w0, model.class_fc.weight.detach())
     assert bool(torch.isfinite(store.flat).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# backward at REAL depth, falsifiable: (a) the well-conditioned deep fixture
+# ------------------------------------------------------------------------------------------------------------------------------
+RESIDUAL_GAIN = 0.05
+
+
+def test_full_depth_backward_on_the_well_conditioned_fixture(dev):
+    """CSN-152 at 2x3x32x256x340 through the WHOLE model (training-mode BatchNorm, dropout off, smooth surrogate loss) on the
+    identity-dominated fixture (``synth.load_name_hashed(residual_gain=%.2f)``: every bn4.weight scaled): unlike the plain random
+    weights -- where the bf16-rounded oracle itself decorrelates from fp32 in layer1-3 and the yardstick admits almost anything -- the
+    rounded oracle stays within relerr 0.5 of fp32 on (nearly) every tensor here, so ALL 684 tensors are held, with NO waiver, to
+    relerr(hip) <= 2 x relerr(rounded) + 0.05 and norm ratio in (0.5, 2), and cos(hip) >= 0.9 wherever cos(rounded) >= 0.95.  A
+    backward that returned noise of the right magnitude for any tensor (relerr ~1.4) fails.  Real depth = the 1 GB deferred-reduce
+    arena, 8-GEMM grouped launches spanning four bottlenecks, chained reduce entries, join fusion over 42 block boundaries.
+    (Why not cos >= 0.99: a single random-weight bottleneck already costs ~7 %% of gradient accuracy under bf16 rounding -- ReLU-mask
+    flips of pre-activations within one bf16 ulp of zero -- and the join ReLUs add to the residual-stream gradient in quadrature
+    over 50 blocks; DESIGN.md section 4.)""" % RESIDUAL_GAIN
+    B = 2 if host_mem_gb() > 160 else 1
+    cfg, model, _, state = _build("TubeR_CSN152_AVA21.yaml", dev, train=True, residual_gain=RESIDUAL_GAIN)
+    pn = [n for n, _ in model.named_parameters()]
+    clips = synth.synthetic_clips(B, 32, 256, 340, seed=1234)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    det = lambda o: {k: (v.detach() if torch.is_tensor(v) else [{kk: vv.detach() for kk, vv in a.items()} for a in v]) for k, v in o.items()}
+    o32, g32 = run_oracle(cfg, state, clips, train=True, param_names=pn, loss=surrogate)
+    obf, gbf = run_oracle(cfg, state, clips, train=True, rounded=True, param_names=pn, loss=surrogate)
+    o32, obf = det(o32), det(obf)
+    t1 = time.time()
+    store, _ = model.engine()
+    store.zero_grad()
+    out = model(clips.to(dev))
+    surrogate(out).backward()
+    torch.cuda.synchronize()
+    errs = output_errors(out, o32, obf)
+    print("residual_gain %.2f, batch %d, train-mode outputs hip / bf16-rounded oracle vs fp32: %s   [2 oracle fwd+bwd: %.1f s]" % (
+        RESIDUAL_GAIN, B, {k: "%.2e / %.2e" % v for k, v in errs.items()}, t1 - t0))
+    for kind, (eh, eb) in errs.items():
+        assert eh <= 3 * eb + 2e-2, (kind, eh, eb)
+    rows, _ = compare_gradients([(n, p.grad) for n, p in model.named_parameters()], g32, gbf, min_cb=None)
+    report(rows, "CSN-152 %dx3x32x256x340 backward, residual gain %.2f, all tensors" % (B, RESIDUAL_GAIN))
+    groups = {}
+    for ch, cb, eh, eb, nr, n in rows:
+        key = n.split(".")[2] if n.startswith("backbone.body.") else n.split(".")[0]
+        groups.setdefault(key, []).append((eh, eb, ch, cb))
+    for key, v in groups.items():
+        med = lambda i: sorted(x[i] for x in v)[len(v) // 2]
+        print("   %-16s tensors %3d   median relerr hip %.3f / rounded oracle %.3f   median cos hip %.4f / %.4f   min cos hip %.4f / %.4f"
+              % (key, len(v), med(0), med(1), med(2), med(3), min(x[2] for x in v), min(x[3] for x in v)))
+    assert len(rows) >= 620, len(rows)          # of 684; the rest has a numerically zero fp32 gradient (< 1e-5 of the global norm)
+    conditioned = [r for r in rows if r[3] <= 0.5]
+    print("   rounded oracle within relerr 0.5 of fp32: %d of %d tensors; cos >= 0.9: %d; cos >= 0.99: %d" % (
+        len(conditioned), len(rows), sum(1 for r in rows if r[1] >= 0.9), sum(1 for r in rows if r[1] >= 0.99)))
+    assert len(conditioned) >= 0.95 * len(rows), (len(conditioned), len(rows))       # the fixture does what it is for
+    # the yardstick inequality for EVERY tensor; the norm ratio for every tensor the rounded oracle itself resolves (>= 95 % of
+    # them by the assertion above; what is left are gradients that are numerically zero in fp32, e.g. the first decoder layer's
+    # self-attention in-projection, whose queries and keys are identical for every clip)
+    worse = [(n, "cos %.4f/%.4f" % (ch, cb), "relerr %.3f/%.3f" % (eh, eb), "norm %.3f" % nr) for ch, cb, eh, eb, nr, n in rows
+             if eh > 2.0 * eb + 0.05 or (eb <= 0.5 and not (0.5 < nr < 2.0))]
+    assert not worse, "gradients worse than 2x the bf16-rounded oracle (+0.05) or off in norm: %s" % worse[:20]
+    weak = [(n, ch, cb) for ch, cb, eh, eb, nr, n in rows if cb >= 0.95 and ch < 0.9]
+    assert not weak, weak[:10]
+    _check_bn_buffers(cfg, model, state, clips)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# backward at REAL depth, falsifiable: (b) teacher-forced bottlenecks of the random-weight CSN-152 at the BASELINE size
+# ------------------------------------------------------------------------------------------------------------------------------
+def _rows(t):
+    """fp32 NCDHW -> bf16 NDHWC rows [B*T*H*W, C] (the layout of the HIP path)"""
+    return t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).to(torch.bfloat16).contiguous()
+
+
+def _unrows(r, like):
+    B, C, T, H, W = like.shape
+    return r.float().view(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+
+
+def test_teacher_forced_bottleneck_gradients_at_real_depth(dev):
+    """Every one of the 50 bottlenecks of CSN-152 at 2x3x32x256x340 with the random-weight fixture, conditioned independently of
+    depth: the fp32 oracle's autograd supplies each block's input x_i and output gradient dy_i; the HIP path runs the block's forward
+    + backward from (x_i, dy_i) through CSNRunner's ordinary code path (queued / grouped dW launches, deferred reductions, and -- for
+    the multi-block segments -- the conv1-dgrad + join fusion and the 8-GEMM launches spanning four bottlenecks) and must match the
+    oracle's dW / dgamma / dbeta / dx with the bf16-rounded oracle of the SAME segment as the yardstick:
+    relerr(hip) <= 2 x relerr(rounded) + 0.05 (at most 0.5 % of the tensors up to 3 x), norm ratio in (0.5, 2) -- no waiver --,
+    cos >= 0.9 wherever the rounded oracle has >= 0.95.  Reference: models/backbones/ir_CSN_152.py:70-90,142-170."""
+    from oracle import tuber_oracle as O
+    from parity_util import grad_row, rounded_convs
+    B = 2 if host_mem_gb() > 100 else 1
+    cfg, model, _, state = _build("TubeR_CSN152_AVA21.yaml", dev, train=True)
+    store, runner = model.engine()
+    P = "backbone.body"
+    bstate = {k: v for k, v in state.items() if k.startswith(P + ".")}
+    pn = [k for k in bstate if "running" not in k and "num_batches" not in k]
+    clips = synth.synthetic_clips(B, 32, 256, 340, seed=1234)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    # --- fp32 oracle, whole body, capturing (x_i, dy_i, dx_i) of every bottleneck ------------------------------------------------
+    recs = []
+    orig = O.bottleneck
+
+    def capture(st, p, x, stride, tstride, has_ds, train):
+        y = orig(st, p, x, stride, tstride, has_ds, train)
+        rec = {"p": p, "x": x.detach(), "args": (stride, tstride, has_ds)}
+        y.register_hook(lambda g, rec=rec: rec.__setitem__("dy", g.detach().clone()))
+        x.register_hook(lambda g, rec=rec: rec.__setitem__("dx", g.detach().clone()))
+        recs.append(rec)
+        return y
+    st32 = {k: (v.clone().requires_grad_(True) if k in pn else v.clone()) for k, v in bstate.items()}
+    t0 = time.time()
+    O.bottleneck = capture
+    try:
+        feat = O.csn_body(st32, P, clips, "CSN-152", cfg.CONFIG.MODEL.LAST_STRIDE, True)
+        (feat * torch.randn(feat.shape, generator=torch.Generator().manual_seed(5))).sum().backward()
+    finally:
+        O.bottleneck = orig
+    g32 = {k: st32[k].grad for k in pn}
+    del feat
+    assert len(recs) == 50 and all("dy" in r and "dx" in r for r in recs)
+    print("fp32 oracle body fwd+bwd with per-block capture: %.1f s" % (time.time() - t0))
+    # segments: every block alone, then groups (layer1 | layer2 in two fours | layer3 in nine fours | layer4)
+    segs = [(i, i + 1) for i in range(50)] + [(0, 3), (3, 7), (7, 11)] + [(11 + 4 * k, 15 + 4 * k) for k in range(9)] + [(47, 50)]
+    rows, worse, weak = [], [], []
+    store.refresh()
+    t0 = time.time()
+    for lo, hi in segs:
+        names = [k for k in pn if any(k.startswith(recs[i]["p"] + ".") for i in range(lo, hi))]
+        # yardstick: the bf16-rounded oracle, teacher-forced on the same segment
+        stb = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in bstate.items()
+               if any(k.startswith(recs[i]["p"] + ".") for i in range(lo, hi))}
+        xb = recs[lo]["x"].to(torch.bfloat16).float().requires_grad_(True)
+        with rounded_convs():
+            yb = xb
+            for i in range(lo, hi):
+                yb = orig(stb, recs[i]["p"], yb, *recs[i]["args"], True)
+            yb.backward(recs[hi - 1]["dy"].to(torch.bfloat16).float())
+        # HIP: same inputs, CSNRunner's own forward / backward on blocks [lo, hi)
+        x = recs[lo]["x"]
+        store.begin_step(True)
+        store.zero_grad()
+        y, _, saved = runner.run_blocks(_rows(x).to(dev), (x.shape[0], x.shape[2], x.shape[3], x.shape[4]), lo, hi, train=True)
+        dx = runner.backward_blocks(saved, _rows(recs[hi - 1]["dy"]).to(dev))
+        torch.cuda.synchronize()
+        params = dict(model.named_parameters())
+        tag = "block %d" % lo if hi == lo + 1 else "blocks %d-%d" % (lo, hi - 1)
+        items = [(n, params[n].grad, g32[n], stb[n].grad) for n in names] + [(recs[lo]["p"] + ".dx", _unrows(dx.cpu(), x), recs[lo]["dx"], xb.grad)]
+        for n, h, a, b in items:
+            ch, cb, eh, eb, nr = grad_row(h, a, b)
+            rows.append((ch, cb, eh, eb, nr, tag + " " + n))
+            if eh > 2.0 * eb + 0.05 or not (0.5 < nr < 2.0):
+                worse.append((tag, n, "cos %.4f/%.4f" % (ch, cb), "relerr %.3f/%.3f" % (eh, eb), "norm %.3f" % nr))
+            if cb >= 0.95 and ch < 0.9:
+                weak.append((tag, n, ch, cb))
+    print("50 single-block + %d multi-block teacher-forced segments: %.1f s" % (len(segs) - 50, time.time() - t0))
+    rows.sort()
+    report(rows, "CSN-152 %dx3x32x256x340 teacher-forced bottlenecks" % B)
+    for stage, (a, b) in (("layer1", (0, 3)), ("layer2", (3, 11)), ("layer3", (11, 47)), ("layer4", (47, 50))):
+        sel = [r for r in rows if r[5].startswith("block ") and a <= int(r[5].split()[1]) < b]
+        multi = [r for r in rows if r[5].startswith("blocks ") and a <= int(r[5].split()[1].split("-")[0]) < b]
+        med = lambda v, i: sorted(x[i] for x in v)[len(v) // 2]
+        print("   %s: single-block tensors %3d  median relerr hip %.4f / rounded %.4f, min cos hip %.4f | multi-block tensors %3d  median relerr %.4f / %.4f, min cos hip %.4f"
+              % (stage, len(sel), med(sel, 2), med(sel, 3), min(r[0] for r in sel), len(multi), med(multi, 2), med(multi, 3), min(r[0] for r in multi)))
+    single = [r for r in rows if r[5].startswith("block ")]
+    multi = [r for r in rows if r[5].startswith("blocks ")]
+    good = sum(1 for r in single if r[1] >= 0.99)
+    print("   rounded oracle: cos >= 0.99 on %d of %d single-block tensors; min cos over the %d multi-block tensors %.4f"
+          % (good, len(single), len(multi), min(r[1] for r in multi)))
+    # the fixture is well-conditioned (one bottleneck deep / four deep), so the gates below bind for every tensor
+    assert good >= 0.95 * len(single), (good, len(single))
+    assert min(r[1] for r in multi) >= 0.9
+    # The yardstick's BACKWARD is fp32 (only its forward operands are rounded) while the HIP path also stores every gradient tensor as
+    # bf16, so a handful of cancellation-heavy BatchNorm scale gradients sit just outside 2x: at most 0.5 % of the tensors may, and
+    # none beyond 3x (+0.05) or outside the norm window -- noise of the right magnitude (relerr ~1.4) fails either way
+    print("   outside 2x (+0.05): %d of %d tensors: %s" % (len(worse), len(rows), [w[:5] for w in worse[:8]]))
+    assert len(worse) <= 0.005 * len(rows), "teacher-forced gradients worse than 2x the bf16-rounded oracle (+0.05): %s" % worse[:20]
+    assert not [w for w in worse if w[5]], "teacher-forced gradients worse than 3x the bf16-rounded oracle (+0.05) or off in norm: %s" % [w for w in worse if w[5]][:20]
+    assert not weak, weak[:10]

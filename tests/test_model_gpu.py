@@ -1,9 +1,11 @@
 """End-to-end parity of the HIP model against the committed golden vectors (generated from the imported reference)
 and against the CPU oracle run on the GPU box with the same name-hashed weights and seeded inputs.
 
-Stated tolerances for the bf16 path (bf16-autocast noise of the reference itself is 1.3e-3 .. 7.3e-3):
-  eval outputs:  |logits| err <= 5e-2 abs (class / actor logits are O(1..3)), boxes <= 1e-2 abs, AND <= 2x the error of a
-                 bf16-rounded execution of the fp32 oracle on the same fixture (+4e-3 / +1e-3): the numbers per fixture are in
+Stated tolerance of the bf16 path (this build's own statement -- DESIGN.md section 4, README.md, the bench line's ``tolerance``
+field; it REPLACES the 2e-2 / 5e-3 figures BASELINE.md section 4 / SURVEY.md section 8c guessed before any bf16 run existed, which an
+ideally-accumulated bf16 execution of the reference graph does not meet either: 2.0e-2 .. 3.9e-2 on ``pred_logits_b``):
+  eval outputs:  err <= 2x the error of a bf16-ROUNDED execution of the fp32 oracle on the same fixture + slack (4e-3 logits /
+                 1e-3 boxes), AND absolute caps 5e-2 on logits (O(1..3)) / 1e-2 on boxes: the numbers per fixture are in
                  DESIGN.md section 4; the BASELINE-size cases live in tests/test_fullsize_gpu.py
   train step (golden, deep bodies): the Hungarian assignment is discontinuous and training-mode BatchNorm over the
                  few samples of the tiny fixtures amplifies bf16 rounding (a bf16-ROUNDED run of the fp32 oracle itself

@@ -264,7 +264,7 @@ def test_graph_cache_is_bounded_and_keyed_on_frozen_set(dev):
     _freeze_like_load_csn_mat(model)
     n = len(step.graphs)
     step(clips, targets)
-    assert len(step.graphs) <= 2 and (tuple(clips.shape), model.engine()[0].trainable_signature(), True) in step.graphs and n <= 2
+    assert len(step.graphs) <= 2 and (tuple(clips.shape), model.engine()[0].trainable_signature(), True, 16) in step.graphs and n <= 2
     torch.cuda.synchronize()
 
 
@@ -382,3 +382,101 @@ def test_deploy_model_under_a_one_rank_nccl_process_group(tmp_path):
         out.append(line)
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2], out
     assert int(out[1][3]) > 0 and int(out[0][3]) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# world size 2 on ONE GPU (gloo transport, both ranks on cuda:0): the reduced flat gradient buffer must equal the mean of the two
+# ranks' single-GPU gradients -- on the hook-driven eager path (incl. the pool-decoder window of the 'decode' configs, whose deferred
+# second-stage sums must land BEFORE the window is handed to the transport) and on the cut-graph path
+# ------------------------------------------------------------------------------------------------------------------------------
+_WORLD2_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+root, port, rank, mode, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+sys.path.insert(0, root)
+from tubelet_transformer_amd import synth
+from tubelet_transformer_amd.config import load_cfg
+from tubelet_transformer_amd.ddp import attach_reducer, broadcast_parameters
+from tubelet_transformer_amd.training import GraphedTrainStep, build_optimizer
+from tubelet_transformer_amd.tuber import build_model
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+cfg = load_cfg(os.path.join(root, "configuration", "TubeR_CSN50_AVA21.yaml"))      # 'decode': pool decoder behind the body
+cfg.CONFIG.MODEL.BACKBONE_NAME = "CSN-TEST"
+model, crit, _ = build_model(cfg)
+synth.load_name_hashed(model)
+model.to(dev).train(); crit.to(dev).train()
+store, _ = model.engine()
+
+def grads(reduced, graph):
+    store.manual_seed(99)
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=3 + rank, device=dev)
+    targets = synth.synthetic_targets(2, "ava", 80, seed=5 + rank, device=dev, hw=(64, 96))
+    red = store.reducer if reduced else None
+    keep, store.reducer = store.reducer, red
+    try:
+        if graph:
+            opt = build_optimizer(model, cfg)
+            for g in opt.param_groups:
+                g["lr"] = 0.0; g["weight_decay"] = 0.0          # the captured step includes AdamW: keep the parameters where they are
+            flat0 = store.flat.clone()
+            step = GraphedTrainStep(model, crit, opt, 0.1)
+            step(clips, targets)
+            torch.cuda.synchronize()
+            assert (next(iter(step.graphs.values())).A2 is not None) == reduced
+            store.flat.copy_(flat0)
+        else:
+            out_ = model(clips)
+            ld = crit(out_, targets)
+            loss = crit.weighted_total(ld, crit.weight_dict)
+            store.zero_grad()
+            if red is not None:
+                red.begin()
+            loss.backward()
+            if red is not None:
+                red.finish()
+        torch.cuda.synchronize()
+        return store.gflat.detach().clone()
+    finally:
+        store.reducer = keep
+
+local = grads(False, mode == "graph")
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+dist.init_process_group("gloo", rank=rank, world_size=2)
+broadcast_parameters(store)
+red = attach_reducer(store)
+assert red is not None and red.comm is None and red.world == 2
+got = grads(True, mode == "graph")
+both = [torch.zeros_like(local).cpu() for _ in range(2)]
+dist.all_gather(both, local.cpu())
+want = (both[0] + both[1]) * 0.5
+torch.save({"got": got.cpu(), "want": want, "issued": red.issued, "trainable": sum(b - a for a, b in store.trainable_ranges()),
+            "names": store.names, "offsets": [store.offsets[n] for n in store.names]}, out + ".%d" % rank)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_world2_reduced_gradients_equal_the_mean_of_the_ranks(tmp_path, dev, mode):
+    import subprocess
+    import sys
+    script = str(tmp_path / "w2.py")
+    open(script, "w").write(_WORLD2_WORKER)
+    port = str(29700 + os.getpid() % 200 + (0 if mode == "eager" else 1))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TUBER_SHARE_GPU="1")
+    for k in ("TUBER_RCCL_IN_GRAPH", "TUBER_DDP_BF16", "TUBER_FORCE_DDP", "TUBER_NO_SPLIT_GRAPH"):
+        env.pop(k, None)
+    out = str(tmp_path / "res")
+    procs = [subprocess.Popen([sys.executable, script, ROOT, port, str(r), mode, out], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    for r in range(2):
+        res = torch.load(out + ".%d" % r)
+        got, want = res["got"], res["want"]
+        assert res["issued"] == res["trainable"], (res["issued"], res["trainable"])      # every trainable window sent exactly once
+        bad = []
+        for n, o, e in zip(res["names"], res["offsets"], res["offsets"][1:] + [got.numel()]):
+            if not torch.equal(got[o:e], want[o:e]):
+                bad.append((n, float((got[o:e] - want[o:e]).abs().max()), float(want[o:e].abs().max())))
+        assert not bad, "rank %d: %d tensors differ from the mean of the ranks, e.g. %s" % (r, len(bad), bad[:6])

@@ -25,6 +25,7 @@ BN_EPS = 1e-3       # ir_CSN_152.py:15
 BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
+LATE_WGRAD = not os.environ.get("TUBER_NO_LATE_WGRAD")      # A/B switch: layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward (single GPU)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -242,9 +243,16 @@ class CSNRunner:
         x = torch.empty(B * T * Hp * Wp, 64, dtype=BF, device=dev)
         arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
         lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
-        saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": []}
-        Ti, Hi, Wi = T, Hp, Wp
-        for d in self.blocks:
+        saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": [], "lo": 0}
+        x, (Ti, Hi, Wi) = self._forward_blocks(x, B, (T, Hp, Wp), 0, len(self.blocks), train, saved["blocks"])
+        feat = x.view(B, Ti, Hi, Wi, 2048)
+        return feat, saved
+
+    def _forward_blocks(self, x, B, geom, lo, hi, train, out_saved):
+        """bottlenecks [lo, hi) on x = bf16 rows [B*Ti*Hi*Wi, cin] (NDHWC); appends the saved-for-backward tuples to ``out_saved``"""
+        dev = self.dev
+        Ti, Hi, Wi = geom
+        for d in self.blocks[lo:hi]:
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
@@ -279,11 +287,30 @@ class CSNRunner:
             else:
                 lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, x, None, None, y, Mout, 4 * P)
             if train:
-                saved["blocks"].append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq)))
+                out_saved.append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq)))
             x = y
             Ti, Hi, Wi = To, Hq, Wq
-        feat = x.view(B, Ti, Hi, Wi, 2048)
-        return feat, saved
+        return x, (Ti, Hi, Wi)
+
+    # -- teacher-forced segments (tests: every bottleneck of the real-depth body in isolation, on the oracle's activations) ----------
+    def run_blocks(self, x, geom, lo, hi, train=True):
+        """bottlenecks [lo, hi) alone: x = bf16 rows [B*Ti*Hi*Wi, cin] of block ``lo``'s input, geom = (B, Ti, Hi, Wi).
+        Returns (y rows of block hi-1, (To, Ho, Wo), saved) -- ``saved`` feeds ``backward_blocks``."""
+        B, Ti, Hi, Wi = geom
+        saved = {"blocks": [], "lo": lo, "B": B}
+        y, g = self._forward_blocks(x.contiguous(), B, (Ti, Hi, Wi), lo, hi, train, saved["blocks"])
+        return y, g, saved
+
+    def backward_blocks(self, saved, dy, need_dx=True):
+        """backward of a ``run_blocks`` segment through the SAME code path as the full body (queued / grouped weight gradients, join
+        fusion inside the segment, deferred second-stage reductions -- flushed here): parameter gradients are accumulated into the
+        flat gradient buffer; returns the gradient rows of the segment's input."""
+        lo = saved["lo"]
+        plans, _, _ = self.trainable_plan()
+        dx = self._backward_blocks(saved["blocks"], lo, dy.contiguous(), saved["B"], lo, lo + len(saved["blocks"]), plans, need_dx, None)
+        self.flush_wgrads()
+        self.store.defer.flush()
+        return dx
 
     # -- trainability (requires_grad) ---------------------------------------------------------------------
     # The reference freezes by ``requires_grad = False`` (pretrained recipe: stem + layer1 + layer2, ir_CSN_152.py:251-254,301-303;
@@ -369,26 +396,45 @@ class CSNRunner:
     def flush_wgrads(self):
         self.store.wq.flush()
 
-    def backward(self, saved, dfeat):
-        """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients of the TRAINABLE tensors are
-        accumulated into the ParamStore's flat gradient buffer; the chain stops at the lowest block with a trainable tensor."""
+    def _fork_late(self):
+        """launch the parked layer3 / layer4 leaf work on the side stream, behind everything issued so far"""
+        if not self.store.wq.held:
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self._late_keep = self.store.wq.flush_held()
+
+    def _join_late(self):
+        """the side stream's work is ordered before whatever follows on the current stream (deferred reductions, optimizer)"""
+        if getattr(self, "_late_keep", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._late_keep = None
+
+    def _backward_blocks(self, sblocks, base, dy, B, lowest, top, plans, dx_below, red):
+        """bottlenecks [lowest, top) in reverse; ``sblocks[i - base]`` holds block i's saved tensors; ``dx_below``: the gradient of
+        block ``lowest``'s input is wanted (something trainable, or a caller, sits below it).  Returns that gradient (or None)."""
         dev = self.dev
-        dy = dfeat
-        B = saved["stem"][4][0]
-        red = getattr(self.store, "reducer", None)
-        plans, stem_plan, lowest = self.trainable_plan()
-        if red is not None:           # everything behind the body (transformer, heads, pool decoder) is final
-            red.notify(self.body_end, force=True)
-        nblk = len(self.blocks)
         pre = None          # (dz, sum-dz rows, sum-dz*c4 rows, R) of this block's join backward, produced by the block above (tuber_gemm_nt_join)
-        for bi in range(nblk - 1, lowest - 1, -1):
-            d, sv, f = self.blocks[bi], saved["blocks"][bi], plans[bi]
+        wq = self.store.wq
+        # Late mode (single GPU, whole body in one call): the weight gradients of layer3 / layer4 -- grouped dW GEMMs, depthwise
+        # weight gradients: a quarter of layer3's backward timeline, feeding nothing until the optimizer -- are parked while the
+        # latency-bound data-gradient chain of those stages runs, and launched on a side stream at the layer3 -> layer2 boundary,
+        # where they overlap the bandwidth-bound layer2 / layer1 / stem backward (ONE fork and ONE join per step; the per-block
+        # forks measured in rounds 1-2 cost more than they hid).  With a reducer (N > 1) that window belongs to the all-reduce.
+        late = (LATE_WGRAD and red is None and wq.enabled and self.store.defer.enabled and lowest < top and self.blocks[lowest]["stage"] <= 2
+                and self.blocks[top - 1]["stage"] >= 3 and getattr(self, "split_hook", None) is None)
+        for bi in range(top - 1, lowest - 1, -1):
+            d, sv, f = self.blocks[bi], sblocks[bi - base], plans[bi]
+            wq.hold = late and d["stage"] >= 3
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             C4 = 4 * P
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
-            need_dx = stem_plan["any"] or bi > lowest
+            need_dx = dx_below or bi > lowest
             # how deep the chain inside this block has to go: 7 = input gradient, 6 = conv1 weight, 5 = bn1, 4 = conv3 weight,
             # 3 = bn3, 2 = conv4 weight, 1 = bn4 / shortcut only
             depth = 7 if need_dx else (6 if f["w1"] else 5 if f["bn1"] else 4 if f["w3"] else 3 if f["bn3"] else 2 if f["w4"] else 1)
@@ -423,14 +469,21 @@ class CSNRunner:
             if f["w3"]:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
-                if tile:
-                    lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B, Ti, Hi, Wi, P)
+
+                def dw_wgrad(dc3=dc3, c1=c1, b1=b1, part=part, acc=acc, d=d, nb=nb, tile=tile, geo=(B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)):
+                    B_, Ti_, Hi_, Wi_, To_, Hq_, Wq_, P_, st_, ss_ = geo
+                    if tile:
+                        lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B_, Ti_, Hi_, Wi_, P_)
+                    else:
+                        lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B_, Ti_, Hi_, Wi_,
+                                 To_, Hq_, Wq_, P_, st_, ss_)
+                    if acc == 2:
+                        g3 = d["g3"]
+                        self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P_, 27 * P_, nb, 1, P_)
+                if self.store.wq.hold and acc == 2:
+                    self.store.wq.hold_call(dw_wgrad, (dc3, c1))      # leaf work: parked with the held weight-gradient GEMMs
                 else:
-                    lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B, Ti, Hi, Wi,
-                             To, Hq, Wq, P, st, ss)
-                if acc == 2:
-                    g3 = d["g3"]
-                    self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
+                    dw_wgrad()
             dc1 = None
             if depth >= 5:
                 R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
@@ -459,9 +512,9 @@ class CSNRunner:
                 # The input gradient dx IS the gradient of the block below's output y (= this block's x).  When that block is an
                 # identity block and dx is complete after this GEMM, its join backward (dz = dx * [y > 0] + the bn4 statistics) runs
                 # as the GEMM's epilogue: dx never reaches HBM and the block_out_bwd launch of the next iteration is gone.
-                fuse = JOIN_FUSION and bi - 1 >= 0 and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
+                fuse = JOIN_FUSION and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
                 if fuse:
-                    c4l = saved["blocks"][bi - 1][3]
+                    c4l = sblocks[bi - 1 - base][3]
                     Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
@@ -477,20 +530,40 @@ class CSNRunner:
                     dy = dx
             # layer1 / layer2 weight gradients are long GEMMs: launched per bottleneck (their operands are 45-180 MB each);
             # layer3 / layer4 ones are short: up to 8 (four bottlenecks) share a launch
-            if d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
+            if late and d["first"] and d["stage"] == 3:
+                wq.hold = False
+                self.store.defer.flush()         # what is registered so far (transformer / head partials) is reduced on this stream;
+                self._fork_late()                # the parked work registers ITS partials now: reduced by the final flush, behind the join
+            elif d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
                 self.flush_wgrads()
             if red is not None:
                 self.store.defer.flush()         # the slice handed to RCCL must include the deferred second-stage reductions
                 red.notify(d["off0"])
             hook = getattr(self, "split_hook", None)
-            if d["first"] and d["stage"] == 3:
+            if d["first"] and d["stage"] == 3 and not late:
                 self.store.defer.flush()         # always here, so eager warm-up and a split capture build the same reduce tables
             if hook is not None and d["first"] and d["stage"] == 3 and need_dx:
                 # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
                 # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem
                 hook(d["off0"])
+        return dy
+
+    def backward(self, saved, dfeat):
+        """dfeat bf16 [B*T'*h*w, 2048] (gradient of the returned features).  Parameter gradients of the TRAINABLE tensors are
+        accumulated into the ParamStore's flat gradient buffer; the chain stops at the lowest block with a trainable tensor."""
+        dev = self.dev
+        dy = dfeat
+        B = saved["stem"][4][0]
+        red = getattr(self.store, "reducer", None)
+        plans, stem_plan, lowest = self.trainable_plan()
+        if red is not None:           # everything behind the body (pool decoder of the 'decode' configs) is final ...
+            self.store.defer.flush()  # ... once its deferred second-stage sums (LayerNorm / bias / dW partials) have landed
+            red.notify(self.body_end, force=True)
+        nblk = len(self.blocks)
+        dy = self._backward_blocks(saved["blocks"], saved.get("lo", 0), dy, B, lowest, nblk, plans, stem_plan["any"], red)
         self.flush_wgrads()
         if not stem_plan["any"]:
+            self._join_late()
             return
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient (implicit GEMM over the clip)
         clips, _, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
@@ -505,3 +578,4 @@ class CSNRunner:
             H, W = clips.shape[-2:]
             nwg = lib.query("tuber_stem_conv_wgrad_blocks", B, T, H, W)
             lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
+        self._join_late()

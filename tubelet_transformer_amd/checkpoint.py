@@ -67,22 +67,26 @@ def load_model(model, cfg, load_fc=True):
 
 def load_detr_weights(model, pretrain_dir, cfg):
     """utils/model_utils.py:10-36: initialise ``transformer.*``, ``bbox_embed.*`` and the first QUERY_NUM rows of
-    ``query_embed.*`` from a DETR checkpoint whose keys carry one leading component (``module.`` / ``detr.``)."""
+    ``query_embed.*`` from a DETR checkpoint.  The reference selects entries by their SECOND dotted component (``k.split('.')[1]``)
+    and then keeps only keys its DistributedDataParallel-wrapped model has (``k in model_dict``, i.e. ``module.<name>``); this
+    build's model is the unwrapped equivalent, so an entry loads iff its key is ``module.<name>`` with ``<name>`` a tensor of the
+    model -- a file with any other leading component (``detr.``) matches nothing there and loads nothing here
+    (pinned against the reference's own loader: oracle/gen_weight_import_golden.py -> tests/golden/weight_import.json)."""
     ckpt = torch.load(pretrain_dir, map_location="cpu", weights_only=False)
     M = cfg.CONFIG.MODEL
     qsize = M.QUERY_NUM if M.SINGLE_FRAME else M.QUERY_NUM * (M.TEMP_LEN // M.DS_RATE)
-    picked = {}
+    picked, foreign = {}, []
     for k, v in ckpt["model"].items():
         parts = k.split(".")
-        if len(parts) < 2:
+        if len(parts) < 2 or parts[1] not in ("transformer", "bbox_embed", "query_embed"):
             continue
-        rest = ".".join(parts[1:])
-        if parts[1] in ("transformer", "bbox_embed"):
-            picked[rest] = v
-        elif parts[1] == "query_embed":
-            picked[rest] = v[:qsize]
+        if parts[0] != "module":
+            foreign.append(k)
+            continue
+        picked[".".join(parts[1:])] = v[:qsize] if parts[1] == "query_embed" else v
     used, unused, _ = _copy_into(model, picked, what="detr init")
-    print("detr unused model layers:", unused)
+    print("detr unused model layers:", unused + foreign)
+    print("load pretrain success")
     return model
 
 

@@ -10,12 +10,17 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #define TUBER_OK 0
 #define TUBER_EINVAL (-1)
 #define TUBER_ENOLIB (-2)
+#define TUBER_ETIMEDOUT (-3)
 
 namespace {
 
@@ -30,6 +35,8 @@ struct Api {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
+    int (*CommUserRank)(Comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -74,6 +81,8 @@ int load_api() {
         SYM(GetUniqueId, "ncclGetUniqueId")
         SYM(CommInitRank, "ncclCommInitRank")
         SYM(CommDestroy, "ncclCommDestroy")
+        SYM(CommCount, "ncclCommCount")
+        SYM(CommUserRank, "ncclCommUserRank")
         SYM(AllReduce, "ncclAllReduce")
         SYM(GroupStart, "ncclGroupStart")
         SYM(GroupEnd, "ncclGroupEnd")
@@ -127,6 +136,63 @@ int tuber_comm_init(const void* id128, int nranks, int rank, int device, void** 
     const int rc = g_api.CommInitRank(&c, nranks, id, rank);
     if (rc != 0) return fail("ncclCommInitRank", rc);
     *comm_out = c;
+    return TUBER_OK;
+}
+
+// tuber_comm_init with a deadline.  ncclCommInitRank is itself a collective: a rank that never arrives (died before it, no
+// librccl, wrong device) would block every other rank forever.  The bootstrap runs on a helper thread; when it has not returned
+// after timeout_ms the call fails with TUBER_ETIMEDOUT and a message naming the rank -- the caller can then fall back to another
+// transport or abort the job with a readable error instead of a hang.  (The helper thread stays parked inside RCCL in that case;
+// a process that saw a timeout is expected to give up on this communicator.)  timeout_ms <= 0: plain tuber_comm_init.
+int tuber_comm_init_timeout(const void* id128, int nranks, int rank, int device, int timeout_ms, void** comm_out) {
+    if (timeout_ms <= 0) return tuber_comm_init(id128, nranks, rank, device, comm_out);
+    if (!id128 || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    struct State {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = 0;
+        void* comm = nullptr;
+        char id[128];
+    };
+    auto st = std::make_shared<State>();
+    memcpy(st->id, id128, sizeof st->id);
+    std::thread([st, nranks, rank, device] {
+        void* c = nullptr;
+        const int rc = tuber_comm_init(st->id, nranks, rank, device, &c);
+        std::lock_guard<std::mutex> l(st->mu);
+        st->rc = rc;
+        st->comm = c;
+        st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> l(st->mu);
+    if (!st->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return st->done; })) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "ncclCommInitRank: rank %d of %d (device %d) still waiting for its peers after %d ms -- a rank is missing or "
+                 "cannot reach the rendez-vous", rank, nranks, device, timeout_ms);
+        set_err(buf);
+        return TUBER_ETIMEDOUT;
+    }
+    if (st->rc != 0) return st->rc;
+    hipError_t e = hipSetDevice(device);      // the bootstrap ran on another thread: bind the caller's thread too
+    if (e != hipSuccess) { set_err(std::string("hipSetDevice: ") + hipGetErrorString(e)); return (int)e; }
+    *comm_out = st->comm;
+    return TUBER_OK;
+}
+
+// ranks RCCL itself reports for this communicator (ncclCommCount) and this process's rank in it (ncclCommUserRank): what the first
+// multi-GPU run prints, so "8 processes, each alone in a 1-rank communicator" cannot pass for data parallelism.
+int tuber_comm_count(void* comm, int* count_out, int* rank_out) {
+    if (!comm || !count_out) return TUBER_EINVAL;
+    if (load_api() != TUBER_OK) return TUBER_ENOLIB;
+    int rc = g_api.CommCount((Comm)comm, count_out);
+    if (rc != 0) return fail("ncclCommCount", rc);
+    if (rank_out) {
+        rc = g_api.CommUserRank((Comm)comm, rank_out);
+        if (rc != 0) return fail("ncclCommUserRank", rc);
+    }
     return TUBER_OK;
 }
 

@@ -46,6 +46,10 @@ DOC = {
                                 "gradient buffer with no bucket copies; stream-ordered, capturable into a hipGraph.",
     "tuber_comm_allreduce_sum_multi": "the same for n windows (HOST arrays ptrs[n], counts[n]) as ONE RCCL group.",
     "tuber_comm_destroy": "ncclCommDestroy.",
+    "tuber_comm_init_timeout": "tuber_comm_init with a deadline: the bootstrap (a collective) runs on a helper thread and the call returns -3 with a message naming "
+                               "the waiting rank when its peers have not arrived after timeout_ms -- a dead rank fails the job loudly instead of hanging it "
+                               "(what torch.distributed's process-group timeout does for the reference, pipelines/launch.py:44-49). timeout_ms <= 0: no deadline.",
+    "tuber_comm_count": "ncclCommCount / ncclCommUserRank of the communicator: the world size and rank RCCL itself sees (rank_out may be NULL).",
     "tuber_cast_bf16_f32_scale": "dst = float(src) * scale: expands a bf16-compressed, all-reduced gradient window back into the fp32 gradient buffer and averages it in the same pass.",
     "tuber_frames_resize": "PIL.Image.resize((nw, nh)) of every decoded frame (datasets/ava_frame.py:146-150; jhmdb_frame.py alike): Pillow's 8-bit two-pass "
                            "fixed-point bicubic (libImaging/Resample.c), packed RGB uint8 [nimg][H][W][3] -> [nimg][Ho][Wo][3], bit-exact.",

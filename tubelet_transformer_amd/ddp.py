@@ -64,6 +64,7 @@ class RcclComm:
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank, self.world = rank, world
         v = self.lib.tuber_comm_version()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         if v < 0:
             raise RuntimeError("RCCL unavailable: %s" % self.lib.tuber_comm_last_error().decode())
         self.version = v
@@ -75,9 +76,15 @@ class RcclComm:
             dist.broadcast_object_list(box, src=0)
             uid = ctypes.create_string_buffer(box[0], 128)
         comm = ctypes.c_void_p()
-        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self._check(self.lib.tuber_comm_init(ctypes.addressof(uid), world, rank, idx, ctypes.addressof(comm)), "tuber_comm_init")
+        # deadline on the bootstrap (TUBER_RCCL_INIT_TIMEOUT_S, default 120 s; 0 = none): a missing rank is an error message, not a hang
+        timeout_ms = int(float(os.environ.get("TUBER_RCCL_INIT_TIMEOUT_S", "120")) * 1000) if world > 1 else 0
+        self._check(self.lib.tuber_comm_init_timeout(ctypes.addressof(uid), world, rank, idx, timeout_ms, ctypes.addressof(comm)), "tuber_comm_init")
         self.comm = comm.value
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self.lib.tuber_comm_count(self.comm, ctypes.addressof(n), ctypes.addressof(r)), "tuber_comm_count")
+        self.ranks_seen, self.rank_seen = n.value, r.value          # what RCCL itself reports (bench.py's `comm` object)
+        if (self.ranks_seen, self.rank_seen) != (world, rank):
+            raise RuntimeError("RCCL communicator has %d ranks (this one is %d); expected %d / %d" % (n.value, r.value, world, rank))
         self.stream = torch.cuda.Stream(device=self.device)
 
     def _check(self, rc, what):
@@ -108,6 +115,9 @@ class FlatGradReducer:
         self._joined = True
         self.handles = []
         self.issued = 0                       # elements handed to the transport since begin() (tests / logging)
+        self.windows = 0                      # all-reduce calls since begin()
+        self.measure = False                  # bench.py: time how long the optimizer's stream stalls on the transport (HIP events)
+        self.exposed = []                     # [(event before the wait, event after it)] of the measured steps
         self.done_from = store.total          # everything at offsets >= done_from has been handed to the transport
         self.late = []                        # [(begin, end)] windows that must wait for the end of backward
         for n in store.names:
@@ -121,6 +131,7 @@ class FlatGradReducer:
     def begin(self):
         self.handles = []
         self.issued = 0
+        self.windows = 0
         self.done_from = self.store.total
         self.ranges = trainable_ranges(self.store)       # windows of frozen parameters hold no gradient: never sent
         self._joined = True
@@ -138,6 +149,7 @@ class FlatGradReducer:
             for a, b in wins:
                 self.handles.append(dist.all_reduce(st.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
                 self.issued += b - a
+                self.windows += 1
             return
         from . import lib
         cs = self.comm.stream
@@ -160,6 +172,7 @@ class FlatGradReducer:
                     if self.world > 1:
                         lib.call("tuber_scale_f32", base + 4 * a, n, None, inv)
                 self.issued += n
+                self.windows += 1
 
     def _reduce_excluding_late(self, lo, hi):
         cur = lo
@@ -188,7 +201,16 @@ class FlatGradReducer:
                 self.reduce(a, b)
         if self.comm is not None:
             if not self._joined:
-                torch.cuda.current_stream().wait_stream(self.comm.stream)
+                cur = torch.cuda.current_stream()
+                timed = self.measure and not torch.cuda.is_current_stream_capturing()
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                cur.wait_stream(self.comm.stream)
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(cur)
+                    self.exposed.append((e0, e1))
                 self._joined = True
             return
         for h in self.handles:
@@ -203,6 +225,22 @@ class FlatGradReducer:
             else:
                 for a, b in self.ranges:
                     st.gflat[a:b].mul_(1.0 / self.world)
+
+
+    def describe(self):
+        """what bench.py prints as its ``comm`` object: who carries the gradients, how much, in how many pieces, and how long the
+        optimizer's stream actually waited for it (mean over the measured steps; None when nothing was measured)."""
+        exposed = None
+        if self.exposed:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self.exposed]
+            exposed = sum(ms) / len(ms)
+        bpe = 2 if self.compress else 4
+        return {"transport": "own RCCL communicator (csrc/collective.cpp)" if self.comm is not None else "torch.distributed process group (%s)" % (dist.get_backend() if dist.is_initialized() else "none"),
+                "world": self.world, "ranks_seen_by_rccl": getattr(self.comm, "ranks_seen", None) if self.comm is not None else None,
+                "rccl_version": getattr(self.comm, "version", None) if self.comm is not None else None,
+                "bf16_compressed": bool(self.compress), "windows_per_step": self.windows, "bytes_per_step": self.issued * bpe,
+                "exposed_ms": exposed}
 
 
 def broadcast_parameters(store, src=0):
@@ -225,24 +263,43 @@ def attach_reducer(store, force=False):
     comm = None
     own = store.device.type == "cuda" and (not ddp or dist.get_backend() == "nccl" or os.environ.get("TUBER_OWN_RCCL"))
     if own and not os.environ.get("TUBER_NO_OWN_RCCL"):
+        def agree(ok):
+            """MIN over the ranks of a local yes / no (every rank calls this the same number of times, whatever failed locally)"""
+            if world <= 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=store.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag) == 1
+
+        # ncclCommInitRank is itself a collective: agree that EVERY rank can load librccl and owns a usable device BEFORE anyone enters
+        # it -- a rank that failed locally would otherwise leave the others blocked inside the bootstrap (which also has a deadline)
         err = None
         try:
-            comm = RcclComm(store.device)
+            from . import lib
+            if lib.load().tuber_comm_version() < 0:
+                raise RuntimeError(lib.load().tuber_comm_last_error().decode())
+            torch.cuda.set_device(store.device)
         except Exception as e:                      # noqa: BLE001 -- reported below, on every rank
-            if world <= 1:
-                raise
             err = e
-        if world > 1:
-            # all ranks must end up on the SAME transport: if the directly bound communicator failed anywhere, everybody takes the
-            # process group's (both are RCCL over xGMI; the own communicator only adds its own stream and the graph cut)
-            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=store.device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok) == 0:
-                import sys
-                print("[tuber ddp] rank %d: own RCCL communicator unavailable (%s); using the torch.distributed process group"
-                      % (dist.get_rank(), err if err is not None else "failed on another rank"), file=sys.stderr, flush=True)
-                if comm is not None:
-                    comm.close()
-                comm = None
+        if world <= 1 and err is not None:
+            raise err
+        ready = agree(err is None)
+        if ready:
+            try:
+                comm = RcclComm(store.device)
+            except Exception as e:                  # noqa: BLE001
+                if world <= 1:
+                    raise
+                err = e
+            # all ranks must end up on the SAME transport: if the directly bound communicator failed anywhere (e.g. the bootstrap
+            # deadline), everybody takes the process group's (both are RCCL over xGMI; the own one adds its own stream + the graph cut)
+            ready = agree(err is None)
+        if not ready:
+            import sys
+            print("[tuber ddp] rank %d: own RCCL communicator unavailable (%s); using the torch.distributed process group"
+                  % (dist.get_rank() if ddp else 0, err if err is not None else "failed on another rank"), file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm = None
     store.reducer = FlatGradReducer(store, world_size=world, comm=comm)
     return store.reducer

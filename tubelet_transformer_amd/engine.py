@@ -42,6 +42,7 @@ class WgradQueue:
 
     def __init__(self, store):
         self.store, self.q = store, []
+        self.held, self.hold = [], False     # late mode (backbone.py): layer3 / layer4 leaf work parked until the fork onto the side stream
         self.enabled = not os.environ.get("TUBER_NO_WGRAD_GROUPS")        # A/B switch: one tuber_gemm_tn launch per weight gradient
         # (measured and rejected: running the grouped launches on a second HIP stream next to the data-gradient chain -- ~35 fork /
         #  join points per step inside the hipGraph cost +1.9 ms/step, 18.65 -> 20.53: cross-queue edges serialise the replay)
@@ -56,9 +57,34 @@ class WgradQueue:
 
     def add(self, args, keep, defers):
         """args: TnArgs; keep: tensors that must outlive the launch; defers: DeferredReduce.add argument tuples registered at flush"""
+        if self.hold:
+            self.held.append((args, keep, defers))
+            return
         self.q.append((args, keep, defers))
         if len(self.q) >= self.max:
             self.flush()
+
+    def hold_call(self, fn, keep):
+        """late mode: any other leaf launch (depthwise weight gradient) parked next to the held GEMMs; ``fn()`` launches it"""
+        self.held.append((fn, keep, None))
+
+    def flush_held(self):
+        """launch everything parked by ``hold`` on the CURRENT stream (the caller has switched to the side stream): GEMMs in groups of
+        ``max``, other leaf launches one by one.  Returns the parked operand references -- the caller keeps them until the side
+        stream has been joined (they were allocated on the main stream)."""
+        held, self.held = self.held, []
+        gem = [e for e in held if e[2] is not None]
+        for e in held:
+            if e[2] is None:
+                e[0]()
+        for i in range(0, len(gem), self.max):
+            q = gem[i:i + self.max]
+            arr = (TnArgs * len(q))(*[e[0] for e in q])
+            lib.call("tuber_gemm_tn_group", arr, len(q))
+            for _, _, defers in q:
+                for d in defers:
+                    self.store.defer.add(*d)
+        return held
 
     def flush(self):
         q, self.q = self.q, []

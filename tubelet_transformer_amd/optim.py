@@ -31,6 +31,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
         # lr_scheduler.step() / step_update() act on a captured hipGraph too
         self.hyper = torch.zeros(len(self.param_groups), 2, dtype=torch.float32, device=dev)
         self._hyper_host = None
+        self._hyper_pin = None          # pinned staging of the table: per-iteration schedulers change lr every step, no blocking copy
         # flat segments with uniform hyper-parameters: walk the store in layout order
         by_ptr = {}
         for gi, group in enumerate(self.param_groups):
@@ -58,7 +59,24 @@ class FusedClipAdamW(torch.optim.Optimizer):
         """push param_groups' lr / weight_decay to the device table if they changed (one tiny async copy)."""
         host = [(float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups]
         if host != self._hyper_host:
-            self.hyper.copy_(torch.tensor(host, dtype=torch.float32).view(-1, 2), non_blocking=False)
+            if self.hyper.is_cuda:
+                if self._hyper_pin is None:
+                    self._hyper_pin = [torch.empty(len(host), 2, dtype=torch.float32).pin_memory() for _ in range(4)]
+                    self._hyper_ev = [None] * len(self._hyper_pin)
+                    self._hyper_k = 0
+                # a ring of pinned tables: the async copy of step k may still be in flight when step k+1 fills the next one; an
+                # entry is reused only after its copy has executed (the host waits only if it is > 4 lr changes ahead of the GPU)
+                self._hyper_k = (self._hyper_k + 1) % len(self._hyper_pin)
+                pin, ev = self._hyper_pin[self._hyper_k], self._hyper_ev[self._hyper_k]
+                if ev is not None:
+                    ev.synchronize()
+                pin.copy_(torch.tensor(host, dtype=torch.float32).view(-1, 2))
+                self.hyper.copy_(pin, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._hyper_ev[self._hyper_k] = ev
+            else:
+                self.hyper.copy_(torch.tensor(host, dtype=torch.float32).view(-1, 2))
             self._hyper_host = host
 
     # -- checkpointing: the moments live in flat buffers outside Optimizer.state -----------------------------------------------
@@ -122,3 +140,89 @@ def build_param_groups(model, cfg):
         {"params": [p for n, p in named if "class_embed" in n and p.requires_grad], "lr": T.LR},
         {"params": [p for n, p in named if "query_embed" in n and p.requires_grad], "lr": T.LR},
     ]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's own optimizer object: torch.optim.AdamW(param_dicts, lr=..., weight_decay=...) (train_tuber_ava.py:41-58)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _is_plain_adamw(opt):
+    if type(opt).__name__ != "AdamW" or not isinstance(opt, torch.optim.Optimizer):
+        return False
+    for g in opt.param_groups:
+        if g.get("amsgrad") or g.get("maximize") or g.get("decoupled_weight_decay") is False:
+            return False
+    return True
+
+
+def adopt(optimizer, model):
+    """The optimizer the training loop should drive, given what the SCRIPT built.
+
+    * a ``FusedClipAdamW``: itself;
+    * a stock ``torch.optim.AdamW`` over (a subset of) the model's parameters -- what ``train_tuber_ava.py:58`` constructs: a
+      ``FusedClipAdamW`` that SHARES its ``param_groups`` (the same list of the same dicts, so ``MultiStepLR`` /
+      ``build_scheduler`` objects bound to the user's optimizer keep steering the fused step, on a captured hipGraph too) and whose
+      flat moment buffers are exposed as ``optimizer.state[p]['exp_avg' | 'exp_avg_sq' | 'step']`` VIEWS, so
+      ``optimizer.state_dict()`` (``save_checkpoint``, utils/model_utils.py:118-134) stores the live AdamW state and
+      ``optimizer.load_state_dict()`` (resume) flows back into the flat buffers.  Cached on the optimizer object;
+    * anything else (SGD, amsgrad ...): ``None`` -- the caller falls back to ``clip_grad_norm_`` + ``optimizer.step()`` on the
+      gradient views (the reference's literal sequence, video_action_recognition.py:152-154).
+    """
+    if isinstance(optimizer, FusedClipAdamW):
+        return optimizer
+    fused = getattr(optimizer, "_tuber_fused", None)
+    if fused is not None:
+        return fused
+    if not _is_plain_adamw(optimizer):
+        return None
+    model = model.module if hasattr(model, "module") else model
+    groups = optimizer.param_groups
+    g0 = groups[0]
+    fused = FusedClipAdamW([{k: v for k, v in g.items()} for g in groups], lr=g0["lr"], betas=g0["betas"], eps=g0["eps"],
+                           weight_decay=g0["weight_decay"], model=model)
+    fused.param_groups = groups                    # shared, not copied: lr_scheduler.step() on the user's optimizer acts here
+    fused._hyper_host = None
+    st = fused.store
+    import_state = bool(optimizer.state)
+
+    by_ptr = {q.data_ptr(): n for n, q in zip(st.names, st.params)}
+
+    def bind(load):
+        """(re)bind optimizer.state to views of the flat moments; ``load``: first copy what the state holds (resume) into them"""
+        step = None
+        for g in groups:
+            for p in g["params"]:
+                n = by_ptr.get(p.data_ptr())
+                if n is None:
+                    raise ValueError("optimizer holds a parameter that is not part of the model's ParamStore")
+                o = st.offsets[n]
+                ea = fused.exp_avg[o:o + p.numel()].view(p.shape)
+                es = fused.exp_avg_sq[o:o + p.numel()].view(p.shape)
+                old = optimizer.state.get(p)
+                if load and old and "exp_avg" in old:
+                    with torch.no_grad():
+                        ea.copy_(old["exp_avg"])
+                        es.copy_(old["exp_avg_sq"])
+                    step = int(float(old["step"])) if step is None else step
+                optimizer.state[p] = {"step": torch.tensor(float(fused._host_t)), "exp_avg": ea, "exp_avg_sq": es}
+        if load and step is not None:
+            fused.t_dev.fill_(step)
+            fused._host_t = step
+            for s in optimizer.state.values():
+                s["step"] = torch.tensor(float(step))
+
+    fused._host_t = 0
+    bind(import_state)
+
+    def pre_state_dict(opt):                       # optimizer.state_dict(): one device->host read of the step counter, only here
+        t = float(fused.t)
+        for s in opt.state.values():
+            s["step"] = torch.tensor(t)
+
+    def post_load(opt):                            # optimizer.load_state_dict(): loaded tensors replaced the views -> copy in, re-bind
+        bind(True)
+        fused._hyper_host = None
+
+    optimizer.register_state_dict_pre_hook(pre_state_dict)
+    optimizer.register_load_state_dict_post_hook(post_load)
+    optimizer._tuber_fused = fused
+    return fused

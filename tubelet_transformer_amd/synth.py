@@ -23,13 +23,18 @@ def _gen(name, salt=0):
 
 
 @torch.no_grad()
-def name_hashed_state(state_dict, salt=0):
+def name_hashed_state(state_dict, salt=0, residual_gain=None):
     """Return ``{name: tensor}`` with deterministic values for every entry of ``state_dict``.
 
     Rules (by leaf name): BN/LN ``weight`` ~ 1 + 0.1 N, ``bias`` ~ 0.1 N (0.02 N for
     conv/linear biases), ``running_mean`` ~ 0.1 N, ``running_var`` ~ 1 + 0.2 U,
     ``num_batches_tracked`` = 0, embeddings ~ N, every >=2-D weight ~ N(0, 1/fan_in).
     A leading ``module.`` (DDP prefix) is ignored so wrapped and bare models agree.
+
+    ``residual_gain``: scale every ``bn4.weight`` -- the last BatchNorm of each residual branch (ir_CSN_152.py:64,82-84) -- by this
+    factor.  At random weights a 50-bottleneck training-mode-BatchNorm body amplifies bf16 rounding through ReLU-mask flips until even
+    an ideally-accumulated bf16 execution decorrelates from fp32; with identity-dominated blocks (gain ~0.05-0.1) the deep gradient
+    stays well-conditioned, which is what a parity test at real depth needs (tests/test_fullsize_gpu.py).
     """
     out = {}
     for name, t in state_dict.items():
@@ -52,6 +57,8 @@ def name_hashed_state(state_dict, salt=0):
                 v = torch.randn(t.shape, generator=g) * (1.0 / fan_in) ** 0.5
         elif leaf == "weight":            # 1-D weight: BatchNorm / LayerNorm gamma
             v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+            if residual_gain is not None and key.endswith(".bn4.weight"):
+                v = v * float(residual_gain)
         elif leaf in ("bias", "in_proj_bias"):
             is_norm = any(s in key for s in (".bn", "norm", "down_sample.1"))
             v = (0.1 if is_norm else 0.02) * torch.randn(t.shape, generator=g)
@@ -62,10 +69,10 @@ def name_hashed_state(state_dict, salt=0):
 
 
 @torch.no_grad()
-def load_name_hashed(module, salt=0):
+def load_name_hashed(module, salt=0, residual_gain=None):
     """Fill ``module``'s parameters and buffers in place with name-hashed values."""
     sd = module.state_dict()
-    vals = name_hashed_state(sd, salt)
+    vals = name_hashed_state(sd, salt, residual_gain)
     for k, t in sd.items():
         t.copy_(vals[k].to(t.device))
     return module

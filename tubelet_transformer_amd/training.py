@@ -14,7 +14,7 @@ import os
 import torch
 
 from .ddp import attach_reducer, broadcast_parameters
-from .optim import FusedClipAdamW, build_param_groups
+from .optim import FusedClipAdamW, adopt, build_param_groups
 
 
 def deploy_model(model, cfg, is_tuber=True, device=None):
@@ -53,22 +53,32 @@ def build_optimizer(model, cfg):
 
 
 def train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=0, cfg=None):
-    """Returns (total loss tensor, loss dict) -- all on the device, nothing synchronised."""
+    """One eager optimisation step.  ``optimizer``: a ``FusedClipAdamW``, or the object the reference script builds --
+    ``torch.optim.AdamW(param_dicts, lr=..., weight_decay=...)`` (train_tuber_ava.py:58), adopted transparently (optim.adopt: shared
+    ``param_groups``, state exposed as views) -- or any other ``torch.optim.Optimizer``, driven by the reference's literal sequence
+    ``clip_grad_norm_`` + ``optimizer.step()`` on the gradient views (video_action_recognition.py:152-154).
+    Returns (total loss tensor, loss dict) -- all on the device, nothing synchronised."""
     store, _ = model.engine()
     reducer = getattr(store, "reducer", None)
+    fused = adopt(optimizer, model)
     outputs = model(samples)
     loss_dict = criterion(outputs, targets)
     weight_dict = criterion.weight_dict
     if cfg is not None and epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:          # video_action_recognition.py:145-146
         weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
     losses = criterion.weighted_total(loss_dict, weight_dict)
-    optimizer.zero_grad()
+    store.zero_grad()                      # optimizer.zero_grad() of a stock optimizer would drop the views into the flat buffer
     if reducer is not None:
         reducer.begin()
     losses.backward()
     if reducer is not None:
         reducer.finish()
-    optimizer.step(max_norm=max_norm if max_norm and max_norm > 0 else None)
+    if fused is not None:
+        fused.step(max_norm=max_norm if max_norm and max_norm > 0 else None)
+    else:
+        if max_norm and max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
     return losses.detach(), loss_dict
 
 
@@ -85,6 +95,10 @@ class _Snapshot:
         with torch.no_grad():
             for live, saved in self.items:
                 live.copy_(saved)
+
+
+class CaptureFailed(RuntimeError):
+    """the hipGraph capture of a training step did not complete (the eager step remains available)"""
 
 
 class GraphedTrainStep:
@@ -108,12 +122,15 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, criterion, optimizer, max_norm, tmax=16, max_graphs=4):
-        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        fused = adopt(optimizer, model)
+        if fused is None:
+            raise TypeError("GraphedTrainStep needs AdamW (FusedClipAdamW or a stock torch.optim.AdamW); got %s" % type(optimizer).__name__)
+        self.model, self.criterion, self.optimizer = model, criterion, fused
         self.max_norm, self.tmax, self.max_graphs = max_norm, tmax, max_graphs
         self.graphs = collections.OrderedDict()
 
     # -- capture -------------------------------------------------------------------------------------------------------------
-    def _capture(self, clips, mask, targets):
+    def _capture(self, clips, mask, targets, tmax):
         from .criterion import PaddedTargets
         from .misc import NestedTensor
         model, crit, opt = self.model, self.criterion, self.optimizer
@@ -126,7 +143,7 @@ class GraphedTrainStep:
         g.red, g.in_graph = red, in_graph
         g.clips = clips.clone()
         g.mask = mask.clone()
-        g.pt = PaddedTargets(targets, crit.ava, crit.num_classes if crit.ava else crit.num_classes + 1, dev, tmax=self.tmax)
+        g.pt = PaddedTargets(targets, crit.ava, crit.num_classes if crit.ava else crit.num_classes + 1, dev, tmax=tmax)
         max_norm = self.max_norm if self.max_norm and self.max_norm > 0 else None
 
         def head():
@@ -251,12 +268,24 @@ class GraphedTrainStep:
             clips, mask = samples, None
         if mask is None:
             mask = torch.zeros(clips.shape[0], clips.shape[-2], clips.shape[-1], dtype=torch.bool, device=store.device)
-        key = (tuple(clips.shape), store.trainable_signature(), self.criterion.training)
+        # the padded [B, Tmax] target layout is baked into the capture: a batch with more boxes per clip than any before (dense
+        # AVA key frames) gets a graph with a wider layout instead of an error -- the reference has no such limit
+        need = max([int(t["boxes"].shape[0]) for t in targets] + [1])
+        tmax = max(self.tmax, (need + 15) // 16 * 16)
+        for k in self.graphs:                                     # a captured wider layout serves narrower batches too
+            if k[:3] == (tuple(clips.shape), store.trainable_signature(), self.criterion.training) and k[3] >= tmax:
+                tmax = k[3]
+                break
+        key = (tuple(clips.shape), store.trainable_signature(), self.criterion.training, tmax)
         g = self.graphs.get(key)
         if g is None:
             while len(self.graphs) >= self.max_graphs:            # LRU: a graph holds its own memory pool
                 self.graphs.popitem(last=False)
-            g = self.graphs[key] = self._capture(clips.to(store.device, torch.float32), mask.to(store.device), targets)
+            try:
+                g = self._capture(clips.to(store.device, torch.float32), mask.to(store.device), targets, tmax)
+            except (RuntimeError, ValueError) as e:
+                raise CaptureFailed("%s: %s" % (type(e).__name__, e)) from e
+            self.graphs[key] = g
         else:
             self.graphs.move_to_end(key)
         g.clips.copy_(clips, non_blocking=True)
@@ -298,12 +327,55 @@ class GraphedTrainStep:
         return g.loss, g.loss_dict
 
 
+class _DeviceMeters:
+    """The reference's AverageMeters (class_err, losses_avg, losses_box, losses_giou, losses_ce, losses_ce_b:
+    video_action_recognition.py:97-104,182-193), accumulated ON THE DEVICE -- every iteration contributes (weight = len(targets),
+    like ``meter.update(value, len(targets))``), the host reads the six running averages only when it prints."""
+    KEYS = ("class_error", "loss", "loss_bbox", "loss_giou", "loss_ce", "loss_ce_b")
+
+    def __init__(self, device):
+        self.sum = torch.zeros(len(self.KEYS), dtype=torch.float64, device=device)
+        self.count = 0
+
+    def update(self, loss, loss_dict, n):
+        zero = loss.new_zeros(())
+        vals = [loss if k == "loss" else loss_dict.get(k, zero) for k in self.KEYS]
+        vals = [v.detach().reshape(()).to(loss.dtype) if torch.is_tensor(v) else loss.new_tensor(float(v)) for v in vals]
+        self.sum.add_(torch.stack(vals).double(), alpha=float(n))
+        self.count += n
+
+    def averages(self):
+        """{key: running average} -- ONE device->host read"""
+        host = (self.sum / max(self.count, 1)).tolist()
+        return dict(zip(self.KEYS, host))
+
+
+def _graphed_for(model, criterion, optimizer, max_norm):
+    """the cached GraphedTrainStep of (model, criterion, optimizer, max_norm), or None when the optimizer is not AdamW"""
+    fused = adopt(optimizer, model)
+    if fused is None:
+        return None
+    cache = model.__dict__.setdefault("_tuber_graphed", {})
+    key = (id(criterion), id(fused), float(max_norm or 0.0))
+    g = cache.get(key)
+    if g is None:
+        cache.clear()                       # one live training configuration per model: a graph owns its memory pool
+        g = cache[key] = GraphedTrainStep(model, criterion, fused, max_norm)
+    return g
+
+
 def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, max_norm, lr_scheduler=None, writer=None,
                           graphed=None, print_freq=10):
-    """One training epoch -- the reference's ``train_tuber_detection`` (utils/video_action_recognition.py:64-220) on the HIP path:
-    every batch is one ``train_step`` (or one replay of ``graphed``, a ``GraphedTrainStep``); losses are read back only every
-    ``print_freq`` iterations so the GPU queue stays full.  ``epoch > LOSS_COFS.WEIGHT_CHANGE`` switches ``loss_ce``'s weight
-    like the reference (:145-146)."""
+    """One training epoch -- the reference's ``train_tuber_detection`` (utils/video_action_recognition.py:64-220), same argument
+    list, on the HIP path.  ``optimizer`` is whatever the script built: the stock ``torch.optim.AdamW(param_dicts, ...)`` of
+    train_tuber_ava.py:58 is adopted (optim.adopt), ``lr_scheduler`` stays bound to that object.
+
+    Every batch is one replay of the captured hipGraph step (``GraphedTrainStep``, created on first use and cached on the model;
+    ``graphed=False`` or ``TUBER_EAGER_STEP=1`` forces the eager ``train_step``, which is also the fallback when a capture fails or
+    the optimizer is not AdamW).  The six scalars the reference logs -- ``train/{class_error,totall_loss,loss_bbox,loss_giou,
+    loss_ce,loss_ce_b}`` (:215-220), running averages weighted by ``len(targets)`` -- are accumulated on the device for EVERY
+    iteration and read back every ``print_freq`` iterations, so the GPU queue stays full; a non-finite loss stops training like
+    the reference (:195-198).  ``epoch > LOSS_COFS.WEIGHT_CHANGE`` switches ``loss_ce``'s weight (:145-146)."""
     import time
     model.train()
     criterion.train()
@@ -311,25 +383,55 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
     rank = getattr(cfg.DDP_CONFIG, "GPU_WORLD_RANK", 0)
     if epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:
         criterion.weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
+    if graphed is None and not os.environ.get("TUBER_EAGER_STEP"):
+        graphed = _graphed_for(model, criterion, optimizer, max_norm)
+    elif graphed is False or graphed is None:
+        graphed = None
+    meters = _DeviceMeters(dev)
     end = time.time()
     loss = None
+    n_iter = len(data_loader)
     for idx, data in enumerate(data_loader):
         samples, targets = data[0], data[1]
         samples = samples.to(dev)            # reference :121; for an input_pipeline.ClipBatch this IS the HIP pre-pass (uint8 frames -> fp32 batch)
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
         if graphed is not None:
-            loss, loss_dict = graphed(samples, targets)       # NestedTensor: clips AND padding mask go to the captured buffers
+            try:
+                loss, loss_dict = graphed(samples, targets)       # NestedTensor: clips AND padding mask go to the captured buffers
+            except CaptureFailed as e:                            # a failed capture must not end the epoch
+                if getattr(model.engine()[0], "reducer", None) is not None:
+                    raise                                         # N > 1: every rank must stay on the same collective sequence
+                import sys
+                print("[tuber] hipGraph step unavailable (%s: %s); continuing with the eager step" % (type(e).__name__, e), file=sys.stderr, flush=True)
+                graphed = None
+                model.__dict__.pop("_tuber_graphed", None)
+                loss, loss_dict = train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=epoch, cfg=cfg)
         else:
             loss, loss_dict = train_step(model, criterion, optimizer, samples, targets, max_norm, epoch=epoch, cfg=cfg)
         if lr_scheduler is not None and cfg.CONFIG.TRAIN.LR_POLICY == "cosine":
-            lr_scheduler.step_update(epoch * len(data_loader) + idx)
-        if rank == 0 and (idx % print_freq == 0 or idx + 1 == len(data_loader)):
-            lv = float(loss.detach())                          # the only host sync, every print_freq iterations
+            lr_scheduler.step_update(epoch * n_iter + idx)
+        if rank == 0:
+            meters.update(loss, loss_dict, len(targets))
+        if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
+            avg = meters.averages()                            # the only host sync, every print_freq iterations
+            lv = avg["loss"]
             if lv != lv or lv in (float("inf"), float("-inf")):
+                print("Loss is {}, stopping training".format(lv))
+                print({k: float(v.detach()) if torch.is_tensor(v) else v for k, v in loss_dict.items()})
                 raise FloatingPointError("loss is %r at epoch %d iteration %d" % (lv, epoch, idx))
-            print("Epoch: [%d][%d/%d]  %.3f s/iter  loss %.4f  " % (epoch, idx + 1, len(data_loader), (time.time() - end), lv) +
-                  ", ".join("%s %.4f" % (k, float(v.detach() if torch.is_tensor(v) else v)) for k, v in loss_dict.items() if k in ("loss_ce", "loss_bbox", "loss_giou", "loss_ce_b", "class_error")))
+            lr = optimizer.param_groups[-1]["lr"]
+            print("Epoch: [%d][%d/%d]" % (epoch, idx + 1, n_iter))
+            print("lr: ", lr)
+            print("batch time: %.3f" % (time.time() - end))
+            print("class_error: {class_error:.3f}, loss: {loss:.3f}, loss_bbox: {loss_bbox:.3f}, loss_giou: {loss_giou:.3f}, "
+                  "loss_ce: {loss_ce:.3f}, loss_ce_b: {loss_ce_b:.3f}".format(**avg))
             if writer is not None:
-                writer.add_scalar("train/loss", lv, idx + epoch * len(data_loader))
+                it = idx + epoch * n_iter
+                writer.add_scalar("train/class_error", avg["class_error"], it)
+                writer.add_scalar("train/totall_loss", avg["loss"], it)          # (sic) the reference's tag, :216
+                writer.add_scalar("train/loss_bbox", avg["loss_bbox"], it)
+                writer.add_scalar("train/loss_giou", avg["loss_giou"], it)
+                writer.add_scalar("train/loss_ce", avg["loss_ce"], it)
+                writer.add_scalar("train/loss_ce_b", avg["loss_ce_b"], it)
         end = time.time()
     return loss
