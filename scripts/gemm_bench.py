@@ -82,6 +82,35 @@ def bench_tn():
         print("%-28s %8.1f %6d   | %.1f MB %.2f GF" % ("%d %d %d" % (M, N, K), time_it(fn), S, (2 * M * (N + K) + 4 * N * K) / 1e6, 2 * M * N * K / 1e9), flush=True)
 
 
+def bench_tn_group():
+    """the grouped weight-gradient launch as the backward pass issues it: eight layer3 problems (conv4 / conv1 of four bottlenecks),
+    three layer4 ones, the class-branch FFN pair"""
+    import ctypes
+    from tubelet_transformer_amd.engine import TnArgs
+    groups = {"layer3 x8": [(5632, 1024, 256, 1), (5632, 256, 1024, 0)] * 4,
+              "layer4 x6": [(2816, 2048, 512, 1), (2816, 512, 2048, 0)] * 3,
+              "class-branch FFN": [(16896, 256, 2048, 0), (16896, 2048, 512, 0)],
+              "encoder FFN x4": [(704, 256, 2048, 0), (704, 2048, 256, 0)] * 2}
+    for name, probs in groups.items():
+        ents, keep, by, fl = [], [], 0, 0
+        for i, (M, N, K, amode) in enumerate(probs):
+            G = torch.randn(M, N, device=dev).to(BF)
+            A = torch.randn(M, K, device=dev).to(BF)
+            sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)
+            S = lib.query("tuber_gemm_tn_slabs", M, N, K)
+            part = torch.empty(max(S, 1) * N * K, device=dev)
+            out = torch.zeros(N, K, device=dev)
+            ents.append(TnArgs(G.data_ptr(), N, A.data_ptr(), K, part.data_ptr(), out.data_ptr(), 2 if S > 1 else 1, M, N, K, amode, 0,
+                               0, 0, 0, 0, 0, 0, 0, 0, sc.data_ptr() if amode else None, sh.data_ptr() if amode else None, None))
+            keep.append((G, A, sc, sh, part, out))
+            by += 2 * M * (N + K) + 4 * N * K
+            fl += 2 * M * N * K
+        arr = (TnArgs * len(ents))(*ents)
+        t = time_it(lambda: lib.call("tuber_gemm_tn_group", arr, len(ents)))
+        print("%-20s %2d GEMMs  slabs %s  %7.1f us   %.1f MB alg -> %.2f TB/s (%.3f of 8 TB/s), %.0f TF/s" % (
+            name, len(ents), [lib.query("tuber_gemm_tn_slabs", *q[:3]) for q in probs[:2]], t, by / 1e6, by / t / 1e6, by / t / 1e6 / 8.0, fl / t / 1e6), flush=True)
+
+
 def bench_misc():
     for M, E in [(30, 256), (704, 256), (16896, 256)]:
         x = torch.randn(M, E, device=dev).to(BF)
@@ -184,6 +213,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":
         bench_tn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tngroup":
+        bench_tn_group()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
         bench_misc()

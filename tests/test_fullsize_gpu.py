@@ -389,7 +389,8 @@ def test_teacher_forced_bottleneck_gradients_at_real_depth(dev):
             ch, cb, eh, eb, nr = grad_row(h, a, b)
             rows.append((ch, cb, eh, eb, nr, tag + " " + n))
             if eh > 2.0 * eb + 0.05 or not (0.5 < nr < 2.0):
-                worse.append((tag, n, "cos %.4f/%.4f" % (ch, cb), "relerr %.3f/%.3f" % (eh, eb), "norm %.3f" % nr))
+                worse.append((tag, n, "cos %.4f/%.4f" % (ch, cb), "relerr %.3f/%.3f" % (eh, eb), "norm %.3f" % nr,
+                              eh > 3.0 * eb + 0.05 or not (0.5 < nr < 2.0)))
             if cb >= 0.95 and ch < 0.9:
                 weak.append((tag, n, ch, cb))
     print("50 single-block + %d multi-block teacher-forced segments: %.1f s" % (len(segs) - 50, time.time() - t0))

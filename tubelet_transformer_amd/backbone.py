@@ -25,7 +25,7 @@ BN_EPS = 1e-3       # ir_CSN_152.py:15
 BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
-LATE_WGRAD = not os.environ.get("TUBER_NO_LATE_WGRAD")      # A/B switch: layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward (single GPU)
+LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -419,12 +419,13 @@ class CSNRunner:
         dev = self.dev
         pre = None          # (dz, sum-dz rows, sum-dz*c4 rows, R) of this block's join backward, produced by the block above (tuber_gemm_nt_join)
         wq = self.store.wq
-        # Late mode (single GPU, whole body in one call): the weight gradients of layer3 / layer4 -- grouped dW GEMMs, depthwise
-        # weight gradients: a quarter of layer3's backward timeline, feeding nothing until the optimizer -- are parked while the
-        # latency-bound data-gradient chain of those stages runs, and launched on a side stream at the layer3 -> layer2 boundary,
-        # where they overlap the bandwidth-bound layer2 / layer1 / stem backward (ONE fork and ONE join per step; the per-block
-        # forks measured in rounds 1-2 cost more than they hid).  With a reducer (N > 1) that window belongs to the all-reduce.
-        late = (LATE_WGRAD and red is None and wq.enabled and self.store.defer.enabled and lowest < top and self.blocks[lowest]["stage"] <= 2
+        # Late mode (TUBER_LATE_WGRAD=1; single GPU, whole body in one call): the weight gradients of layer3 / layer4 -- grouped dW
+        # GEMMs, depthwise weight gradients: a quarter of layer3's backward timeline, feeding nothing until the optimizer -- are
+        # parked while the latency-bound data-gradient chain of those stages runs, and launched on a side stream at the
+        # layer3 -> layer2 boundary, where they would overlap the bandwidth-bound layer2 / layer1 / stem backward (ONE fork and ONE
+        # join per step).  Measured in round 3: 17.29 vs 16.74 ms/step inside the hipGraph (bit-identical gradients) -- even a single
+        # two-branch region costs the replay more than the 1 ms of leaf work it moves; off by default.
+        late = (LATE_WGRAD and red is None and not getattr(self.store, "no_late", False) and wq.enabled and self.store.defer.enabled and lowest < top and self.blocks[lowest]["stage"] <= 2
                 and self.blocks[top - 1]["stage"] >= 3 and getattr(self, "split_hook", None) is None)
         for bi in range(top - 1, lowest - 1, -1):
             d, sv, f = self.blocks[bi], sblocks[bi - base], plans[bi]

@@ -22,5 +22,5 @@ struct AttnArgs {
 };
 
 // MFMA path (attention_mfma.hip), taken for Lq >= 32
-extern "C" void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream);
-extern "C" void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream);

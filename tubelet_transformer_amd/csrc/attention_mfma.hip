@@ -413,12 +413,12 @@ static bool attn_split(int rows, int H, int B) {
     static const int lim = getenv("TUBER_ATTN_SPLIT_BELOW") ? atoi(getenv("TUBER_ATTN_SPLIT_BELOW")) : 256;
     return (long)ceil_div(rows, 64) * H * B < lim;
 }
-extern "C" void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream) {
+extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_fwd_launch(const void* args, hipStream_t stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
     if (attn_split(a.Lq, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_fwd_kernel<true>, dim3(ceil_div(a.Lq, 16), a.H, a.B), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_mfma_fwd_kernel<false>, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
 }
-extern "C" void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream) {
+extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
     if (attn_split(a.Lq, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<true>, dim3(ceil_div(a.Lq, 16), a.H, a.B), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<false>, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);

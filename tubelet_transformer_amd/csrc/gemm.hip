@@ -680,13 +680,27 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
     if (nt_force_cfg() < 0 && cfg == 13 && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
     switch (cfg) {
-        case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // A/B only
+        case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // class-branch FFN (plain epilogue)
         case 7: return launch_nt_cfg<64, 128, 1, 4, 2, 3>(p, amode, epi, stream);
-        case 12: return launch_nt_cfg<64, 64, 2, 2, 4, 3>(p, amode, epi, stream);     // A/B: 64x64 without register pressure
-        case 13: return launch_nt_cfg<64, 64, 2, 2, 2, 4>(p, amode, epi, stream);     // A/B: shallower prefetch
-        case 17: return launch_nt_cfg<64, 128, 1, 4, 2, 4>(p, amode, epi, stream);    // A/B: round-1 register cap (spills)
-        default: return launch_nt_cfg<64, 64, 2, 2, 4, 4>(p, amode, epi, stream);
+        case 13: return launch_nt_cfg<64, 64, 2, 2, 2, 4>(p, amode, epi, stream);
+#ifdef TUBER_AB_VARIANTS
+        // the measured-and-rejected tile variants of profiles/r02_gemm_nt_tile_ab.txt (deeper prefetch, round-1 register cap: they
+        // spill to scratch) are built only with -DTUBER_AB_VARIANTS (TUBER_AB_VARIANTS=1 python -m tubelet_transformer_amd.build)
+        case 12: return launch_nt_cfg<64, 64, 2, 2, 4, 3>(p, amode, epi, stream);     // 64x64, four-tile prefetch, 3 workgroups / CU
+        case 17: return launch_nt_cfg<64, 128, 1, 4, 2, 4>(p, amode, epi, stream);    // round-1 register cap (spills)
+        case 2: return launch_nt_cfg<64, 64, 2, 2, 4, 4>(p, amode, epi, stream);      // round-1 default (spills in the fused variants)
+#endif
+        default: return TUBER_EINVAL;
     }
+}
+
+// 1 when tuber_gemm_nt_set_cfg(cfg) names a tile configuration this library was built with
+int tuber_gemm_nt_has_cfg(int cfg) {
+#ifdef TUBER_AB_VARIANTS
+    return cfg == 0 || cfg == 7 || cfg == 13 || cfg == 12 || cfg == 17 || cfg == 2;
+#else
+    return cfg == 0 || cfg == 7 || cfg == 13;
+#endif
 }
 
 }  // extern "C"
@@ -1121,6 +1135,200 @@ __device__ __forceinline__ void gemm_tn2_body(const GemmTN& p, int bid, int nblo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_tn3: the same transpose-read weight-gradient GEMM on 128 x 128 output tiles (round 3).  The 64 x 64 kernel moves
+// 16 KB of operands through L2 / LDS per 64-row step for 64 x 64 x 64 MACs; over a grouped launch of eight layer3 problems that is
+// 720 MB of L2 -> LDS traffic for 128 MB of operands (every A panel read 16x, every G panel 4x) at 11 % MFMA utilisation -- it
+// is bound by operand movement, not by HBM or MFMA.  Here a wave owns 64 x 64 of the tile (16 accumulator blocks): one LDS
+// fragment feeds 4 MFMAs instead of 2, a 64-row step carries 4x the MACs for 2x the bytes.  LDS: 2 buffers x 2 operands x
+// [64 m][128 cols] bf16 = 64 KB, two workgroups per CU.  Rows are 256 B = one full sweep of the 64 banks, so the 32-byte units are
+// XOR-swizzled by a 3-bit row key that differs over the eight rows {r..r+3, r+8..r+11} a 32-lane pass of ds_read_b64_tr_b16
+// touches (conflict-free); 16-byte stores cover whole rows.  Taken for N, K multiples of 128 with N*K >= 2^17.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TNP3 128
+__device__ __forceinline__ int tn3_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int tn3_off(int row, int col) { return row * TNP3 + ((((col >> 4) ^ tn3_key(row)) << 4) | (col & 15)); }
+__device__ __forceinline__ bf16x8 tn3_frag(const bf16* img, int m0, int col0, int li) {
+    const bf16* p = img + tn3_off(m0 + (li >> 2), col0 + (li & 3) * 4);          // row + 4 has the same key (m0 % 8 == 0, li >> 2 < 4)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * TNP3));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int AMODE>
+__device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblocks) {
+    constexpr int T = 128, TW = 64, FT = 4;             // wave tile 64 x 64 = 4 x 4 MFMA blocks
+    constexpr int IMG = 64 * TNP3;
+    __shared__ __attribute__((aligned(16))) bf16 smem[2][2][IMG];     // [buf][G | A][64 m][128]
+    const bool bn_relu = AMODE < 0 ? p.amode == A_BN_RELU : AMODE == A_BN_RELU;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + T - 1) / T, tiles_k = (p.K + T - 1) / T;
+    int b = xcd_remap(bid, nblocks);
+    const int slab = b / (tiles_n * tiles_k);
+    b -= slab * tiles_n * tiles_k;
+    const int tile_n = b % tiles_n, tile_k = b / tiles_n;
+    const int n0 = tile_n * T, k0 = tile_k * T;
+    const int m_begin = slab * p.rows_per_slab;
+    const int m_end = min(p.M, m_begin + p.rows_per_slab);
+
+    // staging: thread -> 16-byte chunk c (8 columns) of rows r, r + 16, r + 32, r + 48 of the 64-row step
+    const int c = tid & 15, r = tid >> 4;
+    const bool g_col_ok = n0 + c * 8 < p.N, a_col_ok = k0 + c * 8 < p.K;
+    float asc[8], ash[8];
+    if (bn_relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + c * 8 + e;
+            asc[e] = k < p.K ? p.a_scale[k] : 1.f;
+            ash[e] = k < p.K ? p.a_shift[k] : 0.f;
+        }
+    }
+    const bool do_bias = p.bias_grad != nullptr && tile_k == 0;
+    float bsum = 0.f;
+    constexpr int GS = 2;
+    uint4 rg[GS][4], ra[GS][4];
+    bool rok[GS][4];
+    const bool dense = !p.gather && g_col_ok && a_col_ok && !p.A2;
+    const bf16* gb0 = p.G + (long)(m_begin + r) * p.ldg + n0 + c * 8;
+    const bf16* ab0 = p.A + (long)(m_begin + r) * p.lda + k0 + c * 8;
+    const long g16 = 16 * p.ldg, a16 = 16 * p.lda;
+    auto add8 = [](uint4 a, uint4 b) {
+        const bf16x8 x = as_bf16x8(a), y = as_bf16x8(b);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+        return as_uint4(o);
+    };
+    auto load_step = [&](int ms, uint4 (&xg)[4], uint4 (&xa)[4], bool (&ok)[4]) {
+        if (dense && ms + 64 <= m_end) {
+            const long so = (long)(ms - m_begin);
+            const bf16* gq = gb0 + so * p.ldg;
+            const bf16* aq = ab0 + so * p.lda;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { xg[h] = *(const uint4*)(gq + h * g16); xa[h] = *(const uint4*)(aq + h * a16); ok[h] = true; }
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int m = ms + r + 16 * h;
+            ok[h] = m < m_end;
+            long arow = m;
+            if (p.gather && ok[h]) {
+                int w = m % p.Wo; int q = m / p.Wo;
+                int hh = q % p.Ho; q /= p.Ho;
+                int t = q % p.To; int n = q / p.To;
+                arow = (((long)n * p.Ti + (long)t * p.st) * p.Hi + (long)hh * p.ss) * p.Wi + (long)w * p.ss;
+            }
+            xg[h] = (ok[h] && g_col_ok) ? *(const uint4*)(p.G + (long)m * p.ldg + n0 + c * 8) : make_uint4(0, 0, 0, 0);
+            xa[h] = (ok[h] && a_col_ok) ? *(const uint4*)(p.A + arow * p.lda + k0 + c * 8) : make_uint4(0, 0, 0, 0);
+            if (p.A2 && ok[h] && a_col_ok) xa[h] = add8(xa[h], *(const uint4*)(p.A2 + (long)m * p.lda2 + k0 + c * 8));
+        }
+    };
+    auto store_step = [&](int buf, const uint4 (&xg)[4], const uint4 (&xa)[4], const bool (&ok)[4]) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            uint4 av = xa[h];
+            if (bn_relu) {
+                const bf16x8 x = as_bf16x8(av);
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), asc[e], ash[e]), 0.f));
+                av = (ok[h] && a_col_ok) ? as_uint4(y) : make_uint4(0, 0, 0, 0);
+            }
+            *(uint4*)&smem[buf][0][tn3_off(r + 16 * h, c * 8)] = xg[h];
+            *(uint4*)&smem[buf][1][tn3_off(r + 16 * h, c * 8)] = av;
+        }
+    };
+
+    f32x4 acc[FT][FT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i)
+#pragma unroll
+        for (int j = 0; j < FT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int buf = 0;
+#pragma unroll
+    for (int j = 0; j < GS; ++j)
+        if (m_begin + 64 * j < m_end) load_step(m_begin + 64 * j, rg[j], ra[j], rok[j]);
+    for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            if (ms + 64 * j >= m_end) continue;
+            store_step(buf, rg[j], ra[j], rok[j]);
+            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
+            __syncthreads();
+            const bf16* gi = smem[buf][0];
+            const bf16* ai = smem[buf][1];
+            if (do_bias) {                          // column sums of this step's G rows: thread = (column, 32-row half)
+#pragma unroll
+                for (int mm = 0; mm < 32; ++mm) bsum += bf2f(gi[tn3_off((tid >> 7) * 32 + mm, tid & 127)]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int m0 = ks * 32 + g * 8;
+                bf16x8 fn[FT], fk[FT];
+#pragma unroll
+                for (int j2 = 0; j2 < FT; ++j2) fn[j2] = tn3_frag(gi, m0, wn * TW + j2 * 16, li);      // rows of D: n
+#pragma unroll
+                for (int i2 = 0; i2 < FT; ++i2) fk[i2] = tn3_frag(ai, m0, wm * TW + i2 * 16, li);      // cols of D: k
+#pragma unroll
+                for (int i2 = 0; i2 < FT; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < FT; ++j2)
+                        acc[i2][j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j2], fk[i2], acc[i2][j2], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+    }
+    // D[row n][col k]: lane holds k = wm*64 + i*16 + li, n = wn*64 + j*16 + g*4 + r.  The tile leaves through LDS in two halves of
+    // 64 n-rows (16-byte stores, 512 contiguous bytes per output row)
+    float* P = p.P + (long)slab * p.N * p.K;
+    __syncthreads();
+    float* ot = (float*)&smem[0][0][0];                 // [64 n][128 k + 4] fp32 = 33 KB of the 64 KB staging area
+    if (do_bias) {
+        float* br = ot + 64 * 132;                      // behind the output half-tile
+        br[tid] = bsum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const float v = br[tid] + br[128 + tid];
+            if (p.S == 1) p.bias_grad[n0 + tid] += v;
+            else p.bias_grad[(long)slab * p.N + n0 + tid] = v;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+        if (wn == h) {
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int j = 0; j < FT; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        ot[(j * 16 + g * 4 + rr) * 132 + wm * TW + i * 16 + li] = acc[i][j][rr];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            const int n = n0 + h * 64 + (idx >> 5), k = k0 + (idx & 31) * 4;
+            if (n < p.N && k < p.K) {
+                float4 v = *(const float4*)&ot[(idx >> 5) * 132 + (idx & 31) * 4];
+                float4* o = (float4*)(P + (long)n * p.K + k);
+                if (p.S == 1 && p.accumulate) { const float4 cc = *o; v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w; }
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_tn3_kernel(GemmTN p) { gemm_tn3_body<AMODE>(p, blockIdx.x, gridDim.x); }
+
 template <int AMODE>
 __global__ __launch_bounds__(256, 3) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_body<AMODE>(p, blockIdx.x, gridDim.x); }
 
@@ -1136,6 +1344,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tn2_group_kernel(GemmTNGroup g) {
     for (int i = 1; i < TN_GROUP_MAX; ++i)
         if (i < g.n && (int)blockIdx.x >= g.begin[i]) e = i;
     gemm_tn2_body<-1>(g.p[e], (int)blockIdx.x - g.begin[e], g.begin[e + 1] - g.begin[e]);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(GemmTNGroup g) {
+    int e = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.begin[i]) e = i;
+    gemm_tn3_body<-1>(g.p[e], (int)blockIdx.x - g.begin[e], g.begin[e + 1] - g.begin[e]);
 }
 
 // out[j] (+)= sum_s P[s][j], few slabs: one thread per element
@@ -1170,14 +1386,21 @@ extern "C" {
 // chip to ~256 workgroups but never more than 8 (bounds the fp32 slab traffic to <= the size of the operands) and
 // at least 256 rows each.
 static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
+// 128 x 128 transpose-read tiles (gemm_tn3): layer3 / layer4 convs, FFN and class-branch linears, packed in-projections
+static int g_tn_big = -1;
+static bool tn_big(int N, int K) {
+    if (g_tn_big < 0) { const char* e = getenv("TUBER_TN_NO_BIG_TILES"); g_tn_big = e ? 0 : 1; }      // A/B switch
+    return g_tn_big && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
+}
 static int tn_slabs_wanted(int M, int N, int K) {
-    const int T = tn_tile(N, K);
+    const int T = tn_big(N, K) ? 128 : tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
     static int target = -1;
     // workgroups aimed for per GEMM: 256 since the weight gradients travel in grouped launches (tuber_gemm_tn_group: 2-8 GEMMs share the
     // chip, so each needs fewer slabs to fill it: 18.87 -> 18.65 ms/step against 512, and half the slab traffic; 128 loses again)
     if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 256; }
-    long S = (target + tiles - 1) / tiles;
+    // big tiles: a workgroup does 4x the work and two are resident per CU -> a quarter of the workgroups per GEMM
+    long S = ((tn_big(N, K) ? target / 4 : target) + tiles - 1) / tiles;
     // bound the fp32 slab traffic (S*N*K*4 B written + read) by the size of the operands (2*M*(N+K) B);
     // tiny outputs (<= 16 tiles: <= 256 KB per slab) may split deeply
     long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);
@@ -1230,7 +1453,12 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     const int use_tr = 1;
     p.bias_grad = nullptr;
     if (bias_grad && !tuber_gemm_tn_fuses_bias(M, N, K, ldg, lda)) return TUBER_EINVAL;
-    if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7)) {     // LDS transpose-read kernel
+    if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7) && tn_big(N, K)) {     // ... on 128 x 128 tiles
+        p.bias_grad = bias_grad;
+        const dim3 grid3(ceil_div(N, 128) * ceil_div(K, 128) * p.S);
+        if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn3_kernel<A_BN_RELU>, grid3, block, 0, stream, p);
+        else hipLaunchKernelGGL(gemm_tn3_kernel<A_PLAIN>, grid3, block, 0, stream, p);
+    } else if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7)) {     // LDS transpose-read kernel
         p.bias_grad = bias_grad;
         if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn2_kernel<A_BN_RELU>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(gemm_tn2_kernel<A_PLAIN>, grid, block, 0, stream, p);
@@ -1266,15 +1494,18 @@ int tuber_gemm_tn_group_max(void) { return TN_GROUP_MAX; }
 int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
     if (!args_host || n <= 0 || n > TN_GROUP_MAX) return TUBER_EINVAL;
     const TuberGemmTNArgs* a = (const TuberGemmTNArgs*)args_host;
-    GemmTNGroup g;
-    memset(&g, 0, sizeof g);
-    int total = 0;
+    // problems on 128 x 128 tiles and on 64 x 64 tiles are different kernels (64 KB vs 36 KB of LDS): one launch per kind present
+    GemmTNGroup gs[2];
+    int total[2] = {0, 0}, cnt[2] = {0, 0};
+    memset(gs, 0, sizeof gs);
     for (int i = 0; i < n; ++i) {
         const TuberGemmTNArgs& x = a[i];
         if (x.M <= 0 || x.N <= 0 || x.K <= 0 || ((x.N | x.K | x.ldg | x.lda) & 7) || x.ldg < x.N || x.lda < x.K) return TUBER_EINVAL;
         if (tn_tile(x.N, x.K) != 64 || (x.amode != A_PLAIN && x.amode != A_BN_RELU)) return TUBER_EINVAL;
         if (x.amode == A_BN_RELU && (!x.a_scale || !x.a_shift)) return TUBER_EINVAL;
-        GemmTN& p = g.p[i];
+        const int big = tn_big(x.N, x.K) ? 1 : 0;
+        GemmTNGroup& g = gs[big];
+        GemmTN& p = g.p[cnt[big]];
         p.G = (const bf16*)x.G; p.ldg = x.ldg; p.A = (const bf16*)x.A; p.lda = x.lda;
         p.M = x.M; p.N = x.N; p.K = x.K;
         p.rows_per_slab = tn_rows_per_slab(x.M, x.N, x.K);
@@ -1289,12 +1520,18 @@ int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
         p.A2 = (const bf16*)x.A2; p.lda2 = x.lda2;
         p.gather = x.gather; p.To = x.To; p.Ho = x.Ho; p.Wo = x.Wo; p.Ti = x.Ti; p.Hi = x.Hi; p.Wi = x.Wi; p.st = x.st; p.ss = x.ss;
         p.amode = x.amode;
-        g.begin[i] = total;
-        total += ceil_div(x.N, 64) * ceil_div(x.K, 64) * p.S;
+        const int T = big ? 128 : 64;
+        g.begin[cnt[big]] = total[big];
+        total[big] += ceil_div(x.N, T) * ceil_div(x.K, T) * p.S;
+        ++cnt[big];
     }
-    for (int i = n; i <= TN_GROUP_MAX; ++i) g.begin[i] = total;
-    g.n = n;
-    hipLaunchKernelGGL(gemm_tn2_group_kernel, dim3(total), dim3(256), 0, stream, g);
+    for (int k = 0; k < 2; ++k) {
+        if (!cnt[k]) continue;
+        for (int i = cnt[k]; i <= TN_GROUP_MAX; ++i) gs[k].begin[i] = total[k];
+        gs[k].n = cnt[k];
+        if (k) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(total[k]), dim3(256), 0, stream, gs[k]);
+        else hipLaunchKernelGGL(gemm_tn2_group_kernel, dim3(total[k]), dim3(256), 0, stream, gs[k]);
+    }
     TUBER_RETURN_LAUNCH();
 }
 

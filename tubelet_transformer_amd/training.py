@@ -169,6 +169,7 @@ class GraphedTrainStep:
         # reductions per bottleneck where the captured backward flushes twice): sizes every workspace, builds the reduce tables and
         # the loss-weight / hyper-parameter device tables.  Rolled back afterwards -- a capture is not an optimisation step.
         snap = _Snapshot(model, store, opt)
+        store.no_late = ddp                          # the capture runs with the reducer: the warm-up must take the same launch sequence
         store.reducer = red if in_graph else None
         if in_graph:
             red.dry = True                           # hooks fire (same deferred-reduce flush points as the capture), nothing is sent
