@@ -960,3 +960,61 @@ def test_gemm_nt_addproj_and_its_weight_gradient(dev, M, N, K, add_cols):
     gb = db.view(max(S, 1), add_cols).sum(0)
     close("addproj dW", got, g[:, :add_cols].float().t() @ xs.float(), rel=4e-3)
     close("addproj dbias", gb, g[:, :add_cols].float().sum(0), abs_=2e-3 * float(g.float().abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("N,T,H,W,C,R", [(2, 8, 16, 22, 256, 88), (2, 4, 16, 22, 512, 44), (1, 6, 9, 21, 64, 7), (2, 16, 32, 43, 128, 64)])
+def test_dwconv_tile_backward_with_bn_backward_folded_in(dev, N, T, H, W, C, R):
+    """tuber_dwconv_tile_bwd_{data,weight}_bn: the BatchNorm backward of the layer above (dc3 = cA*dz3 + cB*c3 + cC, coefficients from R
+    partial rows) formed inside the depthwise backward kernels == tuber_bn_bwd_fa followed by the plain kernels, up to the bf16
+    rounding of the dc3 tensor the unfused path stores (the fused path keeps it in fp32): compared against fp32 torch math of the
+    composite; dgamma / dbeta of the folded BatchNorm identical to the stand-alone kernel's"""
+    M = N * T * H * W
+    dz3 = rnd(M, C, dev=dev, seed=1).to(BF)
+    c3 = (rnd(M, C, dev=dev, seed=2) * 1.5 + 0.3).to(BF)
+    c1 = rnd(M, C, dev=dev, seed=3).to(BF)
+    w = rnd(C, 27, dev=dev, seed=4) / 5
+    sc1, sh1 = 1.0 + 0.2 * rnd(C, dev=dev, seed=5), 0.3 * rnd(C, dev=dev, seed=6)
+    gamma = 1.0 + 0.1 * rnd(C, dev=dev, seed=7)
+    mean, invstd = 0.3 + 0.1 * rnd(C, dev=dev, seed=8), 1.0 / (1.5 + 0.1 * rnd(C, dev=dev, seed=9).abs())
+    # partial rows whose column sums are the true statistics (split unevenly over R rows)
+    s_dz, s_dzx = dz3.float().sum(0), (dz3.float() * c3.float()).sum(0)
+    wts = torch.rand(R, 1, device=dev) + 0.1
+    wts = wts / wts.sum()
+    st0, st1 = (wts * s_dz).contiguous(), (wts * s_dzx).contiguous()
+    # fp32 reference of the composite
+    xhat_sum = (s_dzx - mean * s_dz) * invstd
+    cA, cB = gamma * invstd, -gamma * invstd * invstd * (xhat_sum / M)
+    cC = -cB * mean - gamma * invstd * (s_dz / M)
+    dc3 = cA * dz3.float() + cB * c3.float() + cC
+    a1 = bfr((c1.float() * sc1 + sh1).relu()).view(N, T, H, W, C).permute(0, 4, 1, 2, 3)
+    a1 = a1.detach().requires_grad_(True)
+    wt = w.view(C, 1, 3, 3, 3).detach().requires_grad_(True)
+    out = F.conv3d(a1, wt, padding=1, groups=C)
+    out.backward(dc3.view(N, T, H, W, C).permute(0, 4, 1, 2, 3))
+    mask = ((c1.float() * sc1 + sh1) > 0).view(N, T, H, W, C)
+    dz1_ref = a1.grad.permute(0, 2, 3, 4, 1) * mask
+    dw_ref = wt.grad.view(C, 27)
+    # fused kernels
+    dg, db = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
+    Rb = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+    o0, o1 = torch.empty(Rb, C, device=dev), torch.empty(Rb, C, device=dev)
+    dz1 = torch.empty(M, C, device=dev, dtype=BF)
+    lib.call("tuber_dwconv_tile_bwd_data_bn", dz3, c3, st0, st1, R, float(M), gamma, mean, invstd, dg, db, w, c1, sc1, sh1, dz1, o0, o1, N, T, H, W, C)
+    close("dw bwd data with bn3 folded in", dz1.view(N, T, H, W, C), dz1_ref)
+    close("bn3 dgamma", dg - 0.5, xhat_sum, rel=1e-4, abs_=1e-3 * float(xhat_sum.abs().max()))
+    close("bn3 dbeta", db - 0.25, s_dz, rel=1e-4, abs_=1e-3 * float(s_dz.abs().max()))
+    close("dz1 stats sum", o0.sum(0), dz1_ref.reshape(M, C).sum(0), abs_=2e-3 * float(dz1_ref.abs().sum(dim=(0, 1, 2, 3)).max()))
+    nb = lib.query("tuber_dwconv_tile_wgrad_blocks", N, T, H, W, C)
+    part = torch.empty(nb * 27 * C, device=dev)
+    dwg = torch.zeros(C, 27, device=dev)
+    lib.call("tuber_dwconv_tile_bwd_weight_bn", dz3, c3, st0, st1, R, float(M), gamma, mean, invstd, c1, sc1, sh1, part, dwg, 0, N, T, H, W, C)
+    close("dw weight gradient with bn3 folded in", dwg, dw_ref, rel=3e-3, abs_=3e-3 * float(dw_ref.abs().max()))
+    # the unfused sequence agrees to the rounding of its bf16 dc3
+    dc3_t = torch.empty(M, C, device=dev, dtype=BF)
+    dg2, db2 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
+    if C % 128 == 0:
+        lib.call("tuber_bn_bwd_fa", st0, st1, R, C, float(M), gamma, mean, invstd, dg2, db2, dz3, c3, dc3_t, M)
+        assert torch.equal(dg2, dg) and torch.equal(db2, db)        # same fp64 derivation
+        dz1_u = torch.empty(M, C, device=dev, dtype=BF)
+        lib.call("tuber_dwconv_tile_bwd_data", dc3_t, w, c1, sc1, sh1, dz1_u, o0, o1, N, T, H, W, C)
+        close("fused vs unfused dz1", dz1, dz1_u.float(), rel=2 ** -6)

@@ -26,6 +26,7 @@ BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: Ba
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
+BN3_IN_DW = not os.environ.get("TUBER_NO_BN3_IN_DW")       # A/B switch: bn3's backward apply formed inside the depthwise backward kernels (no bn_bwd_fa launch, no dc3 tensor)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
@@ -458,22 +459,34 @@ class CSNRunner:
             if f["w4"]:
                 self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
             dc3 = None
+            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
+            # bn3's backward apply (dc3 = cA*dz3 + cB*c3 + cC) is formed INSIDE the two depthwise backward kernels of the stride-1 blocks
+            # while they load their gradient operand: every workgroup derives the coefficients of its 64 channels from the partial rows
+            # of the conv4 data-gradient GEMM -- the bn_bwd_fa launch and the dc3 round trip through HBM disappear
+            R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
+            fuse3 = (BN3_IN_DW and tile and depth >= 5 and P % 64 == 0 and not wq.hold
+                     and (R3 <= self._fa_max or lib.query("tuber_stat_rows_reduced", R3) <= self._fa_max))
             if depth >= 3:
-                R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
-                s0, s1 = self.ws("st0", R3 * P), self.ws("st1", R3 * P)
+                s0, s1 = self.ws("st0u" if fuse3 else "st0", R3 * P), self.ws("st1u" if fuse3 else "st1", R3 * P)
                 dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
                 lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                          2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
-                dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
+                if fuse3:
+                    bs0, bs1, bR = (s0, s1, R3) if R3 <= self._fa_max else self._stat_rows(s0, s1, R3, P)
+                    bn3 = (dz3, c3, bs0, bs1, bR, float(Mout), b3.gamma, b3.mean, b3.invstd)
+                else:
+                    dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
-            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
             if f["w3"]:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
 
-                def dw_wgrad(dc3=dc3, c1=c1, b1=b1, part=part, acc=acc, d=d, nb=nb, tile=tile, geo=(B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)):
+                def dw_wgrad(dc3=dc3, c1=c1, b1=b1, part=part, acc=acc, d=d, nb=nb, tile=tile, geo=(B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss),
+                             bn3=bn3 if fuse3 else None):
                     B_, Ti_, Hi_, Wi_, To_, Hq_, Wq_, P_, st_, ss_ = geo
-                    if tile:
+                    if bn3 is not None:
+                        lib.call("tuber_dwconv_tile_bwd_weight_bn", *bn3, c1, b1.scale, b1.shift, part, d["g3"], acc, B_, Ti_, Hi_, Wi_, P_)
+                    elif tile:
                         lib.call("tuber_dwconv_tile_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B_, Ti_, Hi_, Wi_, P_)
                     else:
                         lib.call("tuber_dwconv_bwd_weight", dc3, c1, b1.scale, b1.shift, part, d["g3"], acc, B_, Ti_, Hi_, Wi_,
@@ -490,7 +503,10 @@ class CSNRunner:
                 R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
                 s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
                 dz1 = torch.empty(Min, P, dtype=BF, device=dev)
-                if tile:
+                if fuse3:
+                    lib.call("tuber_dwconv_tile_bwd_data_bn", *bn3, b3.dgamma if f["bn3"] else None, b3.dbeta if f["bn3"] else None,
+                             d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
+                elif tile:
                     lib.call("tuber_dwconv_tile_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
                 else:
                     lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)

@@ -41,10 +41,18 @@ struct TileArgs {
     const bf16* aux;       // bwd data: x at the output position (mask + statistics);  wgrad: gout
     float* st0; float* st1;   // partial statistics rows [gridDim.x][C]
     float* P;              // wgrad partials [gridDim.x][27][C]
+    // BNG variants: the gradient operand (bwd data: the staged tensor; wgrad: the side input) is not read from HBM as a finished
+    // tensor but FORMED on load as cA*dzu + cB*xu + cC -- the BatchNorm backward of the layer above (bn3): dzu = its masked output
+    // gradient (`in` resp. `aux`), xu = its input (the raw depthwise-conv output c3), coefficients derived by every workgroup for
+    // its 64 channels from the R partial rows (sum dz, sum dz*x) like tuber_bn_bwd_fa does
+    const bf16* xu;
+    const float* bst0; const float* bst1; int bR; float bcount;
+    const float* bgamma; const float* bmean; const float* binvstd;
+    float* bdgamma; float* bdbeta;      // accumulated (+=) by the workgroups with blockIdx.x == 0 when not NULL
     TileGeom g;
 };
 
-template <int MODE>
+template <int MODE, bool BNG = false>
 __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
     const TileGeom g = a.g;
@@ -79,14 +87,23 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     }
     const long plane_elems = (long)g.H * g.W * g.C;
     const bf16* in_n = a.in + (long)n * g.T * plane_elems;
+    constexpr bool STG2 = BNG && MODE == M_BWD_DATA;        // the staged tensor is formed from two tensors
+    const bf16* in2_n = STG2 ? a.xu + (long)n * g.T * plane_elems : nullptr;
     uint2 regs[NLD], regs_a[NLD], regs_b[NLD];     // regs: the steady-state prefetch set; _a / _b: the two extra planes of the prologue
-    auto fetch = [&](int t, uint2 (&regs)[NLD]) {  // input plane t -> registers (zeros outside the volume)
+    uint2 regx[STG2 ? NLD : 1], regx_a[STG2 ? NLD : 1], regx_b[STG2 ? NLD : 1];
+    auto fetch = [&](int t, uint2 (&regs)[NLD], uint2 (&rx)[STG2 ? NLD : 1]) {  // input plane t -> registers (zeros outside the volume)
         const bool tok = t >= 0 && t < g.T;
         const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) regs[i] = (tok && s_ok[i]) ? *(const uint2*)(p + s_off[i]) : make_uint2(0, 0);
+        if constexpr (STG2) {
+            const bf16* p2 = in2_n + (long)(tok ? t : 0) * plane_elems;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) rx[i] = (tok && s_ok[i]) ? *(const uint2*)(p2 + s_off[i]) : make_uint2(0, 0);
+        }
     };
-    auto park = [&](int t, const uint2 (&regs)[NLD]) {   // registers -> activated fp32 in ring slot t mod 3
+    float kA[4] = {1.f, 1.f, 1.f, 1.f}, kB[4] = {0.f, 0.f, 0.f, 0.f}, kC[4] = {0.f, 0.f, 0.f, 0.f};     // BNG: this thread's channel quad
+    auto park = [&](int t, const uint2 (&regs)[NLD], const uint2 (&rx)[STG2 ? NLD : 1]) {   // registers -> activated fp32 in ring slot t mod 3
         const bool tok = t >= 0 && t < g.T;
         float* dst = smem + ((t + 3) % 3) * PLANE;
 #pragma unroll
@@ -94,7 +111,14 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
             if (s_lds[i] < 0) continue;
             const bf16x4 v = as_bf16x4(regs[i]);
             float4 o;
-            if (act) {
+            if constexpr (STG2) {
+                const bool ok = tok && s_ok[i];          // the gradient is zero outside the volume (cC must not leak into the padding)
+                const bf16x4 u = as_bf16x4(rx[i]);
+                o.x = ok ? fmaf(kA[0], bf2f(v[0]), fmaf(kB[0], bf2f(u[0]), kC[0])) : 0.f;
+                o.y = ok ? fmaf(kA[1], bf2f(v[1]), fmaf(kB[1], bf2f(u[1]), kC[1])) : 0.f;
+                o.z = ok ? fmaf(kA[2], bf2f(v[2]), fmaf(kB[2], bf2f(u[2]), kC[2])) : 0.f;
+                o.w = ok ? fmaf(kA[3], bf2f(v[3]), fmaf(kB[3], bf2f(u[3]), kC[3])) : 0.f;
+            } else if (act) {
                 const bool ok = tok && s_ok[i];
                 o.x = ok ? fmaxf(fmaf(bf2f(v[0]), sa[0], sb[0]), 0.f) : 0.f;
                 o.y = ok ? fmaxf(fmaf(bf2f(v[1]), sa[1], sb[1]), 0.f) : 0.f;
@@ -109,9 +133,49 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
 
     // ---- all three planes of the prologue go out together (one memory latency instead of three dependent fetch -> park rounds:
     // the short-T stages run one output plane per workgroup, so the prologue IS the kernel) ----
-    fetch(t0 - 1, regs_a);
-    fetch(t0, regs_b);
-    fetch(t0 + 1, regs);
+    fetch(t0 - 1, regs_a, regx_a);
+    fetch(t0, regs_b, regx_b);
+    fetch(t0 + 1, regs, regx);
+
+    // ---- BNG: coefficients of the BatchNorm backward above, derived under the latency of the fetches just issued ----
+    if constexpr (BNG) {
+        double* red = (double*)smem;                     // [2][32][64] in the (still empty) ring
+        float* coef = smem + 3 * PLANE + 27 * 64;        // [3][64] behind the filter taps
+        {
+            const int q = tid & 15, rg = tid >> 4;       // 16 channel quads x 32 row groups
+            double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+            const float* p0 = a.bst0 + c0 + q * 4;
+            const float* p1 = a.bst1 + c0 + q * 4;
+            for (int r = rg; r < a.bR; r += 32) {
+                const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
+                sa[0] += u.x; sa[1] += u.y; sa[2] += u.z; sa[3] += u.w;
+                sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[(0 * 32 + rg) * 64 + q * 4 + e] = sa[e]; red[(1 * 32 + rg) * 64 + q * 4 + e] = sb[e]; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { sa += red[(0 * 32 + k) * 64 + tid]; sb += red[(1 * 32 + k) * 64 + tid]; }
+            const int cc = c0 + tid;
+            const double mu = a.bmean[cc], rr = a.binvstd[cc], gm = a.bgamma[cc];
+            const double sum_dz = sa, sum_dz_xhat = (sb - mu * sa) * rr;
+            const double m1 = sum_dz / a.bcount, m2 = sum_dz_xhat / a.bcount;
+            coef[0 * 64 + tid] = (float)(gm * rr);
+            coef[1 * 64 + tid] = (float)(-gm * rr * rr * m2);
+            coef[2 * 64 + tid] = (float)(gm * rr * rr * m2 * mu - gm * rr * m1);
+            if (blockIdx.x == 0 && a.bdgamma) {
+                a.bdgamma[cc] += (float)sum_dz_xhat;
+                a.bdbeta[cc] += (float)sum_dz;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kA[e] = coef[0 * 64 + cl * 4 + e]; kB[e] = coef[1 * 64 + cl * 4 + e]; kC[e] = coef[2 * 64 + cl * 4 + e]; }
+        __syncthreads();                                  // the ring is written next
+    }
 
     // ---- filter taps of this thread's 4 channels (bwd data: flipped) ----
     // filter taps [27][64] stay in LDS behind the ring (bwd data: flipped); every lane group reads its quad as a broadcast --
@@ -140,27 +204,33 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
     const bool row_ok = ho < g.H;
     // side inputs of an output plane (global, 8 B per column): bwd data: x (needed after the taps);  wgrad: gout (needed BEFORE the
     // taps -- so the weight gradient fetches them one plane ahead, the first ones together with the prologue planes)
-    auto side_fetch = [&](int t, uint2 (&sd)[4]) {
+    constexpr bool SD2 = BNG && MODE == M_BWD_WEIGHT;     // the side input (gout at the output position) is formed from two tensors
+    auto side_fetch = [&](int t, uint2 (&sd)[4], uint2 (&sx)[SD2 ? 4 : 1]) {
         const long ob = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            sd[j] = (row_ok && wo0 + j < g.W) ? *(const uint2*)(a.aux + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = row_ok && wo0 + j < g.W;
+            sd[j] = ok ? *(const uint2*)(a.aux + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+            if constexpr (SD2) sx[j] = ok ? *(const uint2*)(a.xu + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+        }
     };
     uint2 side_nx[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
-    if constexpr (MODE == M_BWD_WEIGHT) side_fetch(t0, side_nx);
-    park(t0 - 1, regs_a);
-    park(t0, regs_b);
+    uint2 sidx_nx[SD2 ? 4 : 1];
+    if constexpr (MODE == M_BWD_WEIGHT) side_fetch(t0, side_nx, sidx_nx);
+    park(t0 - 1, regs_a, regx_a);
+    park(t0, regs_b, regx_b);
     for (int t = t0; t < t1; ++t) {
-        park(t + 1, regs);
-        if (t + 1 < t1) fetch(t + 2, regs);
+        park(t + 1, regs, regx);
+        if (t + 1 < t1) fetch(t + 2, regs, regx);
         uint2 side[4];
+        uint2 sidx[SD2 ? 4 : 1];
         const long obase = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
         if constexpr (MODE == M_BWD_WEIGHT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) side[j] = side_nx[j];
-            if (t + 1 < t1) side_fetch(t + 1, side_nx);
+            for (int j = 0; j < 4; ++j) { side[j] = side_nx[j]; if constexpr (SD2) sidx[j] = sidx_nx[j]; }
+            if (t + 1 < t1) side_fetch(t + 1, side_nx, sidx_nx);
         } else if (MODE != M_FWD) {
-            side_fetch(t, side);
+            side_fetch(t, side, sidx);
         }
         __syncthreads();
         f32x2 acc[4][2];
@@ -171,8 +241,18 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bf16x4 v = as_bf16x4(side[j]);
-                gv[j][0] = f32x2{bf2f(v[0]), bf2f(v[1])};
-                gv[j][1] = f32x2{bf2f(v[2]), bf2f(v[3])};
+                if constexpr (SD2) {
+                    const bool ok = row_ok && wo0 + j < g.W;      // zero gradient outside the volume
+                    const bf16x4 u = as_bf16x4(sidx[j]);
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = ok ? fmaf(kA[e], bf2f(v[e]), fmaf(kB[e], bf2f(u[e]), kC[e])) : 0.f;
+                    gv[j][0] = f32x2{q[0], q[1]};
+                    gv[j][1] = f32x2{q[2], q[3]};
+                } else {
+                    gv[j][0] = f32x2{bf2f(v[0]), bf2f(v[1])};
+                    gv[j][1] = f32x2{bf2f(v[2]), bf2f(v[3])};
+                }
             }
         }
         auto tap_plane = [&](int dt) {
@@ -300,17 +380,17 @@ TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
     return g;
 }
 
-template <int MODE>
+template <int MODE, bool BNG = false>
 int launch_tile(TileArgs& a, hipStream_t stream) {
     const TileGeom& g = a.g;
     dim3 grid(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), block(512);
-    const size_t lds = (3 * PLANE + 27 * 64) * sizeof(float);       // ring + filter taps (wgrad reuses the ring for its reduction)
-    static bool attr_done[3] = {false, false, false};
-    if (!attr_done[MODE]) {                            // > 64 KB of dynamic LDS needs the opt-in once per kernel
-        hipFuncSetAttribute((const void*)dwconv_tile_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[MODE] = true;
+    const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);       // ring + filter taps + BNG coefficients (wgrad reuses the ring for its reduction)
+    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+    if (!attr_done[MODE][BNG]) {                            // > 64 KB of dynamic LDS needs the opt-in once per kernel
+        hipFuncSetAttribute((const void*)dwconv_tile_kernel<MODE, BNG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[MODE][BNG] = true;
     }
-    hipLaunchKernelGGL(dwconv_tile_kernel<MODE>, grid, block, lds, stream, a);
+    hipLaunchKernelGGL((dwconv_tile_kernel<MODE, BNG>), grid, block, lds, stream, a);
     TUBER_RETURN_LAUNCH();
 }
 
@@ -357,6 +437,39 @@ int tuber_dwconv_tile_bwd_weight(const void* gout, const void* x, const float* s
     a.g = make_geom(N, T, H, W, C, true);
     const int rc = launch_tile<M_BWD_WEIGHT>(a, stream);
     if (rc || accumulate == 2) return rc;      // accumulate == 2: partial blocks reduced later by tuber_multi_reduce
+    return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
+}
+
+// The two backward kernels with the BatchNorm backward of the layer ABOVE the depthwise conv (bn3) folded into their gradient
+// operand: instead of a finished dc3 they take bn3's masked output gradient dzu [M, C], bn3's input xu = c3 [M, C] and the R <= 128
+// partial rows (sum dz, sum dz*x) the producer of dzu wrote, derive cA / cB / cC for their 64 channels and form
+// dc3 = cA*dzu + cB*xu + cC (fp32) on load.  The stand-alone tuber_bn_bwd_fa launch and the dc3 tensor disappear.
+// dgamma / dbeta of bn3 (accumulated, +=) are written by the data-gradient kernel unless NULL.
+int tuber_dwconv_tile_bwd_data_bn(const void* dzu, const void* xu, const float* bst0, const float* bst1, int R, float count,
+                                  const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                  const float* w, const void* x, const float* sc, const float* sh, void* dz,
+                                  float* st0, float* st1, int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || !sc || !sh || R <= 0 || R > 128 || !bst0 || !bst1) return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)dzu; a.xu = (const bf16*)xu; a.sc = sc; a.sh = sh; a.w = w; a.out = (bf16*)dz; a.aux = (const bf16*)x;
+    a.st0 = st0; a.st1 = st1;
+    a.bst0 = bst0; a.bst1 = bst1; a.bR = R; a.bcount = count; a.bgamma = gamma; a.bmean = mean; a.binvstd = invstd;
+    a.bdgamma = dgamma; a.bdbeta = dbeta;
+    a.g = make_geom(N, T, H, W, C);
+    return launch_tile<M_BWD_DATA, true>(a, stream);
+}
+
+int tuber_dwconv_tile_bwd_weight_bn(const void* dzu, const void* xu, const float* bst0, const float* bst1, int R, float count,
+                                    const float* gamma, const float* mean, const float* invstd,
+                                    const void* x, const float* sc, const float* sh, float* partial, float* dw, int accumulate,
+                                    int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || !sc || !sh || R <= 0 || R > 128 || !bst0 || !bst1) return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.aux = (const bf16*)dzu; a.xu = (const bf16*)xu; a.P = partial;
+    a.bst0 = bst0; a.bst1 = bst1; a.bR = R; a.bcount = count; a.bgamma = gamma; a.bmean = mean; a.binvstd = invstd;
+    a.g = make_geom(N, T, H, W, C, true);
+    const int rc = launch_tile<M_BWD_WEIGHT, true>(a, stream);
+    if (rc || accumulate == 2) return rc;
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
 }
 

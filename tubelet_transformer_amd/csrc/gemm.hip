@@ -1388,19 +1388,31 @@ extern "C" {
 static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
 // 128 x 128 transpose-read tiles (gemm_tn3): layer3 / layer4 convs, FFN and class-branch linears, packed in-projections
 static int g_tn_big = -1;
-static bool tn_big(int N, int K) {
+// Measured (scripts/gemm_bench.py tngroup, round 3): eight layer3 problems 68.2 -> 50.9 us, six layer4 ones 87.5 -> 82.6 us; but the
+// long-M class-branch pair (M = 16896: few tiles x few slabs underfill the chip at two workgroups per CU) 132 -> 224 us and the
+// short-M encoder FFNs (M = 704: 11 steps) 13.5 -> 20.8 us -- so only the mid-M backbone shapes take the big tiles.
+static bool tn_big(int M, int N, int K) {
     if (g_tn_big < 0) { const char* e = getenv("TUBER_TN_NO_BIG_TILES"); g_tn_big = e ? 0 : 1; }      // A/B switch
-    return g_tn_big && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
+    return g_tn_big && M >= 2048 && M <= 8192 && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
 }
 static int tn_slabs_wanted(int M, int N, int K) {
-    const int T = tn_big(N, K) ? 128 : tn_tile(N, K);
+    const int T = tn_big(M, N, K) ? 128 : tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
     static int target = -1;
     // workgroups aimed for per GEMM: 256 since the weight gradients travel in grouped launches (tuber_gemm_tn_group: 2-8 GEMMs share the
     // chip, so each needs fewer slabs to fill it: 18.87 -> 18.65 ms/step against 512, and half the slab traffic; 128 loses again)
     if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 256; }
-    // big tiles: a workgroup does 4x the work and two are resident per CU -> a quarter of the workgroups per GEMM
-    long S = ((tn_big(N, K) ? target / 4 : target) + tiles - 1) / tiles;
+    // big tiles: ~22 steps of 64 rows per workgroup measured best on both backbone shapes (layer3 M = 5632: 4 slabs 51 us per eight
+    // problems against 56 us with 8 and 75 with 15; layer4 M = 2816: 2 slabs 72 us per six against 82 us with 1) -- fewer steps do not
+    // amortise the 64 KB prologue / 64 KB fp32 epilogue of a tile, more leave the chip underfilled
+    long S;
+    if (tn_big(M, N, K)) {
+        static int big_rows = -1;
+        if (big_rows < 0) { const char* e = getenv("TUBER_TN_BIG_ROWS"); big_rows = e ? atoi(e) : 1408; }
+        S = (M + big_rows / 2) / big_rows;
+    } else {
+        S = (target + tiles - 1) / tiles;
+    }
     // bound the fp32 slab traffic (S*N*K*4 B written + read) by the size of the operands (2*M*(N+K) B);
     // tiny outputs (<= 16 tiles: <= 256 KB per slab) may split deeply
     long cap = tiles <= 16 ? 256 : (long)M * (N + K) / (2L * N * K);
@@ -1453,7 +1465,7 @@ int tuber_gemm_tn(const void* G, long ldg, const void* A, long lda, float* parti
     const int use_tr = 1;
     p.bias_grad = nullptr;
     if (bias_grad && !tuber_gemm_tn_fuses_bias(M, N, K, ldg, lda)) return TUBER_EINVAL;
-    if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7) && tn_big(N, K)) {     // ... on 128 x 128 tiles
+    if (T == 64 && !gmode && use_tr && !((N | K | ldg | lda) & 7) && tn_big(M, N, K)) {     // ... on 128 x 128 tiles
         p.bias_grad = bias_grad;
         const dim3 grid3(ceil_div(N, 128) * ceil_div(K, 128) * p.S);
         if (amode == A_BN_RELU) hipLaunchKernelGGL(gemm_tn3_kernel<A_BN_RELU>, grid3, block, 0, stream, p);
@@ -1503,7 +1515,7 @@ int tuber_gemm_tn_group(const void* args_host, int n, hipStream_t stream) {
         if (x.M <= 0 || x.N <= 0 || x.K <= 0 || ((x.N | x.K | x.ldg | x.lda) & 7) || x.ldg < x.N || x.lda < x.K) return TUBER_EINVAL;
         if (tn_tile(x.N, x.K) != 64 || (x.amode != A_PLAIN && x.amode != A_BN_RELU)) return TUBER_EINVAL;
         if (x.amode == A_BN_RELU && (!x.a_scale || !x.a_shift)) return TUBER_EINVAL;
-        const int big = tn_big(x.N, x.K) ? 1 : 0;
+        const int big = tn_big(x.M, x.N, x.K) ? 1 : 0;
         GemmTNGroup& g = gs[big];
         GemmTN& p = g.p[cnt[big]];
         p.G = (const bf16*)x.G; p.ldg = x.ldg; p.A = (const bf16*)x.A; p.lda = x.lda;

@@ -46,6 +46,11 @@ DOC = {
                                 "gradient buffer with no bucket copies; stream-ordered, capturable into a hipGraph.",
     "tuber_comm_allreduce_sum_multi": "the same for n windows (HOST arrays ptrs[n], counts[n]) as ONE RCCL group.",
     "tuber_comm_destroy": "ncclCommDestroy.",
+    "tuber_dwconv_tile_bwd_data_bn": "tuber_dwconv_tile_bwd_data with the BatchNorm backward of bn3 (autograd of nn.BatchNorm3d, ir_CSN_152.py:56,76-77) folded into its "
+                                     "gradient operand: takes bn3's masked output gradient dzu, bn3's input xu (= c3) and the R <= 128 partial rows (sum dz, sum dz*x) "
+                                     "instead of a finished dc3; every workgroup derives cA / cB / cC of its 64 channels (fp64) and forms dc3 = cA*dzu + cB*xu + cC "
+                                     "in fp32 while staging. dgamma / dbeta of bn3 are accumulated (+=) unless NULL. Replaces tuber_bn_bwd_fa + tuber_dwconv_tile_bwd_data.",
+    "tuber_dwconv_tile_bwd_weight_bn": "tuber_dwconv_tile_bwd_weight with the same fold: the output-position gradient is formed from (dzu, xu, partial rows) on load.",
     "tuber_comm_init_timeout": "tuber_comm_init with a deadline: the bootstrap (a collective) runs on a helper thread and the call returns -3 with a message naming "
                                "the waiting rank when its peers have not arrived after timeout_ms -- a dead rank fails the job loudly instead of hanging it "
                                "(what torch.distributed's process-group timeout does for the reference, pipelines/launch.py:44-49). timeout_ms <= 0: no deadline.",

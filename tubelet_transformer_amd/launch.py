@@ -23,24 +23,36 @@ import torch.multiprocessing as mp
 def get_local_ip_and_match(ip_list):
     """index of this host in ``ip_list`` (pipelines/launch.py:8-17), -1 if absent.  The address is taken from the route towards
     the first peer (a UDP connect sends nothing), falling back to the host name's addresses on an isolated node."""
-    mine = set()
-    for peer in list(ip_list) + ["8.8.8.8"]:
+    # the reference matches ONE address: the source of the route to a public host (pipelines/launch.py:9-13).  Here: the source
+    # address of the route towards the first OTHER entry of the list (no packet is sent by a UDP connect), then the public route,
+    # then the host name's addresses; the loopback address only counts when nothing else was found (single isolated node).  More
+    # than one matching entry -- a multi-homed host listed twice, a list that contains 127.0.0.1 next to real addresses -- would hand
+    # the same WORLD_RANK to two nodes: that is an error, not index 0.
+    def route_source(peer):
         try:
             s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
             s.connect((peer, 80))
-            mine.add(s.getsockname()[0])
+            ip = s.getsockname()[0]
             s.close()
+            return ip
         except OSError:
-            pass
-    try:
-        mine.update(socket.gethostbyname_ex(socket.gethostname())[2])
-    except OSError:
-        pass
-    mine.add("127.0.0.1")
-    for i, ip in enumerate(ip_list):
-        if ip in mine:
-            return i
-    return -1
+            return None
+    mine = []
+    for peer in list(ip_list) + ["8.8.8.8"]:
+        ip = route_source(peer)
+        if ip and not ip.startswith("127.") and ip not in mine:
+            mine.append(ip)
+    if not mine:
+        try:
+            mine = [ip for ip in socket.gethostbyname_ex(socket.gethostname())[2] if not ip.startswith("127.")]
+        except OSError:
+            mine = []
+    hits = [i for i, ip in enumerate(ip_list) if ip in mine]
+    if not hits:                         # no real address of this host is listed: a loopback entry means "this node"
+        hits = [i for i, ip in enumerate(ip_list) if ip.startswith("127.")]
+    if len(hits) > 1:
+        raise RuntimeError("AUTO_RANK_MATCH: this host's addresses %s match %d entries of WOLRD_URLS %s" % (mine, len(hits), list(ip_list)))
+    return hits[0] if hits else -1
 
 
 def main_worker(gpu, ngpus_per_node, main, cfg, from_env=False):
