@@ -18,7 +18,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts: RCCL needs it before the runtime starts
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -57,7 +59,9 @@ def alg_cost(name, a):
         return "gemm_tn_kernel<%d,%d,%d>" % (a[10], T, 1 if gmode else 0), 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
     if name == "tuber_gemm_tn_group":
         by = sum(2 * e.M * (e.N + e.K) + 4 * e.N * e.K for e in a[0])
-        return "gemm_tn2_group_kernel", by, sum(2 * e.M * e.N * e.K for e in a[0])
+        tiles = {lib.query("tuber_gemm_tn_tile", e.M, e.N, e.K) for e in a[0]}
+        key = "gemm_tn3_group_kernel" if tiles == {128} else "gemm_tn2_group_kernel" if tiles == {64} else "gemm_tn2+tn3_group_kernels"
+        return key, by, sum(2 * e.M * e.N * e.K for e in a[0])
     if name in ("tuber_dwconv_fwd", "tuber_dwconv_bwd_data", "tuber_dwconv_bwd_weight"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
         N, Ti, Hi, Wi, To, Ho, Wo, C, st, ss = a[off:off + 10]
@@ -67,6 +71,14 @@ def alg_cost(name, a):
         key = {"tuber_dwconv_fwd": "dwconv_fwd_kernel<%d>" % ss, "tuber_dwconv_bwd_data": "dwconv_bwd_data_kernel<%d>" % ss,
                "tuber_dwconv_bwd_weight": "dwconv_bwd_weight_kernel<%d>" % ss}[name]
         return key, by, 2 * 27 * C * N * To * Ho * Wo
+    if name == "tuber_bn_bwd_fa":
+        return "bn_bwd_fa_kernel", 2 * 3 * a[13] * a[3], 0
+    if name == "tuber_dwconv_tile_bwd_data_bn":
+        N, T, H, W, C = a[18:23]
+        return "dwconv_tile_kernel<1,true>", 2 * C * N * T * H * W * 4, 2 * 27 * C * N * T * H * W
+    if name == "tuber_dwconv_tile_bwd_weight_bn":
+        N, T, H, W, C = a[15:20]
+        return "dwconv_tile_kernel<2,true>", 2 * C * N * T * H * W * 3, 2 * 27 * C * N * T * H * W
     if name in ("tuber_dwconv_tile_fwd", "tuber_dwconv_tile_bwd_data", "tuber_dwconv_tile_bwd_weight"):
         off = 8 if name == "tuber_dwconv_tile_bwd_data" else 7
         N, T, H, W, C = a[off:off + 5]
@@ -106,7 +118,7 @@ def shape_of(name, a):
                 "tuber_reduce_rows", "tuber_colsum", "tuber_reduce_slabs", "tuber_layernorm_fwd", "tuber_layernorm_bwd", "tuber_dropout"):
         return " ".join(str(x) for x in a if isinstance(x, int) and not isinstance(x, bool))[:44]
     if name.startswith("tuber_dwconv_tile"):
-        off = 8 if name == "tuber_dwconv_tile_bwd_data" else 7
+        off = {"tuber_dwconv_tile_bwd_data": 8, "tuber_dwconv_tile_bwd_data_bn": 18, "tuber_dwconv_tile_bwd_weight_bn": 15}.get(name, 7)
         return "N%d %dx%dx%d C%d" % tuple(a[off:off + 5])
     if name.startswith("tuber_dwconv"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]

@@ -1424,6 +1424,8 @@ static int tn_slabs_wanted(int M, int N, int K) {
     return (int)S;
 }
 static int tn_rows_per_slab(int M, int N, int K) { return ceil_div(ceil_div(M, tn_slabs_wanted(M, N, K)), 64) * 64; }
+// output tile edge the transpose-read kernels use for (M, N, K): 128 (gemm_tn3) or 64 (gemm_tn2); profiling / bench bookkeeping
+int tuber_gemm_tn_tile(int M, int N, int K) { return tn_big(M, N, K) ? 128 : 64; }
 // slabs actually written (rows per slab are rounded up to 64, so this can be fewer than the split aimed for)
 int tuber_gemm_tn_slabs(int M, int N, int K) { return ceil_div(M, tn_rows_per_slab(M, N, K)); }
 

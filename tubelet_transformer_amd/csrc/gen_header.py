@@ -83,6 +83,7 @@ DOC = {
                      "backward mask from the saved activation). Accumulators are scaled by alpha first; epi 0 can end with Dropout(drop_p) "
                      "keyed by (seed, salt, m*N+n) -- FFN linear1 (transformer.py:160-162). K % 64 == 0.",
     "tuber_gemm_nt_cfg": "tile configuration tuber_gemm_nt uses for (M,N,K): 13 = 64x64 (two-tile prefetch), 7 = 64x128, 0 = 128x128 (plain epilogue only); 2 / 12 / 17 = rejected A/B variants, built only with -DTUBER_AB_VARIANTS.",
+    "tuber_gemm_tn_tile": "output tile edge of the transpose-read weight-gradient kernel for (M, N, K): 128 (mid-M backbone shapes, N and K multiples of 128) or 64.",
     "tuber_gemm_nt_has_cfg": "1 when tuber_gemm_nt_set_cfg(cfg) names a tile configuration this library was built with.",
     "tuber_gemm_nt_stat_rows": "rows of partial statistics tuber_gemm_nt(epi 1|2) writes for (M,N).",
     "tuber_gemm_tn": "dW[N,K] (+)= sum_m G[m,N]^T . f(A)[m,K]: weight gradient of the same convs / linears (autograd of the ops above); "
