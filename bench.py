@@ -495,7 +495,7 @@ def main():
             kt = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_trace_stats.txt")) if not re.search(r"_(cfg\d|freeze)_", os.path.basename(f)))
             if kt and headline:
                 for ln in open(kt[-1]).read().splitlines()[2:]:
-                    if re.sub(r"\s+", "", ln).replace("void", "", 1).startswith(re.sub(r"\s+", "", dominant)):
+                    if re.sub(r"\s+", "", dominant) in re.sub(r"\s+", "", ln.split("  ")[0]):
                         rp_avg = float(ln.split()[-4])
                         break
         except Exception:

@@ -5,6 +5,7 @@ on bf16-rounded operands with a bf16-rounded result, exact accumulation) is what
 path must stay within a small factor of THAT error on the same fixture -- written down per fixture in DESIGN.md section 4 -- in
 addition to the absolute caps.
 
+  config 1  TubeR_CSN50_AVA21   'decode'   1 x 3x32x224x224     eval forward (the CPU-plumbing config's geometry through the HIP path)
   config 2  TubeR_CSN50_AVA21   'decode'   2 x 3x32x256x340     eval forward + step properties
   config 3  TubeR_CSN152_AVA21  'avg'      2 x 3x32x256x340     eval forward, per-parameter backward vs oracle autograd
   config 4  TubeR_CSN152_AVA22  'decode'   1 x 3x32x256x340     eval forward
@@ -31,6 +32,7 @@ CAP = {"pred_logits": 5e-2, "pred_logits_b": 5e-2, "pred_boxes": 1e-2}
 K_ROUNDED, SLACK = 2.0, {"pred_logits": 4e-3, "pred_logits_b": 4e-3, "pred_boxes": 1e-3}
 
 FULL = {
+    "cfg1_csn50_decode_224": ("TubeR_CSN50_AVA21.yaml", 1, (224, 224), "ava"),      # BASELINE config 1's geometry: 14 x 14 grid = 196 tokens (not a multiple of 16)
     "cfg2_csn50_decode": ("TubeR_CSN50_AVA21.yaml", 2, (256, 340), "ava"),
     "cfg3_csn152_avg": ("TubeR_CSN152_AVA21.yaml", 2, (256, 340), "ava"),
     "cfg4_csn152_decode": ("TubeR_CSN152_AVA22.yaml", 1, (256, 340), "ava"),
