@@ -260,6 +260,7 @@ def timed_with_input_pipeline(step_fn, args, hw, dev, fence):
     T, H0, W0 = 32, 360, 480
     RH, RW = hw[0] + 32, hw[1] + 44
     frames = [np.ascontiguousarray(rng.integers(0, 256, (T, H0, W0, 3), dtype=np.uint8)) for _ in range(args.batch)]
+    pinned = [torch.from_numpy(f).pin_memory() for f in frames]      # what DataLoader(pin_memory=True) -> ClipBatch.pin_memory() hands over
     side = torch.cuda.Stream()
     main = torch.cuda.current_stream()
 
@@ -267,6 +268,7 @@ def timed_with_input_pipeline(step_fn, args, hw, dev, fence):
         clips = []
         for b, f in enumerate(frames):
             c = P.FrameClip(f)
+            c.pinned = pinned[b]
             c.resize((RW, RH))
             if (i + b) % 2:
                 c._hflip()
@@ -298,7 +300,7 @@ def timed_with_input_pipeline(step_fn, args, hw, dev, fence):
     fence()
     dt = time.perf_counter() - t0
     return {"ms_per_step": round(1e3 * dt / args.steps, 3), "seconds": dt,
-            "feed": "uint8 frames %dx%dx%dx%d on the host -> ClipBatch.to(device) on a side stream (H2D %.1f MB + resize to %dx%d + flip/crop/jitter/"
+            "feed": "page-locked uint8 frames %dx%dx%dx%d on the host (DataLoader pin_memory -> ClipBatch.pin_memory) -> ClipBatch.to(device) on a side stream (H2D %.1f MB + resize to %dx%d + flip/crop/jitter/"
                     "normalise/collate), one batch ahead" % (args.batch, T, H0, W0, args.batch * T * H0 * W0 * 3 / 1e6, RH, RW)}
 
 

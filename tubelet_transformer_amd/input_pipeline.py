@@ -92,6 +92,7 @@ class FrameClip:
         if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
             raise ValueError("FrameClip wants uint8 frames [T,H,W,3], got %s %s" % (frames.dtype, frames.shape))
         self.frames = frames
+        self.pinned = None               # page-locked torch view of the frames (ClipBatch.pin_memory: the DataLoader's pin thread)
         self.resize_hw = None
         self.oy, self.ox, self.sx = 0, 0, 1
         self.height, self.width = int(frames.shape[1]), int(frames.shape[2])
@@ -349,6 +350,15 @@ class ClipBatch:
     def __len__(self):
         return len(self.clips)
 
+    def pin_memory(self):
+        """``DataLoader(pin_memory=True)`` calls this on a custom batch object (in its pin thread, off the training loop): the uint8
+        frames move to page-locked memory once, so ``.to(device)`` is an asynchronous copy instead of a staged, host-blocking one --
+        what the reference gets for its fp32 NestedTensor from the same flag (datasets/ava_frame.py:279)."""
+        for c in self.clips:
+            if c.pinned is None:
+                c.pinned = torch.from_numpy(c.frames).pin_memory()
+        return self
+
     def to(self, device):
         device = torch.device(device)
         if device.type != "cuda":
@@ -371,7 +381,7 @@ class ClipBatch:
         for c, off in zip(clips, offs):
             H, W = c.frame_hw
             nbytes = T * H * W * 3
-            host = torch.from_numpy(c.frames)
+            host = c.pinned if c.pinned is not None else torch.from_numpy(c.frames)
             if c.resize_hw is None:
                 staging[off:off + nbytes].view(T, H, W, 3).copy_(host, non_blocking=True)
             else:
