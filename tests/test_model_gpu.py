@@ -486,6 +486,10 @@ def test_two_rank_bench_captures_the_graph_step(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["launch_mode"] == "hipgraph" and j["config"]["global_batch"] == 4
     assert j["value"] > 0 and math.isfinite(j["final_loss"])
+    # the diagnosability object of the N > 1 line: who carried the gradients, how much, in how many pieces
+    c = j["comm"]
+    assert c["world"] == 2 and "process group (gloo)" in c["transport"] and c["ranks_seen_by_rccl"] is None
+    assert c["windows_per_step"] >= 2 and c["bytes_per_step"] > 4 * 40e6 and "graph A" in c["launch"]
 
 
 @pytest.mark.gpu
