@@ -313,8 +313,8 @@ def lib_md5():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default 60 = ~1 s of GPU time: long enough for a 5 s SMI sampler to see it)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (reference: TRAIN.BATCH_SIZE 2)")
     ap.add_argument("--config", default="TubeR_CSN152_AVA21.yaml", help="BASELINE.json configs: TubeR_CSN50_AVA21.yaml (2), "
                     "TubeR_CSN152_AVA21.yaml (3, the headline), Tuber_CSN152_JHMDB.yaml (5: use --height 288 --width 384)")
