@@ -1018,3 +1018,44 @@ def test_dwconv_tile_backward_with_bn_backward_folded_in(dev, N, T, H, W, C, R):
         dz1_u = torch.empty(M, C, device=dev, dtype=BF)
         lib.call("tuber_dwconv_tile_bwd_data", dc3_t, w, c1, sc1, sh1, dz1_u, o0, o1, N, T, H, W, C)
         close("fused vs unfused dz1", dz1, dz1_u.float(), rel=2 ** -6)
+
+
+@pytest.mark.parametrize("M", [64 * 700, 64 * 37 + 29, 50])
+def test_conv4_bwd_fused(dev, M):
+    """tuber_conv4_bwd_fused (layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel)
+    against fp32 torch math of the three-kernel sequence it replaces: dc4 = bf16(cA*dz + cB*c4 + cC); dz3 = (dc4 . W4) masked by
+    relu'(bn3(c3)) with the per-64-row statistics rows; dW4 = dc4^T . bf16(relu(bn3(c3))) summed over the workgroup slabs.
+    Ragged M (last tile partly empty), fewer tiles than workgroups, and many tiles per workgroup."""
+    C4, P = 256, 64
+    assert lib.query("tuber_conv4_bwd_supported", C4, P) == 1 and lib.query("tuber_conv4_bwd_supported", 512, 128) == 0
+    dz = rnd(M, C4, dev=dev, seed=1).to(BF)
+    c4 = (rnd(M, C4, dev=dev, seed=2) * 1.3 + 0.2).to(BF)
+    c3 = rnd(M, P, dev=dev, seed=3).to(BF)
+    W4 = rnd(C4, P, dev=dev, seed=4, scale=P ** -0.5)                      # conv4.weight [C4][P]
+    ldw = 256
+    w4t = torch.zeros(P, ldw, device=dev, dtype=BF)
+    w4t[:, :C4] = W4.t().to(BF)
+    cA, cB, cC = 1 + 0.2 * rnd(C4, dev=dev, seed=5), 0.1 * rnd(C4, dev=dev, seed=6), 0.05 * rnd(C4, dev=dev, seed=7)
+    sc3, sh3 = 1 + 0.2 * rnd(P, dev=dev, seed=8), 0.3 * rnd(P, dev=dev, seed=9)
+    S = lib.query("tuber_conv4_bwd_slabs", M)
+    tiles = (M + 63) // 64
+    assert S == min(tiles, 512)
+    dz3 = torch.full((M, P), float("nan"), device=dev, dtype=BF)
+    st0, st1 = torch.full((tiles, P), float("nan"), device=dev), torch.full((tiles, P), float("nan"), device=dev)
+    slab = torch.full((S, C4, P), float("nan"), device=dev)
+    lib.call("tuber_conv4_bwd_fused", dz, c4, c3, w4t, ldw, cA, cB, cC, sc3, sh3, dz3, st0, st1, slab, M)
+    torch.cuda.synchronize()
+    dc4 = bfr(cA * dz.float() + cB * c4.float() + cC)
+    z3 = c3.float() * sc3 + sh3
+    ref3 = (dc4 @ W4.to(BF).float()) * (z3 > 0)
+    close("conv4 bwd fused dz3", dz3, ref3)
+    ref3r = bfr(ref3)
+    pad = tiles * 64 - M
+    rows = torch.cat([ref3, torch.zeros(pad, P, device=dev)]).view(tiles, 64, P)
+    crow = torch.cat([c3.float(), torch.zeros(pad, P, device=dev)]).view(tiles, 64, P)
+    close("conv4 bwd fused stats sum dz3", st0, rows.sum(1), abs_=2e-3 * float(rows.abs().sum(1).max()) + 1e-6)
+    close("conv4 bwd fused stats sum dz3*c3", st1, (rows * crow).sum(1), abs_=2e-3 * float((rows * crow).abs().sum(1).max()) + 1e-6)
+    dW = slab.sum(0)
+    refW = dc4.t() @ bfr(z3.relu())
+    close("conv4 bwd fused dW4", dW, refW, rel=2e-3)
+    assert bool(torch.isfinite(slab).all())

@@ -26,6 +26,7 @@ BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: Ba
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
+CONV4_BWD_FUSED = not os.environ.get("TUBER_NO_CONV4_BWD_FUSED")   # A/B switch: layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel
 BN3_IN_DW = not os.environ.get("TUBER_NO_BN3_IN_DW")       # A/B switch: bn3's backward apply formed inside the depthwise backward kernels (no bn_bwd_fa launch, no dc3 tensor)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
@@ -450,13 +451,17 @@ class CSNRunner:
                 dz = torch.empty(Mout, C4, dtype=BF, device=dev)
                 lib.call("tuber_block_out_bwd", dy, y, c4, cd, dz, sa, sb, sc_ if d["ds"] else None, Mout, C4)
             dc4 = None
+            # layer1 (C4 = 256, P = 64: the widest activations): bn4's backward apply, the conv4 data gradient and the conv4 weight
+            # gradient run as ONE persistent kernel that reads dz and c4 once and never writes dc4 (csrc/conv4_bwd.hip)
+            fuse4 = (CONV4_BWD_FUSED and depth >= 3 and f["w4"] and not wq.hold and self.store.defer.enabled
+                     and lib.query("tuber_conv4_bwd_supported", C4, P) == 1)
             if depth >= 2 or f["bn4"]:
-                dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2)
+                dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2 and not fuse4)
             dcd = None
             if d["ds"] and (need_dx or f["wd"] or f["bnd"]):
                 dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=need_dx or f["wd"])
             # conv4: weight grad (A = relu(bn3(c3)) recomputed on load) and data grad fused with relu/bn3 backward
-            if f["w4"]:
+            if f["w4"] and not fuse4:
                 self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
             dc3 = None
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
@@ -469,8 +474,16 @@ class CSNRunner:
             if depth >= 3:
                 s0, s1 = self.ws("st0u" if fuse3 else "st0", R3 * P), self.ws("st1u" if fuse3 else "st1", R3 * P)
                 dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
-                lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                         2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
+                if fuse4:
+                    S4 = lib.query("tuber_conv4_bwd_slabs", Mout)
+                    part4 = self.store.defer.alloc(S4 * C4 * P)
+                    lib.call("tuber_conv4_bwd_fused", dz, c4, c3, d["w4t"], d["ld4t"], b4.cA, b4.cB, b4.cC, b3.scale, b3.shift,
+                             dz3, s0, s1, part4, Mout)
+                    g4 = d["g4"]
+                    self.store.defer.add(part4, g4 if isinstance(g4, int) else g4.data_ptr(), C4 * P, C4 * P, S4, 0 if S4 <= 16 else 1)
+                else:
+                    lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                             2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
                 if fuse3:
                     bs0, bs1, bR = (s0, s1, R3) if R3 <= self._fa_max else self._stat_rows(s0, s1, R3, P)
                     bn3 = (dz3, c3, bs0, bs1, bR, float(Mout), b3.gamma, b3.mean, b3.invstd)

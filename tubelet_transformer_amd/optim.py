@@ -102,6 +102,13 @@ class FusedClipAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.store.zero_grad()
 
+    def mark_stepped(self):
+        """an adopted stock optimizer never has its own step() called: tell torch's lr_scheduler bookkeeping that a step happened
+        (it warns about 'lr_scheduler.step() before optimizer.step()' otherwise)"""
+        stock = getattr(self, "_stock", None)
+        if stock is not None:
+            stock._opt_called = True
+
     @torch.no_grad()
     def grad_norm(self, max_norm=0.0):
         """device-side total gradient norm (float tensor [2] = norm, clip coefficient); no host sync."""
@@ -114,6 +121,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
         The norm runs over the whole flat gradient buffer: windows of frozen parameters are never written and stay zero, so it equals
         ``clip_grad_norm_`` over the parameters that have a gradient (video_action_recognition.py:153)."""
         st = self.store
+        self.mark_stepped()
         clip = None
         if max_norm is not None and max_norm > 0:
             clip = self.grad_norm(max_norm)
@@ -225,4 +233,5 @@ def adopt(optimizer, model):
     optimizer.register_state_dict_pre_hook(pre_state_dict)
     optimizer.register_load_state_dict_post_hook(post_load)
     optimizer._tuber_fused = fused
+    fused._stock = optimizer          # (the stock object outlives the fused one: it owns it)
     return fused

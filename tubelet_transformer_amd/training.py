@@ -293,6 +293,7 @@ class GraphedTrainStep:
         g.mask.copy_(mask, non_blocking=True)
         g.pt.refill(targets)
         self.optimizer.sync_hyper()
+        self.optimizer.mark_stepped()
         self.criterion.sync_weights(store.device)
         sizes = g.pt.sizes
         g.A.replay()
