@@ -1059,3 +1059,37 @@ def test_conv4_bwd_fused(dev, M):
     refW = dc4.t() @ bfr(z3.relu())
     close("conv4 bwd fused dW4", dW, refW, rel=2e-3)
     assert bool(torch.isfinite(slab).all())
+
+
+@pytest.mark.parametrize("M,PN,proj", [(64 * 600, 64, False), (64 * 41 + 17, 64, True), (64 * 300, 128, False), (40, 128, True)])
+def test_blockout_conv1_fwd_fused(dev, M, PN, proj):
+    """tuber_blockout_conv1_fwd (layer1's residual join + the next bottleneck's conv1 as one persistent kernel) against the two
+    kernels it replaces: y bit-identical to tuber_block_out_fwd, c1 and its statistics rows equal to tuber_gemm_nt(epi 1) on that y
+    (same MFMA k-order: compared to accumulation rounding) and to fp32 torch math; identity and projection shortcut, ragged M"""
+    C = 256
+    assert lib.query("tuber_blockout_conv1_supported", C, PN) == 1 and lib.query("tuber_blockout_conv1_supported", 512, 128) == 0
+    c4 = rnd(M, C, dev=dev, seed=1).to(BF)
+    res = rnd(M, C, dev=dev, seed=2).to(BF)
+    s4, h4 = 1 + 0.2 * rnd(C, dev=dev, seed=3), 0.3 * rnd(C, dev=dev, seed=4)
+    rs, rh = (1 + 0.2 * rnd(C, dev=dev, seed=5), 0.3 * rnd(C, dev=dev, seed=6)) if proj else (None, None)
+    W = rnd(PN, C, dev=dev, seed=7, scale=C ** -0.5).to(BF)
+    tiles = (M + 63) // 64
+    y = torch.empty(M, C, device=dev, dtype=BF)
+    c1 = torch.full((M, PN), float("nan"), device=dev, dtype=BF)
+    st0, st1 = torch.full((tiles, PN), float("nan"), device=dev), torch.full((tiles, PN), float("nan"), device=dev)
+    lib.call("tuber_blockout_conv1_fwd", c4, s4, h4, res, rs, rh, y, W, C, c1, st0, st1, M, PN)
+    y_ref = torch.empty(M, C, device=dev, dtype=BF)
+    lib.call("tuber_block_out_fwd", c4, s4, h4, res, rs, rh, y_ref, M, C)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    c1_ref, r0, r1 = gemm_nt(y_ref, W, M, PN, C, epi=1)
+    close("fused c1 vs gemm_nt", c1, c1_ref.float(), rel=2 ** -8)
+    ref = y_ref.float() @ W.float().t()
+    close("fused c1 vs fp32", c1, ref)
+    close("fused stats sum", st0.sum(0), ref.sum(0), abs_=2e-3 * float(ref.abs().sum(0).max()))
+    close("fused stats sumsq", st1.sum(0), (ref * ref).sum(0), rel=2e-3)
+    close("fused stats rows vs gemm_nt", st0, r0, abs_=1e-3 * float(r0.abs().max()) + 1e-5)
+    # eval mode: no statistics rows
+    c1e = torch.empty(M, PN, device=dev, dtype=BF)
+    lib.call("tuber_blockout_conv1_fwd", c4, s4, h4, res, rs, rh, y, W, C, c1e, None, None, M, PN)
+    assert torch.equal(c1e, c1)

@@ -26,6 +26,7 @@ BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: Ba
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
+BLOCKOUT_CONV1 = not os.environ.get("TUBER_NO_BLOCKOUT_CONV1")     # A/B switch: layer1's residual join + the next block's conv1 as one persistent kernel
 CONV4_BWD_FUSED = not os.environ.get("TUBER_NO_CONV4_BWD_FUSED")   # A/B switch: layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel
 BN3_IN_DW = not os.environ.get("TUBER_NO_BN3_IN_DW")       # A/B switch: bn3's backward apply formed inside the depthwise backward kernels (no bn_bwd_fa launch, no dc3 tensor)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
@@ -254,12 +255,17 @@ class CSNRunner:
         """bottlenecks [lo, hi) on x = bf16 rows [B*Ti*Hi*Wi, cin] (NDHWC); appends the saved-for-backward tuples to ``out_saved``"""
         dev = self.dev
         Ti, Hi, Wi = geom
-        for d in self.blocks[lo:hi]:
+        pre_c1 = None               # the next block's conv1 output when the previous block's join kernel already produced it
+        for bi in range(lo, hi):
+            d = self.blocks[bi]
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
-            c1 = torch.empty(Min, P, dtype=BF, device=dev)
-            self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
+            if pre_c1 is not None:
+                c1, pre_c1 = pre_c1, None
+            else:
+                c1 = torch.empty(Min, P, dtype=BF, device=dev)
+                self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
             c3 = torch.empty(Mout, P, dtype=BF, device=dev)
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
             tile = st == 1 and ss == 1 and not DW_REGISTER_TILED        # LDS-staged kernels for the stride-1 blocks (47 of 50)
@@ -285,9 +291,27 @@ class CSNRunner:
                 strided = st != 1 or ss != 1
                 gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
                 self._gemm_stats(x, cin, d["wd"], cin, cd, Mout, 4 * P, cin, 0, None, None, gather, d["bnd"], train)
-                lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, cd, d["bnd"].scale, d["bnd"].shift, y, Mout, 4 * P)
+            res, rs, rh = (cd, d["bnd"].scale, d["bnd"].shift) if d["ds"] else (x, None, None)
+            # layer1 (256-channel block output, the widest activations): the residual join AND the next bottleneck's conv1 (+ its
+            # BatchNorm statistics) run as one persistent kernel that keeps the y tile in LDS (csrc/blockout_conv1.hip): y is written
+            # once and not read back.  The next block may be layer2's first one (its conv1 is dense; the stride sits on the depthwise conv).
+            nxt = self.blocks[bi + 1] if bi + 1 < hi else None
+            if (BLOCKOUT_CONV1 and nxt is not None and nxt["cin"] == 4 * P
+                    and lib.query("tuber_blockout_conv1_supported", 4 * P, nxt["p"]) == 1):
+                PN = nxt["p"]
+                pre_c1 = torch.empty(Mout, PN, dtype=BF, device=dev)
+                if train:
+                    Rn = lib.query("tuber_gemm_nt_stat_rows", Mout, PN)
+                    n0, n1 = self.ws("st0", Rn * PN), self.ws("st1", Rn * PN)
+                else:
+                    n0 = n1 = None
+                lib.call("tuber_blockout_conv1_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, nxt["w1"], nxt["cin"], pre_c1, n0, n1, Mout, PN)
+                if train:
+                    self._bn_train(nxt["bn1"], n0, n1, Rn, Mout)
+                else:
+                    self._bn_eval(nxt["bn1"])
             else:
-                lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, x, None, None, y, Mout, 4 * P)
+                lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, Mout, 4 * P)
             if train:
                 out_saved.append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq)))
             x = y

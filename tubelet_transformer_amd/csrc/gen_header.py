@@ -46,6 +46,10 @@ DOC = {
                                 "gradient buffer with no bucket copies; stream-ordered, capturable into a hipGraph.",
     "tuber_comm_allreduce_sum_multi": "the same for n windows (HOST arrays ptrs[n], counts[n]) as ONE RCCL group.",
     "tuber_comm_destroy": "ncclCommDestroy.",
+    "tuber_blockout_conv1_fwd": "residual join of one bottleneck + the first pointwise conv of the NEXT one as ONE persistent kernel (256-channel block output: layer1, and layer1 -> layer2): "
+                                "y = relu(bn4(c4) + shortcut) exactly as tuber_block_out_fwd writes it, kept in LDS per 64-row tile and multiplied with the next conv1 weight from there "
+                                "(c1 + the partial statistics rows of tuber_gemm_nt epi 1) -- y is written once and not read back. models/backbones/ir_CSN_152.py:84-90 then :72-74.",
+    "tuber_blockout_conv1_supported": "1 for the (block-output channels, next conv1 output channels) the fused forward kernel is built for.",
     "tuber_conv4_bwd_fused": "backward of the bottleneck's second pointwise conv through bn4, for the wide-activation stage (C4 = 256, P = 64: layer1), as ONE persistent kernel: "
                              "dc4 = cA*dz + cB*c4 + cC (bn4 backward apply; coefficients from tuber_bn_bwd_finalize) is formed per 64-row tile in LDS and feeds BOTH the data gradient "
                              "dz3 = (dc4 . W4) * [bn3(c3) > 0] (+ the per-tile statistics rows tuber_gemm_nt epi 2 writes) and the weight gradient dW4 = dc4^T . relu(bn3(c3)) "
