@@ -85,6 +85,16 @@ def alg_cost(name, a):
         el = C * N * T * H * W
         mode = {"tuber_dwconv_tile_fwd": 0, "tuber_dwconv_tile_bwd_data": 1, "tuber_dwconv_tile_bwd_weight": 2}[name]
         return "dwconv_tile_kernel<%d>" % mode, 2 * el * (3 if mode == 1 else 2), 2 * 27 * el
+    if name == "tuber_conv4_bwd_fused":          # reads dz, c4 [M,256] and c3 [M,64], writes dz3 [M,64]; conv4 data + weight gradient
+        M = a[14]
+        return "conv4_bwd_kernel", 2 * M * (256 + 256 + 64 + 64), 2 * 2 * M * 256 * 64
+    if name == "tuber_blockout_conv1_fwd":       # reads c4 and the shortcut, writes y [M,256] and the next conv1 output [M,pn]
+        M, pn = a[12], a[13]
+        return "blockout_conv1_kernel<%d>" % pn, 2 * M * (3 * 256 + pn), 2 * M * 256 * pn
+    if name == "tuber_conv1_bwd_fused":          # reads dz1, c1 [M,64], x [M,256] (+ residual gradient, + lower c4), writes [M,256]
+        M = a[14]
+        wide = 2 + (a[7] is not None) + (a[9] is not None)
+        return "conv1_bwd_kernel<%s>" % ("true" if a[9] is not None else "false"), 2 * M * (128 + 256 * wide), 2 * 2 * M * 256 * 64
     if name == "tuber_block_out_fwd":
         return "block_out_fwd_kernel", 2 * 3 * a[7] * a[8], 0
     if name == "tuber_block_out_bwd":
@@ -114,6 +124,10 @@ def shape_of(name, a):
     if name in ("tuber_attn_fwd", "tuber_attn_bwd"):
         off = 10 if name == "tuber_attn_fwd" else 19
         return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])
+    if name in ("tuber_conv4_bwd_fused", "tuber_conv1_bwd_fused"):
+        return "M%d" % a[14]
+    if name == "tuber_blockout_conv1_fwd":
+        return "M%d pn%d" % (a[12], a[13])
     if name in ("tuber_bn_bwd_apply", "tuber_block_out_fwd", "tuber_block_out_bwd", "tuber_bn_finalize", "tuber_bn_bwd_finalize",
                 "tuber_reduce_rows", "tuber_colsum", "tuber_reduce_slabs", "tuber_layernorm_fwd", "tuber_layernorm_bwd", "tuber_dropout"):
         return " ".join(str(x) for x in a if isinstance(x, int) and not isinstance(x, bool))[:44]

@@ -1093,3 +1093,53 @@ def test_blockout_conv1_fwd_fused(dev, M, PN, proj):
     c1e = torch.empty(M, PN, device=dev, dtype=BF)
     lib.call("tuber_blockout_conv1_fwd", c4, s4, h4, res, rs, rh, y, W, C, c1e, None, None, M, PN)
     assert torch.equal(c1e, c1)
+
+
+@pytest.mark.parametrize("M,join,with_r,with_dw", [(64 * 500, True, True, True), (64 * 23 + 11, True, True, True), (64 * 300, False, True, True),
+                                                   (64 * 40, False, False, False), (30, True, False, True)])
+def test_conv1_bwd_fused(dev, M, join, with_r, with_dw):
+    """tuber_conv1_bwd_fused (layer1's bn1 backward apply + conv1 data gradient [+ the lower block's residual join] + conv1 weight
+    gradient as one persistent kernel) against the kernels it replaces: dc1 = bf16(cA*dz1 + cB*c1 + cC); the data gradient through
+    tuber_gemm_nt_join (join form: bit-level comparison of dz, statistics rows to accumulation rounding) or plain fp32 math; the weight
+    gradient dW1 = dc1^T . x summed over the workgroup slabs.  Ragged M, no residual, frozen conv1 (no slab)."""
+    C, P = 256, 64
+    assert lib.query("tuber_conv1_bwd_supported", C, P) == 1 and lib.query("tuber_conv1_bwd_supported", 512, 128) == 0
+    dz1 = rnd(M, P, dev=dev, seed=1).to(BF)
+    c1 = (rnd(M, P, dev=dev, seed=2) * 1.2 + 0.1).to(BF)
+    cA, cB, cC = 1 + 0.2 * rnd(P, dev=dev, seed=3), 0.1 * rnd(P, dev=dev, seed=4), 0.05 * rnd(P, dev=dev, seed=5)
+    W1 = rnd(P, C, dev=dev, seed=6, scale=P ** -0.5)                        # conv1.weight [P][C]
+    ldw = 64
+    w1t = W1.t().contiguous().to(BF)                                        # [C][P]
+    R = rnd(M, C, dev=dev, seed=7).to(BF) if with_r else None
+    X = rnd(M, C, dev=dev, seed=8).to(BF)
+    Cm = rnd(M, C, dev=dev, seed=9).to(BF) if join else None
+    tiles = (M + 63) // 64
+    S = lib.query("tuber_conv1_bwd_slabs", M)
+    assert S == min(tiles, 256)
+    out = torch.full((M, C), float("nan"), device=dev, dtype=BF)
+    st0 = torch.full((tiles, C), float("nan"), device=dev) if join else None
+    st1 = torch.full((tiles, C), float("nan"), device=dev) if join else None
+    slab = torch.full((S, P, C), float("nan"), device=dev) if with_dw else None
+    lib.call("tuber_conv1_bwd_fused", dz1, c1, cA, cB, cC, w1t, ldw, R, X, Cm, out, st0, st1, slab, M)
+    torch.cuda.synchronize()
+    dc1 = (cA * dz1.float() + cB * c1.float() + cC).to(BF)
+    dx = dc1.float() @ W1.to(BF).float() + (R.float() if with_r else 0.0)
+    if join:
+        ref = bfr(dx) * (X.float() > 0)
+        close("conv1 bwd fused dz (join)", out, ref)
+        dz_j = torch.empty(M, C, device=dev, dtype=BF)
+        rows = lib.query("tuber_gemm_nt_stat_rows", M, C)
+        assert rows == tiles
+        j0, j1 = torch.zeros(rows, C, device=dev), torch.zeros(rows, C, device=dev)
+        lib.call("tuber_gemm_nt_join", dc1, P, w1t, ldw, dz_j, C, M, C, P, R, C, X, C, Cm, C, j0, j1)
+        torch.cuda.synchronize()
+        ndiff = int((out != dz_j).sum())                 # same products, another MFMA blocking: bf16 ties may round the other way
+        assert ndiff <= 1e-4 * out.numel() + 2, "join form: dz differs from tuber_gemm_nt_join in %d elements" % ndiff
+        close("conv1 bwd fused dz vs gemm_nt_join", out, dz_j.float(), rel=2 ** -7)
+        close("conv1 bwd fused stats sum dz vs gemm_nt_join", st0, j0, abs_=1e-3 * float(j0.abs().max()) + 1e-5)
+        close("conv1 bwd fused stats sum dz*c4 vs gemm_nt_join", st1, j1, abs_=1e-3 * float(j1.abs().max()) + 1e-5)
+    else:
+        close("conv1 bwd fused dx (plain)", out, dx)
+    if with_dw:
+        close("conv1 bwd fused dW1", slab.sum(0), dc1.float().t() @ X.float(), rel=2e-3)
+        assert bool(torch.isfinite(slab).all())

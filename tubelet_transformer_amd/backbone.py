@@ -27,6 +27,7 @@ JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
 BLOCKOUT_CONV1 = not os.environ.get("TUBER_NO_BLOCKOUT_CONV1")     # A/B switch: layer1's residual join + the next block's conv1 as one persistent kernel
+CONV1_BWD_FUSED = not os.environ.get("TUBER_NO_CONV1_BWD_FUSED")   # A/B switch: layer1's bn1 backward apply + conv1 data gradient (+ join) + conv1 weight gradient as one persistent kernel
 CONV4_BWD_FUSED = not os.environ.get("TUBER_NO_CONV4_BWD_FUSED")   # A/B switch: layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel
 BN3_IN_DW = not os.environ.get("TUBER_NO_BN3_IN_DW")       # A/B switch: bn3's backward apply formed inside the depthwise backward kernels (no bn_bwd_fa launch, no dc3 tensor)
 DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
@@ -477,7 +478,7 @@ class CSNRunner:
             dc4 = None
             # layer1 (C4 = 256, P = 64: the widest activations): bn4's backward apply, the conv4 data gradient and the conv4 weight
             # gradient run as ONE persistent kernel that reads dz and c4 once and never writes dc4 (csrc/conv4_bwd.hip)
-            fuse4 = (CONV4_BWD_FUSED and depth >= 3 and f["w4"] and not wq.hold and self.store.defer.enabled
+            fuse4 = (CONV4_BWD_FUSED and depth >= 3 and f["w4"] and not wq.hold
                      and lib.query("tuber_conv4_bwd_supported", C4, P) == 1)
             if depth >= 2 or f["bn4"]:
                 dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2 and not fuse4)
@@ -500,11 +501,14 @@ class CSNRunner:
                 dz3 = torch.empty(Mout, P, dtype=BF, device=dev)
                 if fuse4:
                     S4 = lib.query("tuber_conv4_bwd_slabs", Mout)
-                    part4 = self.store.defer.alloc(S4 * C4 * P)
+                    part4, acc4 = self.store.partial("c4f", S4 * C4 * P, self.ws)
                     lib.call("tuber_conv4_bwd_fused", dz, c4, c3, d["w4t"], d["ld4t"], b4.cA, b4.cB, b4.cC, b3.scale, b3.shift,
                              dz3, s0, s1, part4, Mout)
                     g4 = d["g4"]
-                    self.store.defer.add(part4, g4 if isinstance(g4, int) else g4.data_ptr(), C4 * P, C4 * P, S4, 0 if S4 <= 16 else 1)
+                    if acc4 == 2:       # second stage deferred to the step's tuber_multi_reduce (mode 1 = the summation order of tuber_reduce_rows)
+                        self.store.defer.add(part4, g4 if isinstance(g4, int) else g4.data_ptr(), C4 * P, C4 * P, S4, 1)
+                    else:
+                        lib.call("tuber_reduce_rows", part4, g4, S4, C4 * P, 1)
                 else:
                     lib.call("tuber_gemm_nt", dc4, C4, d["w4t"], d["ld4t"], dz3, P, Mout, P, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                              2, None, None, 0, 0, 0, s0, s1, c3, P, b3.scale, b3.shift, 1.0, 0.0, None, 0, None, 0, None)
@@ -547,9 +551,16 @@ class CSNRunner:
                     lib.call("tuber_dwconv_tile_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
                 else:
                     lib.call("tuber_dwconv_bwd_data", dc3, d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
-                dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min, train=f["bn1"], apply=depth >= 6)
+                # layer1 (256-channel block input, P = 64): bn1's backward apply, the conv1 data gradient (with the lower block's join
+                # when that is an identity block) and the conv1 weight gradient run as ONE persistent kernel (csrc/conv1_bwd.hip)
+                strided_ds = d["ds"] and (st != 1 or ss != 1)
+                fuse1 = (CONV1_BWD_FUSED and need_dx and not strided_ds and not wq.hold
+                         and lib.query("tuber_conv1_bwd_supported", cin, P) == 1)
+                dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min, train=f["bn1"], apply=depth >= 6 and not fuse1)
+            else:
+                fuse1 = False
             # conv1: weight grad and data grad (+ identity shortcut gradient as residual)
-            if f["w1"]:
+            if f["w1"] and not fuse1:
                 self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
             strided = st != 1 or ss != 1
             gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if (d["ds"] and strided) else None
@@ -567,7 +578,31 @@ class CSNRunner:
                 # identity block and dx is complete after this GEMM, its join backward (dz = dx * [y > 0] + the bn4 statistics) runs
                 # as the GEMM's epilogue: dx never reaches HBM and the block_out_bwd launch of the next iteration is gone.
                 fuse = JOIN_FUSION and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
-                if fuse:
+                if fuse1:
+                    part1 = None
+                    if f["w1"]:
+                        S1 = lib.query("tuber_conv1_bwd_slabs", Min)
+                        part1, acc1 = self.store.partial("c1f", S1 * P * cin, self.ws)
+                    outx = torch.empty(Min, cin, dtype=BF, device=dev)
+                    if fuse:
+                        c4l = sblocks[bi - 1 - base][3]
+                        Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
+                        ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
+                    else:
+                        c4l, ja, jb = None, None, None
+                    lib.call("tuber_conv1_bwd_fused", dz1, c1, b1.cA, b1.cB, b1.cC, d["w1t"], d["ld1t"], res, x, c4l, outx, ja, jb, part1, Min)
+                    if part1 is not None:
+                        g1 = d["g1"]
+                        if acc1 == 2:
+                            self.store.defer.add(part1, g1 if isinstance(g1, int) else g1.data_ptr(), P * cin, P * cin, S1, 1)
+                        else:
+                            lib.call("tuber_reduce_rows", part1, g1, S1, P * cin, 1)
+                    if fuse:
+                        pre = (outx, ja, jb, Rj)
+                        dy = None
+                    else:
+                        dy = outx
+                elif fuse:
                     c4l = sblocks[bi - 1 - base][3]
                     Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)

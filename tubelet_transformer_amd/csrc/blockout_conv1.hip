@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, PN == 64 ? 2 : 1) void blockout_conv1_kernel(B
         }
     };
     long t = blockIdx.x;
-    if (t < ntiles) load_tile(t);
+    load_tile(t);
     for (; t < ntiles; t += gridDim.x) {
         const long m0 = t * TR;
 #pragma unroll
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, PN == 64 ? 2 : 1) void blockout_conv1_kernel(B
             if (m0 + row < a.M) *(uint4*)(a.y + (m0 + row) * C + gch * 8) = ov;
             *(uint4*)(yimg + goff(row, gch * 8)) = ov;
         }
-        if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+        load_tile(min(t + (long)gridDim.x, ntiles - 1));
         __syncthreads();
         // ---- c1[m][p] = sum_c y[m][c] * W[p][c]; issued as D[p][m] so a lane ends up with 4 consecutive p of one row m ----
         f32x4 acc[NB];

@@ -99,24 +99,39 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rz[8], rc[8], r3[2];
-    auto load_tile = [&](long t) {
-        const long m0 = t * TR;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const long m = min(m0 + gr + 8 * h, a.M - 1);
-            rz[h] = *(const uint4*)(a.dz + m * C4 + gch * 8);
-            rc[h] = *(const uint4*)(a.c4 + m * C4 + gch * 8);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long m = min(m0 + cr + 32 * h, a.M - 1);
-            r3[h] = *(const uint4*)(a.c3 + m * P + cch * 8);
-        }
-    };
-
+    // prefetch registers as named scalars: as arrays (indexed in unrolled loops, in a lambda or a macro) the compiler left some of them in
+    // scratch memory, and the scratch store right behind the loads made every prefetch wait for them at issue
+    uint4 rz0, rz1, rz2, rz3, rz4, rz5, rz6, rz7, rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, r30, r31;
+#define LOAD_ROW(h, m0_)                                                          \
+    do {                                                                          \
+        const long m_ = min((m0_) + gr + 8 * h, a.M - 1);                         \
+        rz##h = *(const uint4*)(a.dz + m_ * C4 + gch * 8);                        \
+        rc##h = *(const uint4*)(a.c4 + m_ * C4 + gch * 8);                        \
+    } while (0)
+#define LOAD_C3(h, m0_)                                                           \
+    do {                                                                          \
+        const long m_ = min((m0_) + cr + 32 * h, a.M - 1);                        \
+        r3##h = *(const uint4*)(a.c3 + m_ * P + cch * 8);                         \
+    } while (0)
+#define LOAD_TILE(tt)                                                             \
+    do {                                                                          \
+        const long m0_ = (tt) * TR;                                               \
+        LOAD_ROW(0, m0_); LOAD_ROW(1, m0_); LOAD_ROW(2, m0_); LOAD_ROW(3, m0_);   \
+        LOAD_ROW(4, m0_); LOAD_ROW(5, m0_); LOAD_ROW(6, m0_); LOAD_ROW(7, m0_);   \
+        LOAD_C3(0, m0_); LOAD_C3(1, m0_);                                         \
+    } while (0)
+#define PUT_ROW(h)                                                                \
+    do {                                                                          \
+        const int row = gr + 8 * h;                                               \
+        const bf16x8 z = as_bf16x8(rz##h), x = as_bf16x8(rc##h);                  \
+        bf16x8 o;                                                                 \
+        const bool ok = m0 + row < a.M;                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                             \
+            o[e] = f2bf(ok ? fmaf(kA[e], bf2f(z[e]), fmaf(kB[e], bf2f(x[e]), kC[e])) : 0.f); \
+        *(uint4*)(gimg + goff(row, gch * 8)) = as_uint4(o);                       \
+    } while (0)
     long t = blockIdx.x;
-    if (t < ntiles) load_tile(t);
+    LOAD_TILE(t);                                        // the grid never exceeds the tile count
     __syncthreads();                                     // tab3 / tab4 / wimg are in place
     for (; t < ntiles; t += gridDim.x) {
         const long m0 = t * TR;
@@ -130,19 +145,10 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
             kB[0] = b0.x; kB[1] = b0.y; kB[2] = b0.z; kB[3] = b0.w; kB[4] = b1.x; kB[5] = b1.y; kB[6] = b1.z; kB[7] = b1.w;
             kC[0] = c0.x; kC[1] = c0.y; kC[2] = c0.z; kC[3] = c0.w; kC[4] = c1.x; kC[5] = c1.y; kC[6] = c1.z; kC[7] = c1.w;
         }
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const int row = gr + 8 * h;
-            const bf16x8 z = as_bf16x8(rz[h]), x = as_bf16x8(rc[h]);
-            bf16x8 o;
-            const bool ok = m0 + row < a.M;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(ok ? fmaf(kA[e], bf2f(z[e]), fmaf(kB[e], bf2f(x[e]), kC[e])) : 0.f);
-            *(uint4*)(gimg + goff(row, gch * 8)) = as_uint4(o);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) *(uint4*)(cimg + aoff(cr + 32 * h, cch * 8)) = r3[h];      // (rows beyond M: a copy of row M-1; their dc4 rows are zero)
-        if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);          // next tile's loads run under this tile's MFMA work
+        PUT_ROW(0); PUT_ROW(1); PUT_ROW(2); PUT_ROW(3); PUT_ROW(4); PUT_ROW(5); PUT_ROW(6); PUT_ROW(7);
+        *(uint4*)(cimg + aoff(cr, cch * 8)) = r30;              // (rows beyond M: a copy of row M-1; their dc4 rows are zero)
+        *(uint4*)(cimg + aoff(cr + 32, cch * 8)) = r31;
+        LOAD_TILE(min(t + (long)gridDim.x, ntiles - 1));      // next tile's loads run under this tile's MFMA work (unconditional; the last one re-reads a valid tile)
         __syncthreads();
 
         // ---- data gradient: D[p][m] = sum_c W4^T[p][c] * dc4[m][c]; wave w owns rows m = 16 w + li, all 64 p ----
@@ -224,6 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
             for (int r = 0; r < 4; ++r) out[(long)(64 * wave + j * 16 + g * 4 + r) * P + i * 16 + li] = wacc[i][j][r];
 }
 
+#undef LOAD_TILE
+#undef LOAD_ROW
+#undef LOAD_C3
+#undef PUT_ROW
 constexpr size_t kLds = (size_t)(TR * GP + P * GP + TR * 64) * sizeof(bf16) + (4 * P * 2 + 2 * P + 3 * C4) * sizeof(float);
 
 }  // namespace
