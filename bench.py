@@ -52,10 +52,10 @@ def alg_cost(name, a):
         return "gemm_nt_kernel<%s,0,3,%d>" % (tile, occ), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
-        T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64
         ldg, lda, gmode = a[1], a[3], a[22] is not None
-        if T == 64 and not gmode and not ((N | K | ldg | lda) & 7):      # the LDS-transpose-read kernel (gemm.hip: gemm_tn2_kernel)
-            return "gemm_tn2_kernel<%d>" % a[10], 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
+        if not gmode and not ((N | K | ldg | lda) & 7):      # the LDS-transpose-read kernels (gemm.hip: gemm_tn2_kernel / gemm_tn3_kernel)
+            return "gemm_tn%d_kernel<%d>" % (3 if lib.query("tuber_gemm_tn_tile", M, N, K) == 128 else 2, a[10]), 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
+        T = 128 if ((N + 127) // 128) * ((K + 127) // 128) >= 128 else 64
         return "gemm_tn_kernel<%d,%d,%d>" % (a[10], T, 1 if gmode else 0), 2 * M * (N + K) + 4 * N * K, 2 * M * N * K
     if name == "tuber_gemm_tn_group":
         by = sum(2 * e.M * (e.N + e.K) + 4 * e.N * e.K for e in a[0])

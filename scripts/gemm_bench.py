@@ -153,6 +153,25 @@ def bench_dw():
               % (N, T, H, W, C, mb, *t, R, C // 64), flush=True)
 
 
+def bench_dw_scale():
+    """Do the small-grid depthwise kernels (layer3: 64 workgroups on 256 CUs) get slower when more workgroups run beside them?"""
+    for T, H, W, C in [(8, 16, 22, 256), (16, 32, 43, 128)]:
+        for N in (2, 4, 8, 16):
+            x = torch.randn(N, T, H, W, C, device=dev).to(BF)
+            g = torch.randn(N, T, H, W, C, device=dev).to(BF)
+            w = torch.randn(C, 27, device=dev) / 5
+            sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+            out = torch.empty_like(x)
+            dwg = torch.zeros(C, 27, device=dev)
+            R = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+            st0, st1 = torch.empty(R, C, device=dev), torch.empty(R, C, device=dev)
+            part = torch.empty(R * 27 * C, device=dev)
+            t = [time_it(lambda: lib.call("tuber_dwconv_tile_fwd", x, sc, sh, w, out, st0, st1, N, T, H, W, C)),
+                 time_it(lambda: lib.call("tuber_dwconv_tile_bwd_data", g, w, x, sc, sh, out, st0, st1, N, T, H, W, C)),
+                 time_it(lambda: lib.call("tuber_dwconv_tile_bwd_weight", g, x, sc, sh, part, dwg, 1, N, T, H, W, C))]
+            print("dw scale %dx%dx%dx%d C%d: fwd %.1f  bwd data %.1f  bwd weight(+reduce) %.1f us  [WGs %d x %d]" % (N, T, H, W, C, *t, R, C // 64), flush=True)
+
+
 def bench_attn():
     import numpy as np
     H, E = 8, 256
@@ -207,6 +226,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         bench_attn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dwscale":
+        bench_dw_scale()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dw":
         bench_dw()

@@ -1061,6 +1061,33 @@ def test_conv4_bwd_fused(dev, M):
     assert bool(torch.isfinite(slab).all())
 
 
+@pytest.mark.parametrize("M", [64 * 37 + 9, 64 * 1200])
+def test_conv4_bwd_fused_projection_form(dev, M):
+    """tuber_conv4_bwd_fused with sc3 = sh3 = NULL: the projection shortcut of a stage's first block (down_sample conv + BatchNorm,
+    ir_CSN_152.py:86-87) -- its BatchNorm backward apply, data gradient (no mask: the conv input is the block input, which may be
+    negative) and weight gradient (operand = the block input as it is) against fp32 torch math; no statistics rows are written"""
+    C4, P = 256, 64
+    dz = rnd(M, C4, dev=dev, seed=1).to(BF)
+    cd = (rnd(M, C4, dev=dev, seed=2) * 1.3 + 0.2).to(BF)
+    x = rnd(M, P, dev=dev, seed=3).to(BF)                                  # about half of it negative
+    Wd = rnd(C4, P, dev=dev, seed=4, scale=P ** -0.5)                      # down_sample.0.weight [C4][P]
+    wdt = Wd.t().contiguous().to(BF)
+    cA, cB, cC = 1 + 0.2 * rnd(C4, dev=dev, seed=5), 0.1 * rnd(C4, dev=dev, seed=6), 0.05 * rnd(C4, dev=dev, seed=7)
+    S = lib.query("tuber_conv4_bwd_slabs", M)
+    dx = torch.full((M, P), float("nan"), device=dev, dtype=BF)
+    slab = torch.full((S, C4, P), float("nan"), device=dev)
+    guard = torch.full((4, P), 7.0, device=dev)
+    lib.call("tuber_conv4_bwd_fused", dz, cd, x, wdt, C4, cA, cB, cC, None, None, dx, None, None, slab, M)
+    torch.cuda.synchronize()
+    dcd = bfr(cA * dz.float() + cB * cd.float() + cC)
+    close("projection form dx", dx, dcd @ Wd.to(BF).float())
+    close("projection form dWd", slab.sum(0), dcd.t() @ x.float(), rel=2e-3)
+    assert bool(torch.isfinite(slab).all()) and bool((guard == 7.0).all())
+    # the statistics pointers are mandatory in the conv4 form
+    with pytest.raises(Exception):
+        lib.call("tuber_conv4_bwd_fused", dz, cd, x, wdt, C4, cA, cB, cC, cA[:P], cA[:P], dx, None, None, slab, M)
+
+
 @pytest.mark.parametrize("M,PN,proj", [(64 * 600, 64, False), (64 * 41 + 17, 64, True), (64 * 300, 128, False), (40, 128, True)])
 def test_blockout_conv1_fwd_fused(dev, M, PN, proj):
     """tuber_blockout_conv1_fwd (layer1's residual join + the next bottleneck's conv1 as one persistent kernel) against the two

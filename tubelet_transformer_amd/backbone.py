@@ -483,8 +483,12 @@ class CSNRunner:
             if depth >= 2 or f["bn4"]:
                 dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2 and not fuse4)
             dcd = None
+            # layer1's projection shortcut (64 -> 256 channels, stride 1): the same persistent kernel in its plain form does the shortcut
+            # BatchNorm's backward apply, the projection's data gradient and its weight gradient in one pass over dz and cd
+            fused = (CONV4_BWD_FUSED and d["ds"] and st == 1 and ss == 1 and need_dx and f["wd"] and not wq.hold
+                     and lib.query("tuber_conv4_bwd_supported", C4, cin) == 1)
             if d["ds"] and (need_dx or f["wd"] or f["bnd"]):
-                dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=need_dx or f["wd"])
+                dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=(need_dx or f["wd"]) and not fused)
             # conv4: weight grad (A = relu(bn3(c3)) recomputed on load) and data grad fused with relu/bn3 backward
             if f["w4"] and not fuse4:
                 self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
@@ -564,11 +568,23 @@ class CSNRunner:
                 self._wgrad(dc1, P, x, cin, d["g1"], Min, P, cin)
             strided = st != 1 or ss != 1
             gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if (d["ds"] and strided) else None
-            if d["ds"] and f["wd"]:
+            if d["ds"] and f["wd"] and not fused:
                 self._wgrad(dcd, C4, x, cin, d["gd"], Mout, C4, cin, 0, None, None, gather)
             if need_dx:
                 res = dz if not d["ds"] else None
-                if d["ds"]:
+                if fused:
+                    bd = d["bnd"]
+                    dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
+                    Sd = lib.query("tuber_conv4_bwd_slabs", Mout)
+                    partd, accd = self.store.partial("cdf", Sd * C4 * cin, self.ws)
+                    lib.call("tuber_conv4_bwd_fused", dz, cd, x, d["wdt"], d["lddt"], bd.cA, bd.cB, bd.cC, None, None, dxd, None, None, partd, Mout)
+                    gd = d["gd"]
+                    if accd == 2:
+                        self.store.defer.add(partd, gd if isinstance(gd, int) else gd.data_ptr(), C4 * cin, C4 * cin, Sd, 1)
+                    else:
+                        lib.call("tuber_reduce_rows", partd, gd, Sd, C4 * cin, 1)
+                    res = dxd
+                elif d["ds"]:
                     dxd = torch.empty(Mout, cin, dtype=BF, device=dev)
                     lib.call("tuber_gemm_nt", dcd, C4, d["wdt"], d["lddt"], dxd, cin, Mout, cin, C4, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0,
                              0, 0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)

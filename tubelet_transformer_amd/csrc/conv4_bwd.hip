@@ -64,6 +64,10 @@ struct Conv4BwdArgs {
     long M;
 };
 
+// PLAIN: the projection-shortcut form (down_sample conv + BatchNorm of a stage's first block, ir_CSN_152.py:86-87): the conv input is the
+// block input itself -- no BatchNorm / ReLU in front of it, so no activation on the weight-gradient operand, no mask on the data
+// gradient and no statistics rows.
+template <bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* gimg = (bf16*)smem_raw;                       // [64][256] dc4 tile
@@ -88,10 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
     const int gr = tid >> 5, gch = tid & 31;             // dz / c4 staging: rows gr + 8 h, 16-byte chunk gch (channels gch*8 ..)
     tab4[tid] = a.cA[tid]; tab4[C4 + tid] = a.cB[tid]; tab4[2 * C4 + tid] = a.cC[tid];        // 256 threads = 256 channels
     const int cr = tid >> 3, cch = tid & 7;              // c3 staging: rows cr + 32 h, chunk cch (channels cch*8 ..)
-    if (tid < P) { tab3[tid] = a.sc3[tid]; tab3[P + tid] = a.sh3[tid]; }
+    if (!PLAIN && tid < P) { tab3[tid] = a.sc3[tid]; tab3[P + tid] = a.sh3[tid]; }
     float sA[4], hA[4];                                  // bn3 scale / shift of this lane's weight-gradient columns p = i*16 + li
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sA[i] = a.sc3[i * 16 + li]; hA[i] = a.sh3[i * 16 + li]; }
+    for (int i = 0; i < 4; ++i) { sA[i] = PLAIN ? 1.f : a.sc3[i * 16 + li]; hA[i] = PLAIN ? 0.f : a.sh3[i * 16 + li]; }
 
     f32x4 wacc[4][4];                                    // dW block (p block i, c block j): p = i*16 + li, c = 64*wave + j*16 + g*4 + r
 #pragma unroll
@@ -172,10 +176,16 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int p0 = n * 16 + g * 4;
+                bf16x4 o;
+                if (PLAIN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f2bf(dacc[n][r]);
+                    if (ok) *(uint2*)(a.dz3 + (m0 + row) * P + p0) = as_uint2(o);
+                    continue;
+                }
                 const bf16x4 cv = as_bf16x4(*(const uint2*)(cimg + aoff(row, p0)));
                 const float4 sc = *(const float4*)(tab3 + p0), sh = *(const float4*)(tab3 + P + p0);
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                bf16x4 o;
                 float s0[4], s1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -205,15 +215,17 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                // a3 = relu(bn3(c3)) formed on the transposed fragment (column p = i*16 + li)
                 const bf16x8 x = a_tr_frag(cimg, mm, i * 16, li);
-                bf16x8 fp;
+                bf16x8 fp = x;
+                if (!PLAIN) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fp[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sA[i], hA[i]), 0.f));
+                    for (int e = 0; e < 8; ++e) fp[e] = f2bf(fmaxf(fmaf(bf2f(x[e]), sA[i], hA[i]), 0.f));
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[j], fp, wacc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();                                  // images are free again; the partial statistics are complete
-        if (tid < 2 * P) {
+        if (!PLAIN && tid < 2 * P) {
             const int which = tid >> 6, p = tid & 63;
             const float v = (red[(0 * P + p) * 2 + which] + red[(1 * P + p) * 2 + which]) + (red[(2 * P + p) * 2 + which] + red[(3 * P + p) * 2 + which]);
             (which ? a.st1 : a.st0)[t * P + p] = v;
@@ -252,20 +264,25 @@ int tuber_conv4_bwd_supported(int c4, int p) { return c4 == C4 && p == P; }
 // dz, c4 [M, 256] bf16; c3 [M, 64] bf16; w4t = conv4 weight transposed [64][ldw] bf16; cA / cB / cC [256], sc3 / sh3 [64] fp32;
 // dz3 [M, 64] bf16 out; st0 / st1 [ceil(M / 64)][64] fp32 out (same rows as tuber_gemm_nt epi 2); slab [tuber_conv4_bwd_slabs(M)][256][64]
 // fp32 out (sum over the slabs = dW4 [256][64], conv4.weight layout).
+// sc3 = sh3 = NULL: the projection-shortcut form (down_sample conv of a stage's first block: c4 = its output, c3 = the block input x,
+// w4t = its weight transposed): dz3 = dc4 . W with no mask, the weight-gradient operand is x as it is, st0 / st1 are not written (may be NULL).
 int tuber_conv4_bwd_fused(const void* dz, const void* c4, const void* c3, const void* w4t, long ldw, const float* cA, const float* cB,
                           const float* cC, const float* sc3, const float* sh3, void* dz3, float* st0, float* st1, float* slab,
                           long M, hipStream_t stream) {
-    if (!dz || !c4 || !c3 || !w4t || !cA || !cB || !cC || !sc3 || !sh3 || !dz3 || !st0 || !st1 || !slab || M <= 0 || ldw < C4 || (ldw & 7))
+    const bool plain = !sc3 && !sh3;
+    if (!dz || !c4 || !c3 || !w4t || !cA || !cB || !cC || (!plain && (!sc3 || !sh3 || !st0 || !st1)) || !dz3 || !slab || M <= 0 || ldw < C4 || (ldw & 7))
         return TUBER_EINVAL;
     Conv4BwdArgs a;
     a.dz = (const bf16*)dz; a.c4 = (const bf16*)c4; a.c3 = (const bf16*)c3; a.w4t = (const bf16*)w4t; a.ldw = ldw;
     a.cA = cA; a.cB = cB; a.cC = cC; a.sc3 = sc3; a.sh3 = sh3; a.dz3 = (bf16*)dz3; a.st0 = st0; a.st1 = st1; a.slab = slab; a.M = M;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv4_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute((const void*)conv4_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute((const void*)conv4_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv4_bwd_kernel, dim3(tuber_conv4_bwd_slabs(M)), dim3(256), kLds, stream, a);
+    if (plain) hipLaunchKernelGGL(conv4_bwd_kernel<true>, dim3(tuber_conv4_bwd_slabs(M)), dim3(256), kLds, stream, a);
+    else hipLaunchKernelGGL(conv4_bwd_kernel<false>, dim3(tuber_conv4_bwd_slabs(M)), dim3(256), kLds, stream, a);
     TUBER_RETURN_LAUNCH();
 }
 

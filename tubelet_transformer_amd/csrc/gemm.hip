@@ -1382,10 +1382,13 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 
 extern "C" {
 
-// Tile / slab choice of gemm_tn: 128x128 tiles when they alone give >= 128 workgroups, else 64x64; slabs over M fill the
+// Tile / slab choice of gemm_tn (shapes with odd N / K): 128x128 tiles when they alone give >= 128 workgroups, else 64x64; slabs over M fill the
 // chip to ~256 workgroups but never more than 8 (bounds the fp32 slab traffic to <= the size of the operands) and
 // at least 256 rows each.
-static int tn_tile(int N, int K) { return (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
+// (shapes the transpose-read kernels take -- N and K multiples of 8 -- always walk 64 x 64 tiles here, or 128 x 128 ones by tn_big below:
+// layer4's down-sample weight gradient, 2048 x 1024 over M = 704, took 71.6 us on the in-register-transpose 128-tile kernel against
+// ~14 us for the same work as 512 tiles of gemm_tn2)
+static int tn_tile(int N, int K) { return !((N | K) & 7) ? 64 : (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
 // 128 x 128 transpose-read tiles (gemm_tn3): layer3 / layer4 convs, FFN and class-branch linears, packed in-projections
 static int g_tn_big = -1;
 // Measured (scripts/gemm_bench.py tngroup, round 3): eight layer3 problems 68.2 -> 50.9 us, six layer4 ones 87.5 -> 82.6 us; but the
@@ -1393,7 +1396,9 @@ static int g_tn_big = -1;
 // short-M encoder FFNs (M = 704: 11 steps) 13.5 -> 20.8 us -- so only the mid-M backbone shapes take the big tiles.
 static bool tn_big(int M, int N, int K) {
     if (g_tn_big < 0) { const char* e = getenv("TUBER_TN_NO_BIG_TILES"); g_tn_big = e ? 0 : 1; }      // A/B switch
-    return g_tn_big && M >= 2048 && M <= 8192 && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
+    static int max_m = -1;
+    if (max_m < 0) { const char* e = getenv("TUBER_TN_BIG_MAX_M"); max_m = e ? atoi(e) : 8192; }
+    return g_tn_big && M >= 2048 && M <= max_m && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
 }
 static int tn_slabs_wanted(int M, int N, int K) {
     const int T = tn_big(M, N, K) ? 128 : tn_tile(N, K);
@@ -1409,7 +1414,10 @@ static int tn_slabs_wanted(int M, int N, int K) {
     if (tn_big(M, N, K)) {
         static int big_rows = -1;
         if (big_rows < 0) { const char* e = getenv("TUBER_TN_BIG_ROWS"); big_rows = e ? atoi(e) : 1408; }
-        S = (M + big_rows / 2) / big_rows;
+        static int long_rows = -1;
+        if (long_rows < 0) { const char* e = getenv("TUBER_TN_BIG_ROWS_LONG"); long_rows = e ? atoi(e) : 2112; }
+        const int rows = M > 8192 ? long_rows : big_rows;
+        S = (M + rows / 2) / rows;
     } else {
         S = (target + tiles - 1) / tiles;
     }

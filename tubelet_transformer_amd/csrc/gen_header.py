@@ -60,7 +60,9 @@ DOC = {
                              "dc4 = cA*dz + cB*c4 + cC (bn4 backward apply; coefficients from tuber_bn_bwd_finalize) is formed per 64-row tile in LDS and feeds BOTH the data gradient "
                              "dz3 = (dc4 . W4) * [bn3(c3) > 0] (+ the per-tile statistics rows tuber_gemm_nt epi 2 writes) and the weight gradient dW4 = dc4^T . relu(bn3(c3)) "
                              "(one fp32 slab per workgroup: tuber_conv4_bwd_slabs(M)) -- dc4 never reaches HBM: 2 passes over the [M, C4] tensors instead of 5 "
-                             "(tuber_bn_bwd_fa + tuber_gemm_nt + tuber_gemm_tn). autograd of models/backbones/ir_CSN_152.py:58-64,78-84.",
+                             "(tuber_bn_bwd_fa + tuber_gemm_nt + tuber_gemm_tn). autograd of models/backbones/ir_CSN_152.py:58-64,78-84. "
+                             "sc3 = sh3 = NULL selects the projection-shortcut form (down_sample conv + BatchNorm of a stage's first block, ir_CSN_152.py:86-87): "
+                             "c4 = the projection's output, c3 = the block input, w4t = the projection weight transposed; no mask, no activation, no statistics rows.",
     "tuber_conv4_bwd_slabs": "workgroups = fp32 weight-gradient slabs tuber_conv4_bwd_fused produces for M rows.",
     "tuber_conv4_bwd_supported": "1 for the (C4, P) the fused conv4 backward is built for.",
     "tuber_dwconv_tile_bwd_data_bn": "tuber_dwconv_tile_bwd_data with the BatchNorm backward of bn3 (autograd of nn.BatchNorm3d, ir_CSN_152.py:56,76-77) folded into its "
