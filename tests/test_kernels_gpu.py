@@ -673,6 +673,16 @@ def test_stem(dev, N, T, H, W):
     part = torch.empty(lib.query("tuber_stem_conv_wgrad_blocks", N, T, H, W) * 512 * 64, device=dev)
     lib.call("tuber_stem_conv_bwd_weight", clip, gg, part, dwt, 0, N, T, H, W)
     close("stem conv implicit dW", dwt, wr.grad.view(64, 441), rel=2e-3)
+    # the same kernel with the BatchNorm backward apply folded into its gradient operand: bit-identical to apply + weight gradient
+    cA, cB, cC = 1 + 0.2 * rnd(64, dev=dev, seed=11), 0.1 * rnd(64, dev=dev, seed=12), 0.05 * rnd(64, dev=dev, seed=13)
+    dc = torch.empty(M, 64, device=dev, dtype=BF)
+    lib.call("tuber_bn_bwd_apply", gg, c2, cA, cB, cC, dc, M, 64)
+    dw_a, dw_b = torch.zeros(64, 441, device=dev), torch.zeros(64, 441, device=dev)
+    lib.call("tuber_stem_conv_bwd_weight", clip, dc, part, dw_a, 0, N, T, H, W)
+    lib.call("tuber_stem_conv_bwd_weight_bn", clip, gg, c2, cA, cB, cC, part, dw_b, 0, N, T, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_a, dw_b)
+    assert float(dw_a.abs().max()) > 0
     # pool fwd
     sc, sh = 1 + 0.1 * rnd(64, dev=dev, seed=3), 0.1 * rnd(64, dev=dev, seed=4)
     Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
@@ -1059,6 +1069,43 @@ def test_conv4_bwd_fused(dev, M):
     refW = dc4.t() @ bfr(z3.relu())
     close("conv4 bwd fused dW4", dW, refW, rel=2e-3)
     assert bool(torch.isfinite(slab).all())
+
+
+@pytest.mark.parametrize("M", [40, 64 * 41 + 17, 64 * 700])
+def test_entry_conv_fwd_fused(dev, M):
+    """tuber_entry_conv_fwd (conv1 + projection-shortcut conv of layer1's first bottleneck from one pass over the block input) against
+    the two tuber_gemm_nt(epi 1) launches it replaces (same MFMA k-order) and fp32 torch math; statistics rows per 64-row tile;
+    ragged M, fewer tiles than workgroups, several tiles per workgroup; eval mode without statistics"""
+    CI, P, C4 = 64, 64, 256
+    assert lib.query("tuber_entry_conv_supported", CI, P, C4) == 1 and lib.query("tuber_entry_conv_supported", 256, 64, 256) == 0
+    x = rnd(M, CI, dev=dev, seed=1).to(BF)
+    W1 = rnd(P, CI, dev=dev, seed=2, scale=CI ** -0.5).to(BF)
+    Wd = rnd(C4, CI, dev=dev, seed=3, scale=CI ** -0.5).to(BF)
+    tiles = (M + 63) // 64
+    c1 = torch.full((M, P), float("nan"), device=dev, dtype=BF)
+    cd = torch.full((M, C4), float("nan"), device=dev, dtype=BF)
+    a0, a1 = torch.full((tiles, P), float("nan"), device=dev), torch.full((tiles, P), float("nan"), device=dev)
+    d0, d1 = torch.full((tiles, C4), float("nan"), device=dev), torch.full((tiles, C4), float("nan"), device=dev)
+    lib.call("tuber_entry_conv_fwd", x, W1, CI, Wd, CI, c1, cd, a0, a1, d0, d1, M)
+    torch.cuda.synchronize()
+    for name, out, W, N, s0, s1 in (("c1", c1, W1, P, a0, a1), ("cd", cd, Wd, C4, d0, d1)):
+        g, r0, r1 = gemm_nt(x, W, M, N, CI, epi=1)
+        assert torch.equal(out, g), name                     # K = 64: the same two MFMA steps in the same order
+        ref = x.float() @ W.float().t()
+        close("entry conv %s vs fp32" % name, out, ref)
+        pad = tiles * 64 - M
+        rows = torch.cat([ref, torch.zeros(pad, N, device=dev)]).view(tiles, 64, N)
+        close("entry conv %s stats sum" % name, s0, rows.sum(1), abs_=2e-3 * float(rows.abs().sum(1).max()) + 1e-6)
+        close("entry conv %s stats sumsq" % name, s1, (rows * rows).sum(1), rel=2e-3)
+        if r0.shape == s0.shape:
+            close("entry conv %s stats rows vs gemm_nt" % name, s0, r0, abs_=1e-3 * float(r0.abs().max()) + 1e-5)
+    c1e = torch.empty(M, P, device=dev, dtype=BF)
+    cde = torch.empty(M, C4, device=dev, dtype=BF)
+    lib.call("tuber_entry_conv_fwd", x, W1, CI, Wd, CI, c1e, cde, None, None, None, None, M)
+    torch.cuda.synchronize()
+    assert torch.equal(c1e, c1) and torch.equal(cde, cd)
+    with pytest.raises(Exception):                          # statistics pointers: all four or none
+        lib.call("tuber_entry_conv_fwd", x, W1, CI, Wd, CI, c1e, cde, a0, a1, None, None, M)
 
 
 @pytest.mark.parametrize("M", [64 * 37 + 9, 64 * 1200])

@@ -26,6 +26,9 @@ BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: Ba
 JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
 BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
+STEM_BN_IN_WGRAD = not os.environ.get("TUBER_NO_STEM_BN_IN_WGRAD")   # A/B switch: the stem BatchNorm's backward apply formed inside the stem conv weight-gradient kernel
+PROJ_BWD_FUSED = not os.environ.get("TUBER_NO_PROJ_BWD_FUSED")   # A/B switch: layer1's projection shortcut backward (BatchNorm apply + data gradient + weight gradient) on the fused conv4-backward kernel's plain form
+ENTRY_CONV = not os.environ.get("TUBER_NO_ENTRY_CONV")       # A/B switch: conv1 + projection-shortcut conv of layer1's first block as one persistent kernel
 BLOCKOUT_CONV1 = not os.environ.get("TUBER_NO_BLOCKOUT_CONV1")     # A/B switch: layer1's residual join + the next block's conv1 as one persistent kernel
 CONV1_BWD_FUSED = not os.environ.get("TUBER_NO_CONV1_BWD_FUSED")   # A/B switch: layer1's bn1 backward apply + conv1 data gradient (+ join) + conv1 weight gradient as one persistent kernel
 CONV4_BWD_FUSED = not os.environ.get("TUBER_NO_CONV4_BWD_FUSED")   # A/B switch: layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel
@@ -262,8 +265,27 @@ class CSNRunner:
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
+            cd = None
             if pre_c1 is not None:
                 c1, pre_c1 = pre_c1, None
+            elif (ENTRY_CONV and d["ds"] and st == 1 and ss == 1 and lib.query("tuber_entry_conv_supported", cin, P, 4 * P) == 1):
+                # layer1's first block: conv1 and the projection-shortcut conv read the same [M, 64] input -- one persistent kernel
+                # produces both outputs (and both BatchNorms' statistics rows) from one pass over it (csrc/entry_conv.hip)
+                c1 = torch.empty(Min, P, dtype=BF, device=dev)
+                cd = torch.empty(Min, 4 * P, dtype=BF, device=dev)
+                if train:
+                    Rt = (Min + 63) // 64
+                    a0, a1 = self.ws("st0", Rt * P), self.ws("st1", Rt * P)
+                    e0, e1 = self.ws("std0", Rt * 4 * P), self.ws("std1", Rt * 4 * P)
+                else:
+                    a0 = a1 = e0 = e1 = None
+                lib.call("tuber_entry_conv_fwd", x, d["w1"], cin, d["wd"], cin, c1, cd, a0, a1, e0, e1, Min)
+                if train:
+                    self._bn_train(d["bn1"], a0, a1, Rt, Min)
+                    self._bn_train(d["bnd"], e0, e1, Rt, Min)
+                else:
+                    self._bn_eval(d["bn1"])
+                    self._bn_eval(d["bnd"])
             else:
                 c1 = torch.empty(Min, P, dtype=BF, device=dev)
                 self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
@@ -286,8 +308,7 @@ class CSNRunner:
             c4 = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
             self._gemm_stats(c3, P, d["w4"], P, c4, Mout, 4 * P, P, 1, b3.scale, b3.shift, None, b4, train)
             y = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
-            cd = None
-            if d["ds"]:
+            if d["ds"] and cd is None:
                 cd = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
                 strided = st != 1 or ss != 1
                 gather = (To, Hq, Wq, Ti, Hi, Wi, st, ss) if strided else None
@@ -485,7 +506,7 @@ class CSNRunner:
             dcd = None
             # layer1's projection shortcut (64 -> 256 channels, stride 1): the same persistent kernel in its plain form does the shortcut
             # BatchNorm's backward apply, the projection's data gradient and its weight gradient in one pass over dz and cd
-            fused = (CONV4_BWD_FUSED and d["ds"] and st == 1 and ss == 1 and need_dx and f["wd"] and not wq.hold
+            fused = (PROJ_BWD_FUSED and d["ds"] and st == 1 and ss == 1 and need_dx and f["wd"] and not wq.hold
                      and lib.query("tuber_conv4_bwd_supported", C4, cin) == 1)
             if d["ds"] and (need_dx or f["wd"] or f["bnd"]):
                 dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=(need_dx or f["wd"]) and not fused)
@@ -678,9 +699,15 @@ class CSNRunner:
         dz0 = torch.empty(M0, 64, dtype=BF, device=dev)
         bn = self.stem_bn
         lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
-        dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0, train=stem_plan["bn"], apply=stem_plan["w"])
+        # the BatchNorm backward apply (dc0 = cA*dz0 + cB*c0 + cC, a 3-pass elementwise kernel over [M0, 64]) is formed inside the
+        # weight-gradient kernel while it stages its gradient operand: dc0 never exists in HBM
+        fold = STEM_BN_IN_WGRAD and stem_plan["w"]
+        dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0, train=stem_plan["bn"], apply=stem_plan["w"] and not fold)
         if stem_plan["w"]:
             H, W = clips.shape[-2:]
             nwg = lib.query("tuber_stem_conv_wgrad_blocks", B, T, H, W)
-            lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
+            if fold:
+                lib.call("tuber_stem_conv_bwd_weight_bn", clips, dz0, c0, bn.cA, bn.cB, bn.cC, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
+            else:
+                lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
         self._join_late()

@@ -1392,12 +1392,15 @@ static int tn_tile(int N, int K) { return !((N | K) & 7) ? 64 : (long)ceil_div(N
 // 128 x 128 transpose-read tiles (gemm_tn3): layer3 / layer4 convs, FFN and class-branch linears, packed in-projections
 static int g_tn_big = -1;
 // Measured (scripts/gemm_bench.py tngroup, round 3): eight layer3 problems 68.2 -> 50.9 us, six layer4 ones 87.5 -> 82.6 us; but the
-// long-M class-branch pair (M = 16896: few tiles x few slabs underfill the chip at two workgroups per CU) 132 -> 224 us and the
-// short-M encoder FFNs (M = 704: 11 steps) 13.5 -> 20.8 us -- so only the mid-M backbone shapes take the big tiles.
+// long-M class-branch pair (M = 16896) 132 -> 224 us WITH THE SLAB COUNT OF THE SMALL TILES (2 and 1: few tiles x few slabs underfill
+// the chip at two workgroups per CU; see below) and the short-M encoder FFNs (M = 704: 11 steps) 13.5 -> 20.8 us.
 static bool tn_big(int M, int N, int K) {
     if (g_tn_big < 0) { const char* e = getenv("TUBER_TN_NO_BIG_TILES"); g_tn_big = e ? 0 : 1; }      // A/B switch
+    // long M (the class-branch FFN pair, M = 16896, 256 x 2048 and 2048 x 512): with enough slabs to fill the chip (2112 rows = 33 steps
+    // each: 8 slabs) the big tiles win there too -- 130.8 -> 81.8 us for the pair (650 TFLOP/s), 86.8 / 92.6 / 87.4 us with 12 / 6 / 4 slabs
     static int max_m = -1;
-    if (max_m < 0) { const char* e = getenv("TUBER_TN_BIG_MAX_M"); max_m = e ? atoi(e) : 8192; }
+    if (max_m < 0) { const char* e = getenv("TUBER_TN_BIG_MAX_M"); max_m = e ? atoi(e) : 32768; }
+    if (M > 8192 && (long)N * K < (1L << 19)) return false;
     return g_tn_big && M >= 2048 && M <= max_m && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
 }
 static int tn_slabs_wanted(int M, int N, int K) {

@@ -56,6 +56,13 @@ DOC = {
                                 "y = relu(bn4(c4) + shortcut) exactly as tuber_block_out_fwd writes it, kept in LDS per 64-row tile and multiplied with the next conv1 weight from there "
                                 "(c1 + the partial statistics rows of tuber_gemm_nt epi 1) -- y is written once and not read back. models/backbones/ir_CSN_152.py:84-90 then :72-74.",
     "tuber_blockout_conv1_supported": "1 for the (block-output channels, next conv1 output channels) the fused forward kernel is built for.",
+    "tuber_stem_conv_bwd_weight_bn": "tuber_stem_conv_bwd_weight with the stem BatchNorm's backward apply folded into its gradient operand: takes the masked gradient of "
+                                     "bn's output (tuber_stem_pool_bwd), the raw conv output and cA / cB / cC of tuber_bn_bwd_finalize; G = bf16(cA*dz0 + cB*c0 + cC) is formed "
+                                     "while the tile is parked in LDS. Replaces tuber_bn_bwd_apply + tuber_stem_conv_bwd_weight (autograd of ir_CSN_152.py:131-133).",
+    "tuber_entry_conv_fwd": "layer1's first bottleneck: conv1 (64 -> 64) and the projection-shortcut conv (64 -> 256) from ONE pass over the block input "
+                            "x [M, 64] (persistent 64-row tiles, both weight matrices resident in LDS), with the per-64-row statistics rows of both outputs "
+                            "(what tuber_gemm_nt epi 1 writes; NULL in eval mode). models/backbones/ir_CSN_152.py:72-74 and :86-87.",
+    "tuber_entry_conv_supported": "1 for the (block input channels, conv1 output channels, projection output channels) the fused entry kernel is built for.",
     "tuber_conv4_bwd_fused": "backward of the bottleneck's second pointwise conv through bn4, for the wide-activation stage (C4 = 256, P = 64: layer1), as ONE persistent kernel: "
                              "dc4 = cA*dz + cB*c4 + cC (bn4 backward apply; coefficients from tuber_bn_bwd_finalize) is formed per 64-row tile in LDS and feeds BOTH the data gradient "
                              "dz3 = (dc4 . W4) * [bn3(c3) > 0] (+ the per-tile statistics rows tuber_gemm_nt epi 2 writes) and the weight gradient dW4 = dc4^T . relu(bn3(c3)) "

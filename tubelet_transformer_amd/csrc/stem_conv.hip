@@ -244,12 +244,19 @@ __device__ __forceinline__ bf16x8 stem_frag_shift(const bf16* row, int m0, int s
 // dW'[k'][n] partials: one [512][64] fp32 slab per workgroup.  8 waves: wave = nh*4 + rb; nh picks the channel half (n-tiles
 // 2nh, 2nh+1), rb the run block (tile row i <-> run = rb*16 + i), and the wave's 7 MFMA k'-tiles are the 7 kw of that block --
 // so the fragment shift (kw/2) and the even/odd plane (kw&1) are compile-time.  56 accumulator VGPRs per lane.
-template <int MINW>
+// BNG: the stem BatchNorm's backward apply folded into the G operand (tuber_stem_conv_bwd_weight_bn): G = the masked gradient dz0 of
+// bn's output, X = the raw conv output c0, and the gradient tile is formed as bf16(cA*dz0 + cB*c0 + cC) -- the arithmetic of
+// tuber_bn_bwd_apply -- while it is parked in LDS: the [M, 64] gradient of the raw conv output never exists in HBM.
+template <int MINW, bool BNG>
 __global__ __launch_bounds__(WG_THREADS, MINW) void stem_conv_bwd_w_kernel(const float* __restrict__ clip, const bf16* __restrict__ G,
+                                                                       const bf16* __restrict__ X, const float* __restrict__ cA,
+                                                                       const float* __restrict__ cB, const float* __restrict__ cC,
                                                                        float* __restrict__ partial, StemGeom g) {
     __shared__ __attribute__((aligned(16))) bf16 PE[64][EOW];
     __shared__ __attribute__((aligned(16))) bf16 PO[64][EOW];
     __shared__ __attribute__((aligned(16))) bf16 GT[64][72];            // [n][m], m contiguous, 144-byte rows (16 B aligned)
+    __shared__ __attribute__((aligned(16))) float COEF[3][64];          // BNG: cA | cB | cC (read per tile: 12 registers less across the MFMAs)
+    if (BNG && threadIdx.x < 64) { COEF[0][threadIdx.x] = cA[threadIdx.x]; COEF[1][threadIdx.x] = cB[threadIdx.x]; COEF[2][threadIdx.x] = cC[threadIdx.x]; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, gq = lane >> 4;
     f32x4 acc[7][2];
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void stem_conv_bwd_w_kernel(const
     // in LDS, so that they are in flight during tile t's MFMAs
     float4 pre[5];
     StemMeta meta;
-    uint2 gr[2];
+    uint2 gr[2], gx[2];
     const StemLane L = stem_lane(g);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int nh = wv >> 2, rb = wv & 3;
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void stem_conv_bwd_w_kernel(const
         for (int j = 0; j < 2; ++j) {
             const int w = st.wt * SW + mi * 2 + j;
             gr[j] = w < g.Wo ? *(const uint2*)(G + (st.row0 + mi * 2 + j) * 64 + ci * 4) : make_uint2(0, 0);
+            if (BNG) gx[j] = w < g.Wo ? *(const uint2*)(X + (st.row0 + mi * 2 + j) * 64 + ci * 4) : make_uint2(0, 0);
         }
     };
     const StemWalk wk = stem_walk(g.ntiles);
@@ -283,7 +291,19 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void stem_conv_bwd_w_kernel(const
         __syncthreads();                                     // previous tile's MFMAs are done with PE / PO / GT
         stem_park_eo(PE, PO, pre, meta, L, wv);
         {
-            const bf16x4 x0 = as_bf16x4(gr[0]), x1 = as_bf16x4(gr[1]);
+            bf16x4 x0 = as_bf16x4(gr[0]), x1 = as_bf16x4(gr[1]);
+            if (BNG) {      // (columns beyond Wo: dz0 = c0 = 0 were substituted, but cC is not zero -- those rows must stay zero)
+                const StemTile st = stem_tile(g, tile);
+                const bool ok0 = st.wt * SW + mi * 2 < g.Wo, ok1 = st.wt * SW + mi * 2 + 1 < g.Wo;
+                const float4 a = *(const float4*)&COEF[0][ci * 4], b = *(const float4*)&COEF[1][ci * 4], c = *(const float4*)&COEF[2][ci * 4];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
+                const bf16x4 y0 = as_bf16x4(gx[0]), y1 = as_bf16x4(gx[1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x0[q] = ok0 ? f2bf(fmaf(av[q], bf2f(x0[q]), fmaf(bv[q], bf2f(y0[q]), cv[q]))) : (bf16)0.f;
+                    x1[q] = ok1 ? f2bf(fmaf(av[q], bf2f(x1[q]), fmaf(bv[q], bf2f(y1[q]), cv[q]))) : (bf16)0.f;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) *(bf16x2*)&GT[ci * 4 + c][mi * 2] = bf16x2{x0[c], x1[c]};
         }
@@ -391,8 +411,22 @@ int tuber_stem_conv_bwd_weight(const float* clip, const void* G, float* partial,
     if (B <= 0 || T <= 0 || H < 7 || W < 7) return TUBER_EINVAL;
     const StemGeom g = stem_geom(B, T, H, W);
     const int nwg = tuber_stem_conv_wgrad_blocks(B, T, H, W);
-    if (nwg > 256) hipLaunchKernelGGL(stem_conv_bwd_w_kernel<4>, dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)G, partial, g);
-    else hipLaunchKernelGGL(stem_conv_bwd_w_kernel<2>, dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)G, partial, g);
+    if (nwg > 256) hipLaunchKernelGGL((stem_conv_bwd_w_kernel<4, false>), dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)G, nullptr, nullptr, nullptr, nullptr, partial, g);
+    else hipLaunchKernelGGL((stem_conv_bwd_w_kernel<2, false>), dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)G, nullptr, nullptr, nullptr, nullptr, partial, g);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(KP * 64 / 32), dim3(1024), 0, stream, partial, dW, nwg, accumulate);
+    TUBER_RETURN_LAUNCH();
+}
+
+// The same with the stem BatchNorm's backward apply folded in: dz0 = gradient of bn's output after the ReLU / pool backward
+// (tuber_stem_pool_bwd), c0 = raw conv output, cA / cB / cC [64] from tuber_bn_bwd_finalize; G = bf16(cA*dz0 + cB*c0 + cC) is formed on
+// load (bit-identical to tuber_bn_bwd_apply followed by tuber_stem_conv_bwd_weight, without the [M, 64] tensor in between).
+int tuber_stem_conv_bwd_weight_bn(const float* clip, const void* dz0, const void* c0, const float* cA, const float* cB, const float* cC,
+                                  float* partial, float* dW, int accumulate, int B, int T, int H, int W, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || H < 7 || W < 7 || !dz0 || !c0 || !cA || !cB || !cC) return TUBER_EINVAL;
+    const StemGeom g = stem_geom(B, T, H, W);
+    const int nwg = tuber_stem_conv_wgrad_blocks(B, T, H, W);
+    if (nwg > 256) hipLaunchKernelGGL((stem_conv_bwd_w_kernel<4, true>), dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)dz0, (const bf16*)c0, cA, cB, cC, partial, g);
+    else hipLaunchKernelGGL((stem_conv_bwd_w_kernel<2, true>), dim3(nwg), dim3(WG_THREADS), 0, stream, clip, (const bf16*)dz0, (const bf16*)c0, cA, cB, cC, partial, g);
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(KP * 64 / 32), dim3(1024), 0, stream, partial, dW, nwg, accumulate);
     TUBER_RETURN_LAUNCH();
 }
