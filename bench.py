@@ -87,7 +87,14 @@ def alg_cost(name, a):
         return "dwconv_tile_kernel<%d>" % mode, 2 * el * (3 if mode == 1 else 2), 2 * 27 * el
     if name == "tuber_conv4_bwd_fused":          # reads dz, c4 [M,256] and c3 [M,64], writes dz3 [M,64]; conv4 data + weight gradient
         M = a[14]
-        return "conv4_bwd_kernel", 2 * M * (256 + 256 + 64 + 64), 2 * 2 * M * 256 * 64
+        return "conv4_bwd_kernel<%s>" % ("true" if a[8] is None else "false"), 2 * M * (256 + 256 + 64 + 64), 2 * 2 * M * 256 * 64
+    if name == "tuber_entry_conv_fwd":           # reads x [M,64], writes c1 [M,64] and cd [M,256]
+        M = a[11]
+        return "entry_conv_kernel", 2 * M * (64 + 64 + 256), 2 * M * 64 * 320
+    if name == "tuber_stem_conv_bwd_weight_bn":  # reads the clip, dz0 and c0 [Mo,64]
+        B, T, H, W = a[9:13]
+        Mo = B * T * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        return "stem_conv_bwd_w_kernel", 4 * B * 3 * T * H * W + 2 * 2 * Mo * 64, 2 * Mo * 64 * 441
     if name == "tuber_blockout_conv1_fwd":       # reads c4 and the shortcut, writes y [M,256] and the next conv1 output [M,pn]
         M, pn = a[12], a[13]
         return "blockout_conv1_kernel<%d>" % pn, 2 * M * (3 * 256 + pn), 2 * M * 256 * pn
@@ -126,6 +133,8 @@ def shape_of(name, a):
         return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])
     if name in ("tuber_conv4_bwd_fused", "tuber_conv1_bwd_fused"):
         return "M%d" % a[14]
+    if name == "tuber_entry_conv_fwd":
+        return "M%d" % a[11]
     if name == "tuber_blockout_conv1_fwd":
         return "M%d pn%d" % (a[12], a[13])
     if name in ("tuber_bn_bwd_apply", "tuber_block_out_fwd", "tuber_block_out_bwd", "tuber_bn_finalize", "tuber_bn_bwd_finalize",

@@ -28,6 +28,7 @@ BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")  
 LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
 STEM_BN_IN_WGRAD = not os.environ.get("TUBER_NO_STEM_BN_IN_WGRAD")   # A/B switch: the stem BatchNorm's backward apply formed inside the stem conv weight-gradient kernel
 PROJ_BWD_FUSED = not os.environ.get("TUBER_NO_PROJ_BWD_FUSED")   # A/B switch: layer1's projection shortcut backward (BatchNorm apply + data gradient + weight gradient) on the fused conv4-backward kernel's plain form
+DW_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_DW_BWD_ONE_LAUNCH")   # A/B switch: depthwise data + weight gradient of a stride-1 block in one launch
 ENTRY_CONV = not os.environ.get("TUBER_NO_ENTRY_CONV")       # A/B switch: conv1 + projection-shortcut conv of layer1's first block as one persistent kernel
 BLOCKOUT_CONV1 = not os.environ.get("TUBER_NO_BLOCKOUT_CONV1")     # A/B switch: layer1's residual join + the next block's conv1 as one persistent kernel
 CONV1_BWD_FUSED = not os.environ.get("TUBER_NO_CONV1_BWD_FUSED")   # A/B switch: layer1's bn1 backward apply + conv1 data gradient (+ join) + conv1 weight gradient as one persistent kernel
@@ -543,7 +544,20 @@ class CSNRunner:
                 else:
                     dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
-            if f["w3"]:
+            # (stride-1 blocks with the bn3 fold: both gradients are independent of each other and run as ONE launch -- in the short-T
+            #  stages most of such a kernel's duration is ramp-up / prologue latency / drain)
+            both = (DW_BWD_ONE_LAUNCH and fuse3 and f["w3"] and depth >= 5 and not self.store.wq.hold and self.store.defer.enabled)
+            if both:
+                nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P)
+                part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
+                R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P)
+                s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
+                dz1 = torch.empty(Min, P, dtype=BF, device=dev)
+                lib.call("tuber_dwconv_tile_bwd_both_bn", *bn3, b3.dgamma if f["bn3"] else None, b3.dbeta if f["bn3"] else None,
+                         d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, part, B, Ti, Hi, Wi, P)
+                g3 = d["g3"]
+                self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
+            elif f["w3"]:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
 
@@ -566,10 +580,13 @@ class CSNRunner:
                     dw_wgrad()
             dc1 = None
             if depth >= 5:
-                R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
-                s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
-                dz1 = torch.empty(Min, P, dtype=BF, device=dev)
-                if fuse3:
+                if not both:
+                    R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_data_stat_rows", B, Ti, Hi, Wi)
+                    s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
+                    dz1 = torch.empty(Min, P, dtype=BF, device=dev)
+                if both:
+                    pass
+                elif fuse3:
                     lib.call("tuber_dwconv_tile_bwd_data_bn", *bn3, b3.dgamma if f["bn3"] else None, b3.dbeta if f["bn3"] else None,
                              d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, B, Ti, Hi, Wi, P)
                 elif tile:

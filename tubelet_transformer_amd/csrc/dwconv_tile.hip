@@ -52,14 +52,15 @@ struct TileArgs {
     TileGeom g;
 };
 
+// (bx, by) = the workgroup's position in ITS problem's grid: the kernels below pass blockIdx, the merged backward launch an offset one
 template <int MODE, bool BNG = false>
-__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
+__device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
     const TileGeom g = a.g;
     const int tid = threadIdx.x;
     const int cl = tid & 15, slot = tid >> 4, row = slot >> 2, cg = slot & 3;
-    const int c0 = blockIdx.y * 64, c = c0 + cl * 4;
-    int b = blockIdx.x;
+    const int c0 = by * 64, c = c0 + cl * 4;
+    int b = bx;
     const int wt = b % g.wtiles; b /= g.wtiles;
     const int ht = b % g.htiles; b /= g.htiles;
     const int tk = b % g.tchunks; const int n = b / g.tchunks;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
             coef[0 * 64 + tid] = (float)(gm * rr);
             coef[1 * 64 + tid] = (float)(-gm * rr * rr * m2);
             coef[2 * 64 + tid] = (float)(gm * rr * rr * m2 * mu - gm * rr * m1);
-            if (blockIdx.x == 0 && a.bdgamma) {
+            if (bx == 0 && a.bdgamma) {
                 a.bdgamma[cc] += (float)sum_dz_xhat;
                 a.bdbeta[cc] += (float)sum_dz;
             }
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
 #pragma unroll
             for (int wv8 = 0; wv8 < 8; ++wv8) s += red[wv8 * 27 * 64 + i];
             const int tap = i >> 6, cc = i & 63;
-            a.P[((long)blockIdx.x * 27 + tap) * g.C + c0 + cc] = s;
+            a.P[((long)bx * 27 + tap) * g.C + c0 + cc] = s;
         }
     } else if (a.st0) {
 #pragma unroll
@@ -353,9 +354,21 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 32; ++k) s += red[(which * 32 + k) * 64 + cc];
-            (which ? a.st1 : a.st0)[(long)blockIdx.x * g.C + c0 + cc] = s;
+            (which ? a.st1 : a.st0)[(long)bx * g.C + c0 + cc] = s;
         }
     }
+}
+
+template <int MODE, bool BNG = false>
+__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG>(a, blockIdx.x, blockIdx.y); }
+
+// Data gradient AND weight gradient of one depthwise conv (both with the BatchNorm backward above folded in) as ONE launch: the two are
+// independent of each other and, in the short-T stages, one round of 256 one-plane workgroups each -- two thirds of such a kernel's
+// duration is ramp-up, the dependent prologue fetch and drain.  Workgroups [0, nd) are the data gradient's grid, the rest the weight
+// gradient's; results are bit-identical to the two launches.
+__global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs ad, TileArgs aw, int nd) {
+    if ((int)blockIdx.x < nd) dwconv_tile_body<M_BWD_DATA, true>(ad, blockIdx.x, blockIdx.y);
+    else dwconv_tile_body<M_BWD_WEIGHT, true>(aw, blockIdx.x - nd, blockIdx.y);
 }
 
 TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
@@ -471,6 +484,33 @@ int tuber_dwconv_tile_bwd_weight_bn(const void* dzu, const void* xu, const float
     const int rc = launch_tile<M_BWD_WEIGHT, true>(a, stream);
     if (rc || accumulate == 2) return rc;
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
+}
+
+// tuber_dwconv_tile_bwd_data_bn and tuber_dwconv_tile_bwd_weight_bn of the same conv in ONE launch (same arguments, same results bit for
+// bit; the weight gradient's partial blocks are reduced by the caller: accumulate must be 2).
+int tuber_dwconv_tile_bwd_both_bn(const void* dzu, const void* xu, const float* bst0, const float* bst1, int R, float count,
+                                  const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                  const float* w, const void* x, const float* sc, const float* sh, void* dz, float* st0, float* st1,
+                                  float* partial, int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || !sc || !sh || R <= 0 || R > 128 || !bst0 || !bst1 || !partial || !dz || !st0 || !st1) return TUBER_EINVAL;
+    TileArgs ad{}, aw{};
+    ad.in = (const bf16*)dzu; ad.xu = (const bf16*)xu; ad.sc = sc; ad.sh = sh; ad.w = w; ad.out = (bf16*)dz; ad.aux = (const bf16*)x;
+    ad.st0 = st0; ad.st1 = st1;
+    ad.bst0 = bst0; ad.bst1 = bst1; ad.bR = R; ad.bcount = count; ad.bgamma = gamma; ad.bmean = mean; ad.binvstd = invstd;
+    ad.bdgamma = dgamma; ad.bdbeta = dbeta;
+    ad.g = make_geom(N, T, H, W, C);
+    aw.in = (const bf16*)x; aw.sc = sc; aw.sh = sh; aw.aux = (const bf16*)dzu; aw.xu = (const bf16*)xu; aw.P = partial;
+    aw.bst0 = bst0; aw.bst1 = bst1; aw.bR = R; aw.bcount = count; aw.bgamma = gamma; aw.bmean = mean; aw.binvstd = invstd;
+    aw.g = make_geom(N, T, H, W, C, true);
+    const int nd = ad.g.N * ad.g.tchunks * ad.g.htiles * ad.g.wtiles, nw = aw.g.N * aw.g.tchunks * aw.g.htiles * aw.g.wtiles;
+    const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)dwconv_tile_bwd_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dwconv_tile_bwd_both_kernel, dim3(nd + nw, C / 64), dim3(512), lds, stream, ad, aw, nd);
+    TUBER_RETURN_LAUNCH();
 }
 
 }  // extern "C"

@@ -76,6 +76,9 @@ DOC = {
                                      "gradient operand: takes bn3's masked output gradient dzu, bn3's input xu (= c3) and the R <= 128 partial rows (sum dz, sum dz*x) "
                                      "instead of a finished dc3; every workgroup derives cA / cB / cC of its 64 channels (fp64) and forms dc3 = cA*dzu + cB*xu + cC "
                                      "in fp32 while staging. dgamma / dbeta of bn3 are accumulated (+=) unless NULL. Replaces tuber_bn_bwd_fa + tuber_dwconv_tile_bwd_data.",
+    "tuber_dwconv_tile_bwd_both_bn": "tuber_dwconv_tile_bwd_data_bn and tuber_dwconv_tile_bwd_weight_bn of the same depthwise conv in ONE launch (the two gradients are "
+                                     "independent; workgroups [0, data grid) run the data gradient, the rest the weight gradient). Bit-identical results; the weight "
+                                     "gradient's partial blocks [tuber_dwconv_tile_wgrad_blocks][27][C] are left for the caller's tuber_multi_reduce.",
     "tuber_dwconv_tile_bwd_weight_bn": "tuber_dwconv_tile_bwd_weight with the same fold: the output-position gradient is formed from (dzu, xu, partial rows) on load.",
     "tuber_comm_init_timeout": "tuber_comm_init with a deadline: the bootstrap (a collective) runs on a helper thread and the call returns -3 with a message naming "
                                "the waiting rank when its peers have not arrived after timeout_ms -- a dead rank fails the job loudly instead of hanging it "
