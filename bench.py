@@ -76,6 +76,9 @@ def alg_cost(name, a):
     if name == "tuber_dwconv_tile_bwd_data_bn":
         N, T, H, W, C = a[18:23]
         return "dwconv_tile_kernel<1,true>", 2 * C * N * T * H * W * 4, 2 * 27 * C * N * T * H * W
+    if name == "tuber_dwconv_tile_bwd_both_bn":  # data gradient (reads dzu, xu, x; writes dz) + weight gradient (reads dzu, xu, x)
+        N, T, H, W, C = a[19:24]
+        return "dwconv_tile_bwd_both_kernel", 2 * C * N * T * H * W * 7, 2 * 2 * 27 * C * N * T * H * W
     if name == "tuber_dwconv_tile_bwd_weight_bn":
         N, T, H, W, C = a[15:20]
         return "dwconv_tile_kernel<2,true>", 2 * C * N * T * H * W * 3, 2 * 27 * C * N * T * H * W
@@ -141,7 +144,8 @@ def shape_of(name, a):
                 "tuber_reduce_rows", "tuber_colsum", "tuber_reduce_slabs", "tuber_layernorm_fwd", "tuber_layernorm_bwd", "tuber_dropout"):
         return " ".join(str(x) for x in a if isinstance(x, int) and not isinstance(x, bool))[:44]
     if name.startswith("tuber_dwconv_tile"):
-        off = {"tuber_dwconv_tile_bwd_data": 8, "tuber_dwconv_tile_bwd_data_bn": 18, "tuber_dwconv_tile_bwd_weight_bn": 15}.get(name, 7)
+        off = {"tuber_dwconv_tile_bwd_data": 8, "tuber_dwconv_tile_bwd_data_bn": 18, "tuber_dwconv_tile_bwd_weight_bn": 15,
+               "tuber_dwconv_tile_bwd_both_bn": 19}.get(name, 7)
         return "N%d %dx%dx%d C%d" % tuple(a[off:off + 5])
     if name.startswith("tuber_dwconv"):
         off = {"tuber_dwconv_fwd": 7, "tuber_dwconv_bwd_data": 8, "tuber_dwconv_bwd_weight": 7}[name]
