@@ -225,7 +225,7 @@ def dominant_from_trace(prepass, headline):
         for nk, k in keys.items():
             base = nk.split("<")[0]
             if name.startswith(nk + "(") or name == nk or ("<" not in nk and re.search(r"\d+" + re.escape(base) + r"(P|ILi|\b)", name)) or \
-                    ("<" in nk and name.startswith(nk)):
+                    ("<" in nk and name.startswith(nk[:-1] + ",")) or ("<" in nk and name.startswith(nk)):      # (trace names carry trailing template parameters)
                 return k
     return None
 
@@ -511,7 +511,8 @@ def main():
             if pm:
                 kk = _json.load(open(pm[-1]))["kernels"]
                 fam = dominant.replace(" ", "")
-                traffic = (kk.get(fam) or kk.get(fam.split("<")[0]) or {}).get("hbm_bytes_per_launch")
+                cand = [v for k_, v in kk.items() if fam.endswith(">") and k_.startswith(fam[:-1] + ",")]      # trailing template parameters
+                traffic = (kk.get(fam) or (cand[0] if cand else None) or kk.get(fam.split("<")[0]) or {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
         mfma_util, rp_avg = None, None     # from the committed PMC / kernel-trace passes of this command (profiles/), for cross-checking
@@ -519,11 +520,15 @@ def main():
             import re
             mu = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma_util.json")))
             if mu:
-                mfma_util = (_json.load(open(mu[-1]))["kernels"].get(dominant.replace(",", ", ")) or _json.load(open(mu[-1]))["kernels"].get(dominant) or {}).get("mfma_util")
+                mk = _json.load(open(mu[-1]))["kernels"]
+                dsp = dominant.replace(",", ", ")
+                cand = [v for k_, v in mk.items() if dsp.endswith(">") and k_.startswith(dsp[:-1] + ",")]
+                mfma_util = (mk.get(dsp) or mk.get(dominant) or (cand[0] if cand else None) or {}).get("mfma_util")
             kt = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_trace_stats.txt")) if not re.search(r"_(cfg\d|freeze)_", os.path.basename(f)))
             if kt and headline:
                 for ln in open(kt[-1]).read().splitlines()[2:]:
-                    if re.sub(r"\s+", "", dominant) in re.sub(r"\s+", "", ln.split("  ")[0]):
+                    dn, tn = re.sub(r"\s+", "", dominant), re.sub(r"\s+", "", ln.split("  ")[0])
+                    if dn in tn or (dn.endswith(">") and dn[:-1] + "," in tn):
                         rp_avg = float(ln.split()[-4])
                         break
         except Exception:
