@@ -62,7 +62,10 @@ __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3)
 // through LDS in wave order before the common epilogue.  For the shapes whose time is their k-loop (layer3 / layer4 1x1x1 convs with
 // K >= 1024 on 352 workgroups, the FFN GEMMs with K = 2048 on 11 .. 44): a k-tile costs ~0.24 us of barriers and exposed latency in
 // the shared-tile loop whatever it computes.
-template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC, int WSK = 0>
+// FULL: N is a multiple of the tile width and every leading dimension of the epilogue's tensors a multiple of 8 (all conv / FFN shapes of
+// the model): the per-column bounds checks (an exec-mask branch per output column and row block) and the scalar fall-back paths of the
+// epilogue are compiled out.
+template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC, int WSK = 0, bool FULL = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     static_assert(!WSK || (BM == 64 && BN == 64 && WM == 2 && WN == 2 && AMODE == A_PLAIN), "wave split-K: 64x64 tiles, plain A");
     constexpr int KS = 1, kg = 0;               // (the in-workgroup k-split of round 1 was measured and dropped; the index math keeps its shape)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     // ---- first k-group and the epilogue's side inputs go out before anything waits ----
     constexpr int NC = 4 * NT;
     const int nb = n0 + wn * TN + g * NC;
-    const bool vec_ok = (nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0);
+    const bool vec_ok = FULL || ((nb + NC <= p.N) && ((p.ldc & 7) == 0) && ((p.N & 7) == 0));
     if constexpr (!WSK) {
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     constexpr bool SIDE = EPI == EPI_BWD || EPI == EPI_JOIN;
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
     uint4 sidey[EPI == EPI_JOIN ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
-    const bool side_vec = SIDE && vec_ok && ((p.ldcm & 7) == 0) && (EPI != EPI_JOIN || (p.ldym & 7) == 0);
+    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (EPI != EPI_JOIN || (p.ldym & 7) == 0)));
     if (SIDE && side_vec) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     if (EPI == EPI_BWD) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const bool ok = nb + c < p.N;
+            const bool ok = FULL || nb + c < p.N;
             msc[c] = (p.m_scale && ok) ? p.m_scale[nb + c] : 1.f;
             msh[c] = (p.m_shift && ok) ? p.m_shift[nb + c] : 0.f;
         }
@@ -394,10 +397,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         if (EPI == EPI_PLAIN) {
             if (p.bias) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += p.bias[nb + c];
+                for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += p.bias[nb + c];
             }
             if (p.R && mok) {
-                if (vec_ok && (p.ldr & 7) == 0) {
+                if (FULL || (vec_ok && (p.ldr & 7) == 0)) {
 #pragma unroll
                     for (int c8 = 0; c8 < NC / 8; ++c8) {
                         const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + (long)m * p.ldr + nb + c8 * 8));
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                    for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
                 }
             }
             if (p.relu) {
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         } else if (EPI == EPI_JOIN) {
             if (mok) {
                 if (p.R) {
-                    if (vec_ok && (p.ldr & 7) == 0) {
+                    if (FULL || (vec_ok && (p.ldr & 7) == 0)) {
 #pragma unroll
                         for (int c8 = 0; c8 < NC / 8; ++c8) {
                             const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + (long)m * p.ldr + nb + c8 * 8));
@@ -436,12 +439,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                         }
                     } else {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) if (nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                        for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    if (nb + c < p.N) {
+                    if (FULL || nb + c < p.N) {
                         const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
                         const float yv = side_vec ? bf2f(as_bf16x8(sidey[EPI == EPI_JOIN ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c]);
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             if (mok) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    if (nb + c < p.N) {
+                    if (FULL || nb + c < p.N) {
                         const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
                         const float z = fmaf(cv, msc[c], msh[c]);
                         v[c] = z > 0.f ? v[c] : 0.f;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             if (EPI == EPI_PLAIN && p.out_f32) {
                 float* o = (float*)p.C + (long)m * p.ldc + nb;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) if (nb + c < p.N) o[c] = v[c];
+                for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) o[c] = v[c];
             } else {
                 bf16* o = (bf16*)p.C + (long)m * p.ldc + nb;
                 if (vec_ok) {
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) if (nb + c < p.N) o[c] = f2bf(v[c]);
+                    for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) o[c] = f2bf(v[c]);
                 }
             }
         }
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
         __syncthreads();
-        if (epi_on && tid < BN && n0 + tid < p.N) {
+        if (epi_on && tid < BN && (FULL || n0 + tid < p.N)) {
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
@@ -510,9 +513,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     }
 }
 
+// every output column of every tile exists and every epilogue tensor can be read / written in 16-byte pieces
+static bool nt_full(const GemmNT& p, int bn) {
+    static int on = -1;
+    if (on < 0) on = getenv("TUBER_NT_NO_FULL") ? 0 : 1;       // A/B switch
+    return on && p.N % bn == 0 && !(p.ldc & 7) && !p.out_f32 && (!p.Cm || !(p.ldcm & 7)) && (!p.Ym || !(p.ldym & 7)) && (!p.R || !(p.ldr & 7));
+}
+
 template <int BM, int BN, int WM, int WN, int G, int OCC>
 static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    const bool full = nt_full(p, BN);
     const size_t lds = 2 * (BM + BN) * 128 + (amode == A_BN_RELU ? (size_t)p.K * 8 : (amode == A_BN_BWD ? (size_t)p.K * 12 : 0));
     dim3 grid(tiles), block(256);
 #define LNT(AM, EP)                                                                                                   \
@@ -522,10 +533,13 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
             if (!done) {                                                                                              \
                 (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>,                    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC, 0, true>,           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
                 done = true;                                                                                          \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), grid, block, lds, s, p);                     \
+        if (full) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC, 0, true>), grid, block, lds, s, p);         \
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), grid, block, lds, s, p);                \
     } while (0)
     if (amode == A_PLAIN) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
@@ -554,7 +568,12 @@ static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
     const int tiles = ceil_div(p.M, 64) * ceil_div(p.N, 64);
     dim3 grid(tiles), block(256);
     const size_t lds = 4 * 16384;
-#define LWSK(EP) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, 2, A_PLAIN, EP, 2, 1>), grid, block, lds, s, p)
+    const bool full = nt_full(p, 64);
+#define LWSK(EP)                                                                                                               \
+    do {                                                                                                                       \
+        if (full) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, 2, A_PLAIN, EP, 2, 1, true>), grid, block, lds, s, p);       \
+        else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, 2, A_PLAIN, EP, 2, 1>), grid, block, lds, s, p);                  \
+    } while (0)
     if (epi == EPI_PLAIN) LWSK(EPI_PLAIN);
     else if (epi == EPI_STATS) LWSK(EPI_STATS);
     else if (epi == EPI_JOIN) LWSK(EPI_JOIN);
