@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv4_bwd_kernel(Conv4BwdArgs a) {
         bf16x8 o;                                                                 \
         const bool ok = m0 + row < a.M;                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e)                             \
-            o[e] = f2bf(ok ? fmaf(kA[e], bf2f(z[e]), fmaf(kB[e], bf2f(x[e]), kC[e])) : 0.f); \
-        *(uint4*)(gimg + goff(row, gch * 8)) = as_uint4(o);                       \
+            o[e] = f2bf(fmaf(kA[e], bf2f(z[e]), fmaf(kB[e], bf2f(x[e]), kC[e])));  \
+        /* (rows beyond M were loaded from row M-1: computed, then cleared as a whole -- a select per element became a branch each) */ \
+        *(uint4*)(gimg + goff(row, gch * 8)) = ok ? as_uint4(o) : make_uint4(0, 0, 0, 0); \
     } while (0)
     long t = blockIdx.x;
     LOAD_TILE(t);                                        // the grid never exceeds the tile count
