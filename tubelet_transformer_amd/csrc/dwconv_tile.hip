@@ -156,10 +156,20 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
             for (int e = 0; e < 4; ++e) { red[(0 * 32 + rg) * 64 + q * 4 + e] = sa[e]; red[(1 * 32 + rg) * 64 + q * 4 + e] = sb[e]; }
         }
         __syncthreads();
-        if (tid < 64) {
-            double sa = 0.0, sb = 0.0;
+        // two levels (all 512 threads sum 8 row groups each, then 64 threads sum 4): the 32-entry serial fp64 chain of one wave was ~2 us of
+        // every workgroup's prologue.  (fp64 sums of fp32 partial rows are exact, so the association does not change the result.)
+        double* red2 = red + 2 * 32 * 64;                // [2][4][64]
+        {
+            const int which = tid >> 8, part = (tid >> 6) & 3, ch = tid & 63;
+            double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) { sa += red[(0 * 32 + k) * 64 + tid]; sb += red[(1 * 32 + k) * 64 + tid]; }
+            for (int k = 0; k < 8; ++k) s += red[(which * 32 + part * 8 + k) * 64 + ch];
+            red2[(which * 4 + part) * 64 + ch] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const double sa = (red2[(0 * 4 + 0) * 64 + tid] + red2[(0 * 4 + 1) * 64 + tid]) + (red2[(0 * 4 + 2) * 64 + tid] + red2[(0 * 4 + 3) * 64 + tid]);
+            const double sb = (red2[(1 * 4 + 0) * 64 + tid] + red2[(1 * 4 + 1) * 64 + tid]) + (red2[(1 * 4 + 2) * 64 + tid] + red2[(1 * 4 + 3) * 64 + tid]);
             const int cc = c0 + tid;
             const double mu = a.bmean[cc], rr = a.binvstd[cc], gm = a.bgamma[cc];
             const double sum_dz = sa, sum_dz_xhat = (sb - mu * sa) * rr;
