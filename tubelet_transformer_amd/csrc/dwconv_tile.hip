@@ -53,7 +53,7 @@ struct TileArgs {
 };
 
 // (bx, by) = the workgroup's position in ITS problem's grid: the kernels below pass blockIdx, the merged backward launch an offset one
-template <int MODE, bool BNG = false>
+template <int MODE, bool BNG = false, bool ACT = true>
 __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
     const TileGeom g = a.g;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
     int s_off[NLD], s_lds[NLD];
     bool s_ok[NLD];
     float sa[4] = {1.f, 1.f, 1.f, 1.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};   // (tid + 512 i) & 15 == cl: one channel quad per thread
-    const bool act = (MODE != M_BWD_DATA) && a.sc != nullptr;
+    constexpr bool act = MODE != M_BWD_DATA && ACT;     // forward / weight gradient stage relu(bn1(.)); ACT = false: the plain forward conv (no scale / shift given)
     if (act) {
         const float4 s = *(const float4*)(a.sc + c), h = *(const float4*)(a.sh + c);
         sa[0] = s.x; sa[1] = s.y; sa[2] = s.z; sa[3] = s.w; sb[0] = h.x; sb[1] = h.y; sb[2] = h.z; sb[3] = h.w;
@@ -92,15 +92,19 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
     const bf16* in2_n = STG2 ? a.xu + (long)n * g.T * plane_elems : nullptr;
     uint2 regs[NLD], regs_a[NLD], regs_b[NLD];     // regs: the steady-state prefetch set; _a / _b: the two extra planes of the prologue
     uint2 regx[STG2 ? NLD : 1], regx_a[STG2 ? NLD : 1], regx_b[STG2 ? NLD : 1];
-    auto fetch = [&](int t, uint2 (&regs)[NLD], uint2 (&rx)[STG2 ? NLD : 1]) {  // input plane t -> registers (zeros outside the volume)
+    // input plane t -> registers.  The loads are UNCONDITIONAL: slots outside the volume read element 0 of a valid plane (s_off = 0,
+    // plane 0 when t is outside) and are cleared when they are parked -- a predicated load is a saveexec / branch / restore around every
+    // one of the 18-36 loads of a prologue that is most of the kernel in the short-T stages (phase timestamps: 1.2-2.3 us of a 6.5-10 us
+    // workgroup life pass before the first load is out, at two waves per SIMD every instruction counts twice).
+    auto fetch = [&](int t, uint2 (&regs)[NLD], uint2 (&rx)[STG2 ? NLD : 1]) {
         const bool tok = t >= 0 && t < g.T;
         const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) regs[i] = (tok && s_ok[i]) ? *(const uint2*)(p + s_off[i]) : make_uint2(0, 0);
+        for (int i = 0; i < NLD; ++i) regs[i] = *(const uint2*)(p + s_off[i]);
         if constexpr (STG2) {
             const bf16* p2 = in2_n + (long)(tok ? t : 0) * plane_elems;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) rx[i] = (tok && s_ok[i]) ? *(const uint2*)(p2 + s_off[i]) : make_uint2(0, 0);
+            for (int i = 0; i < NLD; ++i) rx[i] = *(const uint2*)(p2 + s_off[i]);
         }
     };
     float kA[4] = {1.f, 1.f, 1.f, 1.f}, kB[4] = {0.f, 0.f, 0.f, 0.f}, kC[4] = {0.f, 0.f, 0.f, 0.f};     // BNG: this thread's channel quad
@@ -126,7 +130,8 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
                 o.z = ok ? fmaxf(fmaf(bf2f(v[2]), sa[2], sb[2]), 0.f) : 0.f;
                 o.w = ok ? fmaxf(fmaf(bf2f(v[3]), sa[3], sb[3]), 0.f) : 0.f;
             } else {
-                o.x = bf2f(v[0]); o.y = bf2f(v[1]); o.z = bf2f(v[2]); o.w = bf2f(v[3]);   // zeros already where outside
+                const bool ok = tok && s_ok[i];
+                o.x = ok ? bf2f(v[0]) : 0.f; o.y = ok ? bf2f(v[1]) : 0.f; o.z = ok ? bf2f(v[2]) : 0.f; o.w = ok ? bf2f(v[3]) : 0.f;
             }
             *(float4*)(dst + s_lds[i]) = o;
         }
@@ -216,13 +221,13 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
     // side inputs of an output plane (global, 8 B per column): bwd data: x (needed after the taps);  wgrad: gout (needed BEFORE the
     // taps -- so the weight gradient fetches them one plane ahead, the first ones together with the prologue planes)
     constexpr bool SD2 = BNG && MODE == M_BWD_WEIGHT;     // the side input (gout at the output position) is formed from two tensors
-    auto side_fetch = [&](int t, uint2 (&sd)[4], uint2 (&sx)[SD2 ? 4 : 1]) {
-        const long ob = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
+    auto side_fetch = [&](int t, uint2 (&sd)[4], uint2 (&sx)[SD2 ? 4 : 1]) {      // unconditional, from the clamped position (see fetch)
+        const long ob = (((long)n * g.T + t) * g.H + min(ho, g.H - 1)) * (long)g.W * g.C + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = row_ok && wo0 + j < g.W;
-            sd[j] = ok ? *(const uint2*)(a.aux + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
-            if constexpr (SD2) sx[j] = ok ? *(const uint2*)(a.xu + ob + (long)(wo0 + j) * g.C) : make_uint2(0, 0);
+            const long oc = (long)min(wo0 + j, g.W - 1) * g.C;
+            sd[j] = *(const uint2*)(a.aux + ob + oc);
+            if constexpr (SD2) sx[j] = *(const uint2*)(a.xu + ob + oc);
         }
     };
     uint2 side_nx[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
@@ -261,8 +266,9 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
                     gv[j][0] = f32x2{q[0], q[1]};
                     gv[j][1] = f32x2{q[2], q[3]};
                 } else {
-                    gv[j][0] = f32x2{bf2f(v[0]), bf2f(v[1])};
-                    gv[j][1] = f32x2{bf2f(v[2]), bf2f(v[3])};
+                    const bool ok = row_ok && wo0 + j < g.W;      // zero gradient outside the volume
+                    gv[j][0] = f32x2{ok ? bf2f(v[0]) : 0.f, ok ? bf2f(v[1]) : 0.f};
+                    gv[j][1] = f32x2{ok ? bf2f(v[2]) : 0.f, ok ? bf2f(v[3]) : 0.f};
                 }
             }
         }
@@ -369,8 +375,8 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
     }
 }
 
-template <int MODE, bool BNG = false>
-__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG>(a, blockIdx.x, blockIdx.y); }
+template <int MODE, bool BNG = false, bool ACT = true>
+__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG, ACT>(a, blockIdx.x, blockIdx.y); }
 
 // Data gradient AND weight gradient of one depthwise conv (both with the BatchNorm backward above folded in) as ONE launch: the two are
 // independent of each other and, in the short-T stages, one round of 256 one-plane workgroups each -- two thirds of such a kernel's
@@ -435,10 +441,21 @@ int tuber_dwconv_tile_wgrad_blocks(int N, int T, int H, int W, int C) {
 
 int tuber_dwconv_tile_fwd(const void* x, const float* sc, const float* sh, const float* w, void* out, float* st0, float* st1,
                           int N, int T, int H, int W, int C, hipStream_t stream) {
-    if (C & 63) return TUBER_EINVAL;
+    if ((C & 63) || (sc == nullptr) != (sh == nullptr)) return TUBER_EINVAL;
     TileArgs a{};
     a.in = (const bf16*)x; a.sc = sc; a.sh = sh; a.w = w; a.out = (bf16*)out; a.st0 = st0; a.st1 = st1;
     a.g = make_geom(N, T, H, W, C);
+    if (!sc) {                                   // plain conv (no BatchNorm + ReLU in front): its own instantiation
+        const TileGeom& g = a.g;
+        const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<M_FWD, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((dwconv_tile_kernel<M_FWD, false, false>), dim3(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), dim3(512), lds, stream, a);
+        TUBER_RETURN_LAUNCH();
+    }
     return launch_tile<M_FWD>(a, stream);
 }
 
