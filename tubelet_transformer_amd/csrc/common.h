@@ -89,6 +89,32 @@ __device__ __forceinline__ float xor16_sum(float v) { float x, y; row_swap16(v, 
 __device__ __forceinline__ float xor32_sum(float v) { float x, y; row_swap32(v, x, y); return x + y; }
 __device__ __forceinline__ float xor16_max(float v) { float x, y; row_swap16(v, x, y); return fmaxf(x, y); }
 __device__ __forceinline__ float xor32_max(float v) { float x, y; row_swap32(v, x, y); return fmaxf(x, y); }
+// fp64 forms (both 32-bit halves take the same lane exchange).  Without these overloads a double argument converts to float silently:
+// bn_partial_sums reduced its fp64 partial sums across lanes in fp32 until round 3.
+__device__ __forceinline__ double f64_of(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+__device__ __forceinline__ double xor16_sum(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const unsigned l0 = rl[0], l1 = rl[1], h0 = rh[0], h1 = rh[1];
+    return f64_of(l0, h0) + f64_of(l1, h1);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const unsigned l0 = rl[0], l1 = rl[1], h0 = rh[0], h1 = rh[1];
+    return f64_of(l0, h0) + f64_of(l1, h1);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return f64_of(lo, hi);
+}
 __device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(quad16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(quad16_max(v))); }
 

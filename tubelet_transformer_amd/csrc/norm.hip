@@ -44,8 +44,8 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, c
     // 128 row groups -> 16 (one per wave) via shuffles over the lanes sharing qd (lane bits 3..5), then LDS
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        a[e] = xor32_sum(xor16_sum(a[e] + dpp_f32<DPP_ROR8>(a[e])));
-        b[e] = xor32_sum(xor16_sum(b[e] + dpp_f32<DPP_ROR8>(b[e])));
+        a[e] = xor32_sum(xor16_sum(a[e] + dpp_f64<DPP_ROR8>(a[e])));       // (the fp64 overloads: the float ones would narrow silently)
+        b[e] = xor32_sum(xor16_sum(b[e] + dpp_f64<DPP_ROR8>(b[e])));
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < 8) {
