@@ -12,22 +12,26 @@
 // ---------------------------------------------------------------------------------------------
 // finalize kernels: one block per 32 channels, 1024 threads = 32 row-groups x 32 channels
 // ---------------------------------------------------------------------------------------------
-// column sums of the partial-statistics rows st0/st1 [R][C] for channels c0..c0+31 (1024 threads): thread = (row group
-// of 128, channel quad); 16-byte loads, 4 row iterations in flight, double accumulation; the result for channel c0+cl is
-// returned in threads 0..31 (cl = threadIdx.x).
+// column sums of the partial-statistics rows st0/st1 [R][C] for channels c0..c0+31 (NTH threads): thread = (row group
+// of NTH / 8, channel quad); 16-byte loads, 4 row iterations in flight, double accumulation; the result for channel c0+cl is
+// returned in threads 0..31 (cl = threadIdx.x).  NTH = 256 for the short lists (R <= 128: every list of layer3 / layer4 and every
+// first-stage-reduced one): device timestamps showed the 1024-thread workgroups of this tiny kernel starting up to 1.0 us apart
+// (16 waves each to dispatch) for a 2.6 us life -- with 4 waves per workgroup the stagger is a quarter of that.
+template <int NTH>
 __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, int c0,
                                                 double (&red)[2][32][33], double& a_out, double& b_out) {
-    const int qd = threadIdx.x & 7, rq = threadIdx.x >> 3;       // 8 quads x 128 row groups
+    constexpr int RG = NTH / 8, NW = NTH / 64;
+    const int qd = threadIdx.x & 7, rq = threadIdx.x >> 3;       // 8 quads x RG row groups
     const int cq = c0 + qd * 4;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (cq < C) {                                                // C % 4 == 0
         int r = rq;
-        for (; r + 384 < R; r += 512) {
+        for (; r + 3 * RG < R; r += 4 * RG) {
             float4 x[4], y[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                x[u] = *(const float4*)(st0 + (long)(r + 128 * u) * C + cq);
-                y[u] = *(const float4*)(st1 + (long)(r + 128 * u) * C + cq);
+                x[u] = *(const float4*)(st0 + (long)(r + RG * u) * C + cq);
+                y[u] = *(const float4*)(st1 + (long)(r + RG * u) * C + cq);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -35,13 +39,24 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, c
                 b[0] += y[u].x; b[1] += y[u].y; b[2] += y[u].z; b[3] += y[u].w;
             }
         }
-        for (; r < R; r += 128) {
-            const float4 x = *(const float4*)(st0 + (long)r * C + cq), y = *(const float4*)(st1 + (long)r * C + cq);
-            a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
-            b[0] += y.x; b[1] += y.y; b[2] += y.z; b[3] += y.w;
+        {   // tail: up to three more rows, issued together
+            float4 x[3], y[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool ok = r + RG * u < R;
+                const long ro = (long)(ok ? r + RG * u : 0) * C + cq;
+                x[u] = *(const float4*)(st0 + ro);
+                y[u] = *(const float4*)(st1 + ro);
+                if (!ok) { x[u] = make_float4(0.f, 0.f, 0.f, 0.f); y[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                a[0] += x[u].x; a[1] += x[u].y; a[2] += x[u].z; a[3] += x[u].w;
+                b[0] += y[u].x; b[1] += y[u].y; b[2] += y[u].z; b[3] += y[u].w;
+            }
         }
     }
-    // 128 row groups -> 16 (one per wave) via shuffles over the lanes sharing qd (lane bits 3..5), then LDS
+    // RG row groups -> NW (one per wave) via shuffles over the lanes sharing qd (lane bits 3..5), then LDS
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         a[e] = xor32_sum(xor16_sum(a[e] + dpp_f64<DPP_ROR8>(a[e])));       // (the fp64 overloads: the float ones would narrow silently)
@@ -56,11 +71,12 @@ __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ st0, c
     a_out = 0.0; b_out = 0.0;
     if (threadIdx.x < 32) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { a_out += red[0][i][threadIdx.x]; b_out += red[1][i][threadIdx.x]; }
+        for (int i = 0; i < NW; ++i) { a_out += red[0][i][threadIdx.x]; b_out += red[1][i][threadIdx.x]; }
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+template <int NTH>
+__global__ __launch_bounds__(NTH) void bn_finalize_kernel(
     const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float gam = fin ? gamma[c] : 0.f, bet = fin ? beta[c] : 0.f;
     const float rm0 = (fin && rmean) ? rmean[c] : 0.f, rv0 = (fin && rmean) ? rvar[c] : 0.f;
     double a, b;
-    bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
+    bn_partial_sums<NTH>(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
         const double mean = a / (double)count;
         double var = b / (double)count - mean * mean;
@@ -105,7 +121,8 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 }
 
 // dL/dx = A*dz + B*x + C per channel;  dgamma = sum dz*xhat, dbeta = sum dz
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+template <int NTH>
+__global__ __launch_bounds__(NTH) void bn_bwd_finalize_kernel(
     const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     const float mu_f = fin ? mean[c] : 0.f, r_f = fin ? invstd[c] : 0.f, g_f = fin ? gamma[c] : 0.f;
     const float dg0 = (fin && dgamma && accumulate) ? dgamma[c] : 0.f, db0 = (fin && dgamma && accumulate) ? dbeta[c] : 0.f;
     double a, b;
-    bn_partial_sums(st0, st1, R, C, blockIdx.x * 32, red, a, b);
+    bn_partial_sums<NTH>(st0, st1, R, C, blockIdx.x * 32, red, a, b);
     if (rg == 0 && c < C) {
         const double mu = mu_f, r = r_f, g = g_f;
         const double sum_dz = a, sum_dz_xhat = (b - mu * a) * r;
@@ -674,8 +691,12 @@ int tuber_bn_finalize(const float* st0, const float* st1, int R, int C, float co
                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
                       float* scale, float* shift, float* mean, float* invstd, hipStream_t stream) {
     if (R <= 0 || C <= 0) return TUBER_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, beta,
-                       running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
+    if (R <= 128)
+        hipLaunchKernelGGL(bn_finalize_kernel<256>, dim3(ceil_div(C, 32)), dim3(256), 0, stream, st0, st1, R, C, count, gamma, beta,
+                           running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<1024>, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, beta,
+                           running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
     TUBER_RETURN_LAUNCH();
 }
 
@@ -690,8 +711,12 @@ int tuber_bn_bwd_finalize(const float* st0, const float* st1, int R, int C, floa
                           const float* invstd, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
                           hipStream_t stream) {
     if (R <= 0 || C <= 0) return TUBER_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, mean,
-                       invstd, cA, cB, cC, dgamma, dbeta, accumulate);
+    if (R <= 128)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<256>, dim3(ceil_div(C, 32)), dim3(256), 0, stream, st0, st1, R, C, count, gamma, mean,
+                           invstd, cA, cB, cC, dgamma, dbeta, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<1024>, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, st0, st1, R, C, count, gamma, mean,
+                           invstd, cA, cB, cC, dgamma, dbeta, accumulate);
     TUBER_RETURN_LAUNCH();
 }
 
