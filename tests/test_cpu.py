@@ -456,3 +456,27 @@ def test_bench_roofline_bookkeeping_matches_trace_names():
     # every launcher the step calls has a bytes / flops entry or is deliberately uncounted ("...*")
     k, by, fl = bench.alg_cost("tuber_entry_conv_fwd", [None] * 11 + [6400])
     assert k == "entry_conv_kernel" and by == 2 * 6400 * 384 and fl == 2 * 6400 * 64 * 320
+
+
+def test_weight_gradient_gemm_routing_heuristics():
+    """host-side tile / slab choice of the dW GEMMs (csrc/gemm.hip: tn_big, tn_slabs_wanted) for the shapes the measurements in
+    DESIGN.md section 3 were taken on -- a regression guard for the routing, callable without a GPU"""
+    q = lib.query
+    # layer3 conv1 / conv4 (M = 5632): 128 x 128 tiles, 4 slabs of 1408 rows
+    assert q("tuber_gemm_tn_tile", 5632, 1024, 256) == 128 and q("tuber_gemm_tn_slabs", 5632, 1024, 256) == 4
+    assert q("tuber_gemm_tn_tile", 5632, 256, 1024) == 128
+    # layer4 (M = 2816): big tiles, 2 slabs
+    assert q("tuber_gemm_tn_tile", 2816, 2048, 512) == 128 and q("tuber_gemm_tn_slabs", 2816, 2048, 512) == 2
+    # class-branch FFN pair (M = 16896): big tiles with 8 slabs of 2112 rows; its small linears stay on 64 x 64
+    assert q("tuber_gemm_tn_tile", 16896, 256, 2048) == 128 and q("tuber_gemm_tn_slabs", 16896, 256, 2048) == 8
+    assert q("tuber_gemm_tn_tile", 16896, 2048, 512) == 128 and q("tuber_gemm_tn_slabs", 16896, 2048, 512) == 8
+    assert q("tuber_gemm_tn_tile", 16896, 256, 256) == 64
+    # short M (encoder FFN, layer4's down-sample projection over 704 rows): 64 x 64 tiles, groupable, bias gradient fusable
+    assert q("tuber_gemm_tn_tile", 704, 2048, 256) == 64
+    assert q("tuber_gemm_tn_tile", 704, 2048, 1024) == 64 and q("tuber_gemm_tn_fuses_bias", 704, 2048, 1024, 2048, 1024) in (1, 2)
+    # layer1 / layer2 (N or K below 128 or not a multiple of it): small tiles
+    assert q("tuber_gemm_tn_tile", 348160, 64, 256) == 64 and q("tuber_gemm_tn_tile", 87040, 128, 512) == 64
+    # the fused layer1 kernels' shape gates
+    assert q("tuber_conv4_bwd_supported", 256, 64) == 1 and q("tuber_conv4_bwd_supported", 512, 128) == 0
+    assert q("tuber_conv1_bwd_supported", 256, 64) == 1 and q("tuber_conv1_bwd_supported", 64, 64) == 0
+    assert q("tuber_blockout_conv1_supported", 256, 128) == 1 and q("tuber_entry_conv_supported", 64, 64, 256) == 1
