@@ -2,6 +2,7 @@
 """TubeR training-step throughput on MI355X (the headline metric of BASELINE.json).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...            (no launcher: bench.py starts its own N ranks, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one full optimisation step of TubeR_CSN152_AVA21 (forward, Hungarian-matched criterion, backward, global-norm
@@ -76,9 +77,12 @@ def alg_cost(name, a):
     if name == "tuber_dwconv_tile_bwd_data_bn":
         N, T, H, W, C = a[18:23]
         return "dwconv_tile_kernel<1,true>", 2 * C * N * T * H * W * 4, 2 * 27 * C * N * T * H * W
-    if name == "tuber_dwconv_tile_bwd_both_bn":  # data gradient (reads dzu, xu, x; writes dz) + weight gradient (reads dzu, xu, x)
+    if name == "tuber_dwconv_tile_bwd_both_bn":
+        # backward of a depthwise conv = read dy (dzu), read the saved conv output xu (the BatchNorm-backward fold and
+        # the ReLU mask need it -- it stands for "dy" of the un-fused conv), read x, write dx = FOUR tensor passes.  Whatever the kernel
+        # re-reads on top of that (r03: two concatenated grids, 7 passes) is traffic, not algorithmic bytes.
         N, T, H, W, C = a[19:24]
-        return "dwconv_tile_bwd_both_kernel", 2 * C * N * T * H * W * 7, 2 * 2 * 27 * C * N * T * H * W
+        return "dwconv_tile_bwd_both_kernel", 2 * C * N * T * H * W * 4, 2 * 2 * 27 * C * N * T * H * W
     if name == "tuber_dwconv_tile_bwd_weight_bn":
         N, T, H, W, C = a[15:20]
         return "dwconv_tile_kernel<2,true>", 2 * C * N * T * H * W * 3, 2 * 27 * C * N * T * H * W
@@ -234,6 +238,22 @@ def dominant_from_trace(prepass, headline):
     return None
 
 
+def pmc_traffic_per_launch(family):
+    """HBM bytes per launch of a kernel family from the newest committed PMC pass (profiles/*pmc_traffic.json: FETCH_SIZE / WRITE_SIZE
+    collected and corrected as MI355X_MICROARCH.md prescribes); None when the family is not in it."""
+    import glob
+    try:
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+        if not pm:
+            return None
+        kk = json.load(open(pm[-1]))["kernels"]
+        fam = family.replace(" ", "")
+        cand = [v for k_, v in kk.items() if fam.endswith(">") and k_.startswith(fam[:-1] + ",")]      # trailing template parameters
+        return (kk.get(fam) or (cand[0] if cand else None) or kk.get(fam.split("<")[0]) or {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -341,6 +361,40 @@ def lib_md5():
     return hashlib.md5(open(lib.LIBPATH, "rb").read()).hexdigest()[:12]
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher (WORLD_SIZE / RANK unset): start the N ranks here, one process per GPU, the way
+    the reference's ``pipelines/launch.py:20-50`` spawns its own workers -- the same command line re-executed with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR 127.0.0.1 / a free MASTER_PORT).  Rank 0 inherits stdout, so its one JSON line is this
+    job's stdout; the other ranks' stdout (RCCL banners) goes to stderr.  A rank that dies takes the job down instead of leaving the
+    others waiting in a collective.  Returns the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TUBER_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr, flush=True)
+                for q in live:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,6 +414,8 @@ def main():
                     "batch fed as uint8 frames through input_pipeline.ClipBatch.to(device) (H2D + resize + flip/crop/jitter/normalise/collate "
                     "on a side stream, double-buffered) and report both figures")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        raise SystemExit(spawn_ranks(args.gpus))      # the driver's `python bench.py --gpus N`: no launcher needed
 
     import torch.distributed as dist
     from tubelet_transformer_amd import lib, synth
@@ -374,8 +430,8 @@ def main():
         if args.gpus == 1 and world == 1:
             pass
         else:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, world, args.gpus))
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: either leave the launcher environment unset (bench.py starts its own ranks) or "
+                             "launch with python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if os.environ.get("TUBER_SHARE_GPU"):         # logic test of the N > 1 path on a one-GPU box (ranks share cuda:0; use gloo)
@@ -491,7 +547,8 @@ def main():
         "metric": "clips/sec (TubeR CSN-152 AVA2.1 training step fwd+bwd+clip+AdamW, 32x256x340 clips; whole job)" if headline else
                   "clips/sec (%s training step fwd+bwd+clip+AdamW, 32x%dx%d clips; whole job)" % (args.config.replace(".yaml", ""), hw[0], hw[1]),
         "value": round(total_clips / dt, 3), "unit": "clips/s", "per_gpu": round(total_clips / dt / world, 3),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "timed_region_s": round(dt, 4),
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights%s"
                                % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1],
@@ -508,20 +565,11 @@ def main():
         tsum = timer.summary()
         s = tsum[dominant]
         ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9
-        traffic = None      # measured HBM bytes per launch of this kernel family from the committed PMC passes (profiles/)
+        traffic = pmc_traffic_per_launch(dominant)      # measured HBM bytes per launch of this kernel family from the committed PMC passes (profiles/)
+        mfma_util, rp_avg = None, None     # from the committed PMC / kernel-trace passes of this command (profiles/), for cross-checking
         try:
             import glob
             import json as _json
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-            if pm:
-                kk = _json.load(open(pm[-1]))["kernels"]
-                fam = dominant.replace(" ", "")
-                cand = [v for k_, v in kk.items() if fam.endswith(">") and k_.startswith(fam[:-1] + ",")]      # trailing template parameters
-                traffic = (kk.get(fam) or (cand[0] if cand else None) or kk.get(fam.split("<")[0]) or {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-        mfma_util, rp_avg = None, None     # from the committed PMC / kernel-trace passes of this command (profiles/), for cross-checking
-        try:
             import re
             mu = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma_util.json")))
             if mu:
@@ -540,6 +588,7 @@ def main():
             pass
         line["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                            "traffic_over_alg": round(traffic / (s["bytes"] / s["launches"]), 3) if traffic else None,
                             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
                             "alg_bytes_per_launch": int(s["bytes"] / s["launches"]),
                             "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
@@ -555,6 +604,9 @@ def main():
                            "launches": t_["launches"], "avg_launch_us": round(1e3 * t_["ms"] / t_["launches"], 2),
                            "achieved_GBps": round(t_["bytes"] / (t_["ms"] * 1e-3) / 1e9, 1), "hbm_frac": round(t_["bytes"] / (t_["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "tflops": round(t_["flops"] / (t_["ms"] * 1e-3) / 1e12, 1), "mfma_frac": round(t_["flops"] / (t_["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+                tr_ = pmc_traffic_per_launch(k)
+                also[k]["traffic"] = tr_
+                also[k]["traffic_over_alg"] = round(tr_ / (t_["bytes"] / t_["launches"]), 3) if tr_ else None
         if also:
             line["roofline_weight_gradient_gemms"] = also
         line["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(prepass.items(), key=lambda kv: -kv[1]["ms"])[:12]}

@@ -121,7 +121,7 @@ def compare_gradients(named_hip_grads, g32, gbf, k=2.0, slack=0.05, min_cb=0.3):
         eh, eb = float((h - a).norm() / a.norm()), float((b - a).norm() / a.norm())
         nr = float(h.norm() / a.norm())
         rows.append((ch, cb, eh, eb, nr, n))
-        if eh > k * eb + slack or not (0.5 < nr < 2.0 or eb > 0.5):
+        if eh > k * eb + slack or not 0.5 < nr < 2.0:
             worse.append((n, "cos %.4f/%.4f" % (ch, cb), "relerr %.3f/%.3f" % (eh, eb), "norm %.3f" % nr))
     rows.sort()
     return rows, worse

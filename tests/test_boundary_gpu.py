@@ -242,7 +242,8 @@ def test_reference_training_script_sequence_with_stock_adamw(dev, tmp_path, monk
     from utils.video_action_recognition import train_tuber_detection, validate_tuber_detection
     from tubelet_transformer_amd.optim import FusedClipAdamW
     from tubelet_transformer_amd.training import build_optimizer, train_step
-    monkeypatch.delenv("TUBER_EAGER_STEP", raising=False)
+    from tubelet_transformer_amd import ab
+    monkeypatch.setattr(ab, "_active", set())
     H, W = 64, 96
 
     def fresh():
@@ -315,6 +316,17 @@ def test_reference_training_script_sequence_with_stock_adamw(dev, tmp_path, monk
     from tubelet_transformer_amd.optim import adopt
     f3 = adopt(opt3, model3)
     assert f3.t == 3 and torch.equal(f3.exp_avg, fused.exp_avg) and torch.equal(f3.exp_avg_sq, fused.exp_avg_sq)
+    # --- resume AFTER the optimizer was adopted: load_state_dict() replaces optimizer.param_groups with new dicts; the
+    # fused step must follow those, or the scheduler's lr changes after a resume are silently lost
+    f3.exp_avg.zero_()
+    opt3.load_state_dict(saved["optimizer"])
+    assert f3.param_groups is opt3.param_groups and torch.equal(f3.exp_avg, fused.exp_avg) and f3.t == 3
+    sched3 = torch.optim.lr_scheduler.MultiStepLR(opt3, milestones=[1], gamma=0.1)
+    sched3.step()
+    f3.sync_hyper()
+    torch.cuda.synchronize()
+    want = torch.tensor([[g["lr"], g["weight_decay"]] for g in opt3.param_groups], dtype=torch.float32)
+    assert torch.equal(f3.hyper.cpu(), want) and float(want[0, 0]) == pytest.approx(0.1 * saved["optimizer"]["param_groups"][0]["lr"])
 
     # --- an optimizer that is not AdamW: the reference's literal clip_grad_norm_ + optimizer.step() on the gradient views --------
     cfg4, model4, criterion4, _ = fresh()

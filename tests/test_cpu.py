@@ -480,3 +480,60 @@ def test_weight_gradient_gemm_routing_heuristics():
     assert q("tuber_conv4_bwd_supported", 256, 64) == 1 and q("tuber_conv4_bwd_supported", 512, 128) == 0
     assert q("tuber_conv1_bwd_supported", 256, 64) == 1 and q("tuber_conv1_bwd_supported", 64, 64) == 0
     assert q("tuber_blockout_conv1_supported", 256, 128) == 1 and q("tuber_entry_conv_supported", 64, 64, 256) == 1
+
+
+# ---------------------------------------------------------------- the reference's entry scripts import unchanged ---------------------------
+_IMPORT_BLOCK_PROBE = r'''
+import sys, types
+repo, ref, script = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path[:0] = [repo, ref]                       # INTEGRATION.md section A: this repository first, the reference checkout behind it
+def mod(name, **attrs):
+    m = types.ModuleType(name); m.__dict__.update(attrs); m.__path__ = []; sys.modules[name] = m; return m
+# third-party packages the image lacks (nothing of the reference is stubbed)
+mod("tensorboardX", SummaryWriter=object)
+mod("timm"); mod("timm.scheduler")
+mod("timm.scheduler.cosine_lr", CosineLRScheduler=object); mod("timm.scheduler.step_lr", StepLRScheduler=object)
+mod("timm.scheduler.scheduler", Scheduler=object)
+mod("yacs"); mod("yacs.config", CfgNode=dict)
+mod("cv2")
+import torch
+tv = mod("torchvision", __version__="0.15.0")
+mod("torchvision.transforms"); mod("torchvision.transforms.functional")
+mod("torchvision.ops"); mod("torchvision.ops.boxes", box_area=None); mod("torchvision.ops.misc", interpolate=None)
+mod("torchvision.models"); mod("torchvision.models._utils", IntermediateLayerGetter=object)
+mod("torchvision.models.video"); mod("torchvision.models.video.resnet", VideoResNet=object)
+block = []
+for line in open(ref + "/" + script):
+    if line.startswith("def "):
+        break
+    block.append(line)
+ns = {}
+exec(compile("".join(block), script, "exec"), ns)
+import tubelet_transformer_amd.tuber as T, tubelet_transformer_amd.training as TR, tubelet_transformer_amd.evaluation as EV
+import tubelet_transformer_amd.launch as L, tubelet_transformer_amd.config as C, tubelet_transformer_amd.checkpoint as CK
+assert ns["build_model"] is T.build_model
+assert ns["deploy_model"] is TR.deploy_model and ns["load_model"] is CK.load_model
+assert ns["spawn_workers"] is L.spawn_workers and ns["get_cfg_defaults"] is C.get_cfg_defaults
+if "train_tuber_detection" in ns: assert ns["train_tuber_detection"] is TR.train_tuber_detection
+if "validate_tuber_detection" in ns: assert ns["validate_tuber_detection"] is EV.validate_tuber_detection
+if "validate_tuber_ucf_detection" in ns: assert ns["validate_tuber_ucf_detection"] is EV.validate_tuber_ucf_detection
+# the sub-modules this repository does NOT provide come from the reference checkout
+assert ns["build_log_dir"].__code__.co_filename.startswith(ref), ns["build_log_dir"].__code__.co_filename
+assert ns["build_dataloader"].__code__.co_filename.startswith(ref)
+if "build_scheduler" in ns: assert ns["build_scheduler"].__code__.co_filename.startswith(ref)
+print("IMPORT-BLOCK-OK", script, sorted(k for k in ns if not k.startswith("__")))
+'''
+
+
+@pytest.mark.parametrize("script", ["train_tuber_ava.py", "eval_tuber_ava.py", "train_tuber_jhmdb.py", "eval_tuber_jhmdb.py"])
+def test_reference_entry_scripts_import_with_this_repo_first_on_the_path(script):
+    """VERDICT r03 missing #1: with the repository first on ``PYTHONPATH`` the reference's scripts must get past their import block
+    (``train_tuber_ava.py:1-16`` etc.): ``utils.utils``, ``utils.lr_scheduler``, ``datasets.*`` come from the reference checkout, the hot
+    path (``build_model``, ``deploy_model``, ``train_tuber_detection`` ...) from this repository.  Build container only."""
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isfile(os.path.join(ref, script)):
+        pytest.skip("reference checkout absent (GPU box)")
+    r = subprocess.run([sys.executable, "-c", _IMPORT_BLOCK_PROBE, ROOT, ref, script], capture_output=True, text=True, timeout=600,
+                       cwd="/tmp", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert r.returncode == 0 and "IMPORT-BLOCK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -80,53 +80,6 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
         assert eh <= K_ROUNDED * eb + SLACK[kind], "%s: hip %.3e vs %.1f x rounded-oracle %.3e + %.0e" % (kind, eh, K_ROUNDED, eb, SLACK[kind])
 
 
-def test_full_size_backward_per_parameter_vs_oracle(dev):
-    """config 3 at BASELINE size (CSN-152, 3x32x256x340, training-mode BatchNorm, dropout off, smooth surrogate loss): EVERY
-    parameter gradient of the HIP backward against fp32 autograd of the oracle, with the bf16-rounded oracle as the yardstick:
-    relerr(hip) <= 2 x relerr(rounded) + 0.05, norm ratio in (0.5, 2)."""
-    B = 2 if host_mem_gb() > 160 else 1            # fp32 autograd of CSN-152 at this size keeps tens of GB per clip on the host
-    cfg, model, _, state = _build("TubeR_CSN152_AVA21.yaml", dev, train=True)
-    pn = [n for n, _ in model.named_parameters()]
-    clips = synth.synthetic_clips(B, 32, 256, 340, seed=1234)
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    t0 = time.time()
-    o32, g32 = run_oracle(cfg, state, clips, train=True, param_names=pn, loss=surrogate)
-    o32 = {k: (v.detach() if torch.is_tensor(v) else [{kk: vv.detach() for kk, vv in a.items()} for a in v]) for k, v in o32.items()}
-    obf, gbf = run_oracle(cfg, state, clips, train=True, rounded=True, param_names=pn, loss=surrogate)
-    obf = {k: (v.detach() if torch.is_tensor(v) else [{kk: vv.detach() for kk, vv in a.items()} for a in v]) for k, v in obf.items()}
-    t1 = time.time()
-    store, _ = model.engine()
-    store.zero_grad()
-    out = model(clips.to(dev))
-    surrogate(out).backward()
-    torch.cuda.synchronize()
-    errs = output_errors(out, o32, obf)
-    print("train-mode outputs, batch %d: hip / bf16-rounded oracle vs fp32: %s   [2 oracle fwd+bwd: %.1f s]" % (
-        B, {k: "%.2e / %.2e" % v for k, v in errs.items()}, t1 - t0))
-    for kind, (eh, eb) in errs.items():
-        assert eh <= 3 * eb + 2e-2, (kind, eh, eb)
-    # ALL tensors with a non-negligible fp32 gradient (no conditioning filter): at this depth, with training-mode BatchNorm and
-    # random weights, the gradient of the early stages is chaotic under bf16 rounding -- the rounded oracle itself decorrelates
-    # there -- so the yardstick, not an absolute number, is the meaningful bar; per-stage medians show where that happens
-    rows, worse = compare_gradients([(n, p.grad) for n, p in model.named_parameters()], g32, gbf, min_cb=None)
-    report(rows, "CSN-152 %dx3x32x256x340 backward, all tensors" % B)
-    groups = {}
-    for ch, cb, eh, eb, nr, n in rows:
-        key = n.split(".")[2] if n.startswith("backbone.body.") else n.split(".")[0]
-        groups.setdefault(key, []).append((eh, eb, ch, cb))
-    for key, v in groups.items():
-        med = lambda i: sorted(x[i] for x in v)[len(v) // 2]
-        print("   %-16s tensors %3d   median relerr hip %.3f / rounded oracle %.3f   median cos hip %.4f / %.4f" % (key, len(v), med(0), med(1), med(2), med(3)))
-    well = [r for r in rows if r[3] <= 0.5]
-    print("   well-conditioned tensors (rounded-oracle relerr <= 0.5): %d of %d; worst hip relerr among them %.3f" % (len(well), len(rows), max(r[2] for r in well)))
-    assert len(rows) >= 600, len(rows)
-    assert len(well) >= 150
-    assert not worse, "gradients worse than 2x a bf16-rounded oracle (+0.05): %s" % worse[:20]
-    med = len(rows) // 2
-    assert sorted(r[2] for r in rows)[med] <= 1.25 * sorted(r[3] for r in rows)[med] + 0.02
-    _check_bn_buffers(cfg, model, state, clips)
-
-
 def _check_bn_buffers(cfg, model, state, clips):
     """BatchNorm running statistics after one training-mode forward: HIP vs the fp32 oracle, yardstick = the rounded oracle"""
     from oracle import tuber_oracle as O

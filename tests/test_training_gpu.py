@@ -480,3 +480,61 @@ def test_world2_reduced_gradients_equal_the_mean_of_the_ranks(tmp_path, dev, mod
             if not torch.equal(got[o:e], want[o:e]):
                 bad.append((n, float((got[o:e] - want[o:e]).abs().max()), float(want[o:e].abs().max())))
         assert not bad, "rank %d: %d tensors differ from the mean of the ranks, e.g. %s" % (r, len(bad), bad[:6])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# every retained A/B switch is shipped code: hold each to the default path
+# ------------------------------------------------------------------------------------------------------------------------------
+_AB_DEFAULT = {}
+
+
+def _ab_run(dev, names):
+    """one training-mode forward + backward of the 2-blocks-per-stage CSN body + transformer on a 2-clip 64x96 batch (layer1's
+    256/64-channel shapes that the persistent fused kernels take, identity and projection blocks, strided blocks), dropout off ->
+    (loss, {parameter: gradient}, BatchNorm running means)"""
+    from tubelet_transformer_amd import ab
+    with ab.override(*names):
+        cfg, model, crit = _model("TubeR_CSN152_AVA21.yaml", dev, dropout=False)
+        store, _ = model.engine()
+        clips = synth.synthetic_clips(2, 32, 64, 96, seed=21, device=dev)
+        targets = synth.synthetic_targets(2, "ava", 80, seed=22, device=dev, hw=(64, 96))
+        store.zero_grad()
+        out = model(clips)
+        ld = crit(out, targets)
+        loss = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        bufs = {n: b.detach().float().clone() for n, b in model.named_buffers() if n.endswith("running_mean")}
+        return float(loss), grads, bufs
+
+
+def _ab_names():
+    from tubelet_transformer_amd import ab
+    return sorted(k for k in ab.KNOWN if k != "eager_step")      # (eager_step: the training loop's switch, test_boundary_gpu.py)
+
+
+@pytest.mark.parametrize("name", _ab_names())
+def test_every_ab_switch_reproduces_the_default_path(dev, name):
+    """``TUBER_AB=<name>`` routes part of the step through the separate kernels a fused / grouped form replaced.  Those paths ship in
+    the library, so each is held to the default path on the same inputs: same loss, every parameter gradient within bf16 rounding of
+    the default's (most are bit-identical: same arithmetic in a different launch structure; the fused layer1 kernels round
+    intermediate tensors at different points), BatchNorm running statistics equal."""
+    if not _AB_DEFAULT:
+        _AB_DEFAULT["ref"] = _ab_run(dev, ())
+    l0, g0, b0 = _AB_DEFAULT["ref"]
+    l1, g1, b1 = _ab_run(dev, (name,))
+    assert math.isfinite(l1) and abs(l1 - l0) <= 2e-3 * abs(l0), (l0, l1)
+    assert set(g0) == set(g1)
+    worst = ("", 0.0)
+    for n in g0:
+        den = float(g0[n].norm())
+        if den < 1e-12:
+            continue
+        rel = float((g1[n] - g0[n]).norm()) / den
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] <= 0.1, worst            # (a wrong kernel is O(1); re-rounded intermediates measure <= a few 1e-2 on the deepest tensors)
+    for n in b0:
+        assert torch.allclose(b0[n], b1[n], rtol=2e-3, atol=2e-4), n
+    print("TUBER_AB=%s: loss %.6f vs %.6f, worst gradient relerr %.2e (%s)" % (name, l1, l0, worst[1], worst[0]))

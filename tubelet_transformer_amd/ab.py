@@ -1,0 +1,61 @@
+"""A/B switches of the product path, behind ONE parsed list: ``TUBER_AB=name[,name...]``.
+
+Every entry turns one fused / grouped form of the hot path back into the separate kernels it replaced, so that a claim in DESIGN.md
+("the fused conv4 backward is worth 0.2 ms") can be re-measured on the same build.  The alternative paths are part of the shipped
+library, so they are covered by the GPU suite the driver runs: ``tests/test_training_gpu.py::test_every_ab_switch_...`` is
+parametrised over ``KNOWN`` and holds every switch to the default path's gradients.  Unknown names are an error, not ignored.
+Measured-and-rejected paths are not kept behind switches; they are deleted ("Measured and rejected")."""
+import contextlib
+import os
+
+KNOWN = {
+    "no_wgrad_groups": "one tuber_gemm_tn launch per weight-gradient GEMM instead of the grouped launches (engine.WgradQueue)",
+    "immediate_reduce": "second-stage reductions of the weight-gradient partials per call instead of the deferred tuber_multi_reduce",
+    "no_join_fusion": "stand-alone block_out_bwd instead of the join backward in the conv1 data-gradient GEMM's epilogue",
+    "no_bn_bwd_fa": "BatchNorm backward as finalize + apply launches everywhere (no one-launch form)",
+    "no_bn_bwd_fa_after_reduce": "no one-launch BatchNorm backward behind the first-stage row reduction (layer1 / layer2)",
+    "no_bn3_in_dw": "stand-alone bn_bwd_fa for bn3 instead of forming it inside the depthwise backward kernels",
+    "no_dw_bwd_one_launch": "depthwise data and weight gradient of a stride-1 block as two launches",
+    "no_conv4_bwd_fused": "layer1's conv4 backward on the separate BatchNorm / GEMM kernels",
+    "no_conv1_bwd_fused": "layer1's conv1 backward on the separate BatchNorm / GEMM kernels",
+    "no_blockout_conv1": "layer1's residual join and the next conv1 as two launches",
+    "no_entry_conv": "conv1 and the projection conv of layer1's first block as two GEMMs",
+    "no_proj_bwd_fused": "layer1's projection-shortcut backward on the separate kernels",
+    "no_stem_bn_in_wgrad": "stand-alone bn_bwd_apply for the stem instead of forming it inside the stem weight-gradient kernel",
+    "dw_register_tiled": "the register-tiled depthwise kernels (used for the strided blocks) for every block",
+    "eager_step": "train_tuber_detection without the captured hipGraph step",
+}
+
+
+def _parse(text):
+    names = {t.strip().lower() for t in (text or "").replace(";", ",").split(",") if t.strip()}
+    bad = sorted(names - set(KNOWN))
+    if bad:
+        raise ValueError("TUBER_AB: unknown switch(es) %s; known: %s" % (bad, sorted(KNOWN)))
+    return names
+
+
+_active = _parse(os.environ.get("TUBER_AB"))
+
+
+def on(name):
+    """is the A/B switch ``name`` set?  (read at call time: tests flip switches inside one process)"""
+    if name not in KNOWN:
+        raise KeyError(name)
+    return name in _active
+
+
+def active():
+    return sorted(_active)
+
+
+@contextlib.contextmanager
+def override(*names):
+    """run a block with exactly ``names`` set (tests)"""
+    global _active
+    old = _active
+    _active = _parse(",".join(names))
+    try:
+        yield
+    finally:
+        _active = old

@@ -13,28 +13,13 @@ Forward schedule per bottleneck (ir_CSN_152.py:70-90), all BN statistics fused i
     cd = gemm_nt(gather(x), Wd)    [+stats]   -> bn_finalize(down_sample.1)      (first block of a stage)
     y  = relu(bn4(c4) + (bn_d(cd) | x))
 """
-import os
-
 import torch
 from torch import nn
 
-from . import lib
+from . import ab, lib
 from .engine import TnArgs, WgradQueue
 
 BN_EPS = 1e-3       # ir_CSN_152.py:15
-BN_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_BN_BWD_FA")    # A/B switch: BatchNorm backward finalize + apply in one launch (R <= 128)
-JOIN_FUSION = not os.environ.get("TUBER_NO_JOIN_FUSION")      # A/B switch: conv1 data gradient + the lower block's join backward in one GEMM
-BN_BWD_FA_AFTER_REDUCE = not os.environ.get("TUBER_NO_BN_BWD_FA_AFTER_REDUCE")   # A/B switch: ... also behind the first-stage row reduction (layer1 / layer2)
-LATE_WGRAD = bool(os.environ.get("TUBER_LATE_WGRAD"))      # A/B switch (measured and rejected, DESIGN.md section 3 (q)): layer3 / layer4 weight gradients on a side stream under the layer2 / layer1 / stem backward
-STEM_BN_IN_WGRAD = not os.environ.get("TUBER_NO_STEM_BN_IN_WGRAD")   # A/B switch: the stem BatchNorm's backward apply formed inside the stem conv weight-gradient kernel
-PROJ_BWD_FUSED = not os.environ.get("TUBER_NO_PROJ_BWD_FUSED")   # A/B switch: layer1's projection shortcut backward (BatchNorm apply + data gradient + weight gradient) on the fused conv4-backward kernel's plain form
-DW_BWD_ONE_LAUNCH = not os.environ.get("TUBER_NO_DW_BWD_ONE_LAUNCH")   # A/B switch: depthwise data + weight gradient of a stride-1 block in one launch
-ENTRY_CONV = not os.environ.get("TUBER_NO_ENTRY_CONV")       # A/B switch: conv1 + projection-shortcut conv of layer1's first block as one persistent kernel
-BLOCKOUT_CONV1 = not os.environ.get("TUBER_NO_BLOCKOUT_CONV1")     # A/B switch: layer1's residual join + the next block's conv1 as one persistent kernel
-CONV1_BWD_FUSED = not os.environ.get("TUBER_NO_CONV1_BWD_FUSED")   # A/B switch: layer1's bn1 backward apply + conv1 data gradient (+ join) + conv1 weight gradient as one persistent kernel
-CONV4_BWD_FUSED = not os.environ.get("TUBER_NO_CONV4_BWD_FUSED")   # A/B switch: layer1's bn4 backward apply + conv4 data gradient + conv4 weight gradient as one persistent kernel
-BN3_IN_DW = not os.environ.get("TUBER_NO_BN3_IN_DW")       # A/B switch: bn3's backward apply formed inside the depthwise backward kernels (no bn_bwd_fa launch, no dc3 tensor)
-DW_REGISTER_TILED = bool(os.environ.get("TUBER_DW_REGISTER_TILED"))   # A/B switch: the register-tiled depthwise kernels everywhere
 BN_MOM = 0.1        # ir_CSN_152.py:16
 BF = torch.bfloat16
 CMAX = 2048
@@ -269,7 +254,7 @@ class CSNRunner:
             cd = None
             if pre_c1 is not None:
                 c1, pre_c1 = pre_c1, None
-            elif (ENTRY_CONV and d["ds"] and st == 1 and ss == 1 and lib.query("tuber_entry_conv_supported", cin, P, 4 * P) == 1):
+            elif (not ab.on("no_entry_conv") and d["ds"] and st == 1 and ss == 1 and lib.query("tuber_entry_conv_supported", cin, P, 4 * P) == 1):
                 # layer1's first block: conv1 and the projection-shortcut conv read the same [M, 64] input -- one persistent kernel
                 # produces both outputs (and both BatchNorms' statistics rows) from one pass over it (csrc/entry_conv.hip)
                 c1 = torch.empty(Min, P, dtype=BF, device=dev)
@@ -292,7 +277,7 @@ class CSNRunner:
                 self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
             c3 = torch.empty(Mout, P, dtype=BF, device=dev)
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
-            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED        # LDS-staged kernels for the stride-1 blocks (47 of 50)
+            tile = st == 1 and ss == 1 and not ab.on("dw_register_tiled")        # LDS-staged kernels for the stride-1 blocks (47 of 50)
             if train:
                 R = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_fwd_stat_rows", B, To, Hq, Wq)
                 st0, st1 = self.ws("st0", R * P), self.ws("st1", R * P)
@@ -319,7 +304,7 @@ class CSNRunner:
             # BatchNorm statistics) run as one persistent kernel that keeps the y tile in LDS (csrc/blockout_conv1.hip): y is written
             # once and not read back.  The next block may be layer2's first one (its conv1 is dense; the stride sits on the depthwise conv).
             nxt = self.blocks[bi + 1] if bi + 1 < hi else None
-            if (BLOCKOUT_CONV1 and nxt is not None and nxt["cin"] == 4 * P
+            if (not ab.on("no_blockout_conv1") and nxt is not None and nxt["cin"] == 4 * P
                     and lib.query("tuber_blockout_conv1_supported", 4 * P, nxt["p"]) == 1):
                 PN = nxt["p"]
                 pre_c1 = torch.empty(Mout, PN, dtype=BF, device=dev)
@@ -407,8 +392,8 @@ class CSNRunner:
         (Forming dx inside the consuming GEMMs instead -- tuber_gemm_nt amode 2 / tuber_gemm_tn G2 -- removes this kernel and
         7.6 GB/step of HBM traffic but was measured 0.85 ms/step SLOWER on MI355X: the GEMMs are instruction/latency bound,
         not bandwidth bound, and the two-operand prologue costs them more than the apply kernel)"""
-        fa = apply and BN_BWD_ONE_LAUNCH and bn.C % 128 == 0
-        if fa and R > self._fa_max and BN_BWD_FA_AFTER_REDUCE:
+        fa = apply and not ab.on("no_bn_bwd_fa") and bn.C % 128 == 0
+        if fa and R > self._fa_max and not ab.on("no_bn_bwd_fa_after_reduce"):
             st0, st1, R = self._stat_rows(st0, st1, R, bn.C)       # layer1 / layer2: 64 rows after the first stage -> finalize + apply as one launch
         if fa and R <= self._fa_max:
             # short partial lists (layer3 / layer4 directly): every workgroup of the apply derives its strip's coefficients itself -- one launch
@@ -445,40 +430,14 @@ class CSNRunner:
     def flush_wgrads(self):
         self.store.wq.flush()
 
-    def _fork_late(self):
-        """launch the parked layer3 / layer4 leaf work on the side stream, behind everything issued so far"""
-        if not self.store.wq.held:
-            return
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        cur = torch.cuda.current_stream()
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            self._late_keep = self.store.wq.flush_held()
-
-    def _join_late(self):
-        """the side stream's work is ordered before whatever follows on the current stream (deferred reductions, optimizer)"""
-        if getattr(self, "_late_keep", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._late_keep = None
-
     def _backward_blocks(self, sblocks, base, dy, B, lowest, top, plans, dx_below, red):
         """bottlenecks [lowest, top) in reverse; ``sblocks[i - base]`` holds block i's saved tensors; ``dx_below``: the gradient of
         block ``lowest``'s input is wanted (something trainable, or a caller, sits below it).  Returns that gradient (or None)."""
         dev = self.dev
         pre = None          # (dz, sum-dz rows, sum-dz*c4 rows, R) of this block's join backward, produced by the block above (tuber_gemm_nt_join)
         wq = self.store.wq
-        # Late mode (TUBER_LATE_WGRAD=1; single GPU, whole body in one call): the weight gradients of layer3 / layer4 -- grouped dW
-        # GEMMs, depthwise weight gradients: a quarter of layer3's backward timeline, feeding nothing until the optimizer -- are
-        # parked while the latency-bound data-gradient chain of those stages runs, and launched on a side stream at the
-        # layer3 -> layer2 boundary, where they would overlap the bandwidth-bound layer2 / layer1 / stem backward (ONE fork and ONE
-        # join per step).  Measured in round 3: 17.29 vs 16.74 ms/step inside the hipGraph (bit-identical gradients) -- even a single
-        # two-branch region costs the replay more than the 1 ms of leaf work it moves; off by default.
-        late = (LATE_WGRAD and red is None and not getattr(self.store, "no_late", False) and wq.enabled and self.store.defer.enabled and lowest < top and self.blocks[lowest]["stage"] <= 2
-                and self.blocks[top - 1]["stage"] >= 3 and getattr(self, "split_hook", None) is None)
         for bi in range(top - 1, lowest - 1, -1):
             d, sv, f = self.blocks[bi], sblocks[bi - base], plans[bi]
-            wq.hold = late and d["stage"] >= 3
             x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             C4 = 4 * P
@@ -500,14 +459,14 @@ class CSNRunner:
             dc4 = None
             # layer1 (C4 = 256, P = 64: the widest activations): bn4's backward apply, the conv4 data gradient and the conv4 weight
             # gradient run as ONE persistent kernel that reads dz and c4 once and never writes dc4 (csrc/conv4_bwd.hip)
-            fuse4 = (CONV4_BWD_FUSED and depth >= 3 and f["w4"] and not wq.hold
+            fuse4 = (not ab.on("no_conv4_bwd_fused") and depth >= 3 and f["w4"]
                      and lib.query("tuber_conv4_bwd_supported", C4, P) == 1)
             if depth >= 2 or f["bn4"]:
                 dc4 = self._bn_bwd(b4, sa, sb, R, Mout, dz, c4, Mout, train=f["bn4"], apply=depth >= 2 and not fuse4)
             dcd = None
             # layer1's projection shortcut (64 -> 256 channels, stride 1): the same persistent kernel in its plain form does the shortcut
             # BatchNorm's backward apply, the projection's data gradient and its weight gradient in one pass over dz and cd
-            fused = (PROJ_BWD_FUSED and d["ds"] and st == 1 and ss == 1 and need_dx and f["wd"] and not wq.hold
+            fused = (not ab.on("no_proj_bwd_fused") and d["ds"] and st == 1 and ss == 1 and need_dx and f["wd"]
                      and lib.query("tuber_conv4_bwd_supported", C4, cin) == 1)
             if d["ds"] and (need_dx or f["wd"] or f["bnd"]):
                 dcd = self._bn_bwd(d["bnd"], sa, sc_, R, Mout, dz, cd, Mout, train=f["bnd"], apply=(need_dx or f["wd"]) and not fused)
@@ -515,12 +474,12 @@ class CSNRunner:
             if f["w4"] and not fuse4:
                 self._wgrad(dc4, C4, c3, P, d["g4"], Mout, C4, P, 1, b3.scale, b3.shift)
             dc3 = None
-            tile = st == 1 and ss == 1 and not DW_REGISTER_TILED
+            tile = st == 1 and ss == 1 and not ab.on("dw_register_tiled")
             # bn3's backward apply (dc3 = cA*dz3 + cB*c3 + cC) is formed INSIDE the two depthwise backward kernels of the stride-1 blocks
             # while they load their gradient operand: every workgroup derives the coefficients of its 64 channels from the partial rows
             # of the conv4 data-gradient GEMM -- the bn_bwd_fa launch and the dc3 round trip through HBM disappear
             R3 = lib.query("tuber_gemm_nt_stat_rows", Mout, P)
-            fuse3 = (BN3_IN_DW and tile and depth >= 5 and P % 64 == 0 and not wq.hold
+            fuse3 = (not ab.on("no_bn3_in_dw") and tile and depth >= 5 and P % 64 == 0
                      and (R3 <= self._fa_max or lib.query("tuber_stat_rows_reduced", R3) <= self._fa_max))
             if depth >= 3:
                 s0, s1 = self.ws("st0u" if fuse3 else "st0", R3 * P), self.ws("st1u" if fuse3 else "st1", R3 * P)
@@ -546,7 +505,7 @@ class CSNRunner:
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             # (stride-1 blocks with the bn3 fold: both gradients are independent of each other and run as ONE launch -- in the short-T
             #  stages most of such a kernel's duration is ramp-up / prologue latency / drain)
-            both = (DW_BWD_ONE_LAUNCH and fuse3 and f["w3"] and depth >= 5 and not self.store.wq.hold and self.store.defer.enabled)
+            both = (not ab.on("no_dw_bwd_one_launch") and fuse3 and f["w3"] and depth >= 5 and self.store.defer.enabled)
             if both:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
@@ -574,10 +533,7 @@ class CSNRunner:
                     if acc == 2:
                         g3 = d["g3"]
                         self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P_, 27 * P_, nb, 1, P_)
-                if self.store.wq.hold and acc == 2:
-                    self.store.wq.hold_call(dw_wgrad, (dc3, c1))      # leaf work: parked with the held weight-gradient GEMMs
-                else:
-                    dw_wgrad()
+                dw_wgrad()
             dc1 = None
             if depth >= 5:
                 if not both:
@@ -596,7 +552,7 @@ class CSNRunner:
                 # layer1 (256-channel block input, P = 64): bn1's backward apply, the conv1 data gradient (with the lower block's join
                 # when that is an identity block) and the conv1 weight gradient run as ONE persistent kernel (csrc/conv1_bwd.hip)
                 strided_ds = d["ds"] and (st != 1 or ss != 1)
-                fuse1 = (CONV1_BWD_FUSED and need_dx and not strided_ds and not wq.hold
+                fuse1 = (not ab.on("no_conv1_bwd_fused") and need_dx and not strided_ds
                          and lib.query("tuber_conv1_bwd_supported", cin, P) == 1)
                 dc1 = self._bn_bwd(b1, s0, s1, R1, Min, dz1, c1, Min, train=f["bn1"], apply=depth >= 6 and not fuse1)
             else:
@@ -631,7 +587,7 @@ class CSNRunner:
                 # The input gradient dx IS the gradient of the block below's output y (= this block's x).  When that block is an
                 # identity block and dx is complete after this GEMM, its join backward (dz = dx * [y > 0] + the bn4 statistics) runs
                 # as the GEMM's epilogue: dx never reaches HBM and the block_out_bwd launch of the next iteration is gone.
-                fuse = JOIN_FUSION and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
+                fuse = not ab.on("no_join_fusion") and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
                 if fuse1:
                     part1 = None
                     if f["w1"]:
@@ -673,17 +629,13 @@ class CSNRunner:
                     dy = dx
             # layer1 / layer2 weight gradients are long GEMMs: launched per bottleneck (their operands are 45-180 MB each);
             # layer3 / layer4 ones are short: up to 8 (four bottlenecks) share a launch
-            if late and d["first"] and d["stage"] == 3:
-                wq.hold = False
-                self.store.defer.flush()         # what is registered so far (transformer / head partials) is reduced on this stream;
-                self._fork_late()                # the parked work registers ITS partials now: reduced by the final flush, behind the join
-            elif d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
+            if d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
                 self.flush_wgrads()
             if red is not None:
                 self.store.defer.flush()         # the slice handed to RCCL must include the deferred second-stage reductions
                 red.notify(d["off0"])
             hook = getattr(self, "split_hook", None)
-            if d["first"] and d["stage"] == 3 and not late:
+            if d["first"] and d["stage"] == 3:
                 self.store.defer.flush()         # always here, so eager warm-up and a split capture build the same reduce tables
             if hook is not None and d["first"] and d["stage"] == 3 and need_dx:
                 # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
@@ -706,7 +658,6 @@ class CSNRunner:
         dy = self._backward_blocks(saved["blocks"], saved.get("lo", 0), dy, B, lowest, nblk, plans, stem_plan["any"], red)
         self.flush_wgrads()
         if not stem_plan["any"]:
-            self._join_late()
             return
         # stem: pool + relu + bn backward, then the 3->64 conv weight gradient (implicit GEMM over the clip)
         clips, _, c0, arg, (B, T, Ho, Wo, Hp, Wp) = saved["stem"]
@@ -718,7 +669,7 @@ class CSNRunner:
         lib.call("tuber_stem_pool_bwd", dy, arg, c0, bn.scale, bn.shift, dz0, s0, s1, B * T, Ho, Wo, Hp, Wp)
         # the BatchNorm backward apply (dc0 = cA*dz0 + cB*c0 + cC, a 3-pass elementwise kernel over [M0, 64]) is formed inside the
         # weight-gradient kernel while it stages its gradient operand: dc0 never exists in HBM
-        fold = STEM_BN_IN_WGRAD and stem_plan["w"]
+        fold = not ab.on("no_stem_bn_in_wgrad") and stem_plan["w"]
         dc0 = self._bn_bwd(bn, s0, s1, R, M0, dz0, c0, M0, train=stem_plan["bn"], apply=stem_plan["w"] and not fold)
         if stem_plan["w"]:
             H, W = clips.shape[-2:]
@@ -727,4 +678,3 @@ class CSNRunner:
                 lib.call("tuber_stem_conv_bwd_weight_bn", clips, dz0, c0, bn.cA, bn.cB, bn.cC, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
             else:
                 lib.call("tuber_stem_conv_bwd_weight", clips, dc0, self.ws("tn", nwg * 512 * 64), self.stem_g, 1, B, T, H, W)
-        self._join_late()

@@ -86,7 +86,14 @@ def load_detr_weights(model, pretrain_dir, cfg):
         picked[".".join(parts[1:])] = v[:qsize] if parts[1] == "query_embed" else v
     used, unused, _ = _copy_into(model, picked, what="detr init")
     print("detr unused model layers:", unused + foreign)
-    print("load pretrain success")
+    if not used:
+        # the reference prints "load pretrain success" here as well (its DDP-wrapped model matches only ``module.`` keys); a silent
+        # random-init transformer is the worst outcome of a mis-prefixed file, so say so loudly
+        import warnings
+        warnings.warn("load_detr_weights: NO tensor of %r was loaded (%d candidate entries, none keyed 'module.<name>' for a tensor of this "
+                      "model; first keys: %s) -- the transformer keeps its initialisation" % (pretrain_dir, len(picked) + len(foreign), (foreign + list(picked))[:3]),
+                      RuntimeWarning, stacklevel=2)
+    print("load pretrain success (%d tensors loaded)" % len(used))
     return model
 
 

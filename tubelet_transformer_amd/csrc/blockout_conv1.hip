@@ -139,11 +139,8 @@ __global__ __launch_bounds__(256, PN == 64 ? 2 : 1) void blockout_conv1_kernel(B
 template <int PN>
 int launch(const BoC1Args& a, hipStream_t stream) {
     const size_t lds = (size_t)(TR * GP + PN * GP) * sizeof(bf16) + 4 * PN * 2 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)blockout_conv1_kernel<PN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsOptIn opt;
+    TUBER_LDS_OPT_IN(opt, blockout_conv1_kernel<PN>, lds);
     const long tiles = (a.M + TR - 1) / TR;
     const long slots = PN == 64 ? 512 : 256;
     hipLaunchKernelGGL(blockout_conv1_kernel<PN>, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), lds, stream, a);

@@ -141,9 +141,10 @@ int tuber_comm_init(const void* id128, int nranks, int rank, int device, void** 
 
 // tuber_comm_init with a deadline.  ncclCommInitRank is itself a collective: a rank that never arrives (died before it, no
 // librccl, wrong device) would block every other rank forever.  The bootstrap runs on a helper thread; when it has not returned
-// after timeout_ms the call fails with TUBER_ETIMEDOUT and a message naming the rank -- the caller can then fall back to another
-// transport or abort the job with a readable error instead of a hang.  (The helper thread stays parked inside RCCL in that case;
-// a process that saw a timeout is expected to give up on this communicator.)  timeout_ms <= 0: plain tuber_comm_init.
+// after timeout_ms the call fails with TUBER_ETIMEDOUT and a message naming the rank -- the caller aborts the job with a readable
+// error instead of a hang (ddp.py treats it as fatal: the helper thread stays parked inside RCCL holding the device, so running
+// another transport's collectives beside the half-made communicator is not safe; if the peers do arrive later the helper destroys
+// the communicator it gets).  timeout_ms <= 0: plain tuber_comm_init.
 int tuber_comm_init_timeout(const void* id128, int nranks, int rank, int device, int timeout_ms, void** comm_out) {
     if (timeout_ms <= 0) return tuber_comm_init(id128, nranks, rank, device, comm_out);
     if (!id128 || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return TUBER_EINVAL;
@@ -154,6 +155,7 @@ int tuber_comm_init_timeout(const void* id128, int nranks, int rank, int device,
         bool done = false;
         int rc = 0;
         void* comm = nullptr;
+        bool abandoned = false;      // the caller gave up at the deadline: a communicator that completes later is destroyed, not leaked
         char id[128];
     };
     auto st = std::make_shared<State>();
@@ -161,11 +163,16 @@ int tuber_comm_init_timeout(const void* id128, int nranks, int rank, int device,
     std::thread([st, nranks, rank, device] {
         void* c = nullptr;
         const int rc = tuber_comm_init(st->id, nranks, rank, device, &c);
-        std::lock_guard<std::mutex> l(st->mu);
-        st->rc = rc;
-        st->comm = c;
-        st->done = true;
-        st->cv.notify_all();
+        bool orphan;
+        {
+            std::lock_guard<std::mutex> l(st->mu);
+            st->rc = rc;
+            st->comm = c;
+            st->done = true;
+            orphan = st->abandoned;
+            st->cv.notify_all();
+        }
+        if (orphan && rc == TUBER_OK && c) g_api.CommDestroy((Comm)c);      // the peers arrived after the deadline: nobody owns this one
     }).detach();
     std::unique_lock<std::mutex> l(st->mu);
     if (!st->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return st->done; })) {
@@ -173,6 +180,7 @@ int tuber_comm_init_timeout(const void* id128, int nranks, int rank, int device,
         snprintf(buf, sizeof buf, "ncclCommInitRank: rank %d of %d (device %d) still waiting for its peers after %d ms -- a rank is missing or "
                  "cannot reach the rendez-vous", rank, nranks, device, timeout_ms);
         set_err(buf);
+        st->abandoned = true;
         return TUBER_ETIMEDOUT;
     }
     if (st->rc != 0) return st->rc;

@@ -19,6 +19,27 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
         return e__ == hipSuccess ? TUBER_OK : (int)e__; \
     } while (0)
 
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is PER DEVICE, so the "done" state is a bit per device id and the
+// runtime's answer is checked (a process that drives a second GPU must opt in there too).  Returns TUBER_OK or the hipError_t.
+struct LdsOptIn {
+    unsigned long long done = 0;       // benign race: two threads may both set the attribute, the value is the same
+};
+static inline int lds_opt_in(LdsOptIn& st, const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (st.done & bit) return TUBER_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    st.done |= bit;
+    return TUBER_OK;
+}
+#define TUBER_LDS_OPT_IN(st, fn, bytes)                          \
+    do {                                                         \
+        int rc__ = lds_opt_in(st, (const void*)(fn), bytes);     \
+        if (rc__ != TUBER_OK) return rc__;                       \
+    } while (0)
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -251,13 +251,10 @@ int tuber_conv1_bwd_fused(const void* dz1, const void* c1, const float* cA, cons
     Conv1BwdArgs a;
     a.dz1 = (const bf16*)dz1; a.c1 = (const bf16*)c1; a.cA = cA; a.cB = cB; a.cC = cC; a.w1t = (const bf16*)w1t; a.ldw = ldw;
     a.R = (const bf16*)R; a.X = (const bf16*)X; a.Cm = (const bf16*)Cm; a.out = (bf16*)out; a.st0 = st0; a.st1 = st1; a.slab = slab; a.M = M;
-    static bool attr_done[2] = {false, false};
+    static LdsOptIn opt[2];
     const int j = Cm ? 1 : 0;
-    if (!attr_done[j]) {
-        if (j) (void)hipFuncSetAttribute((const void*)conv1_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsJoin);
-        else (void)hipFuncSetAttribute((const void*)conv1_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPlain);
-        attr_done[j] = true;
-    }
+    if (j) TUBER_LDS_OPT_IN(opt[1], conv1_bwd_kernel<true>, kLdsJoin);
+    else TUBER_LDS_OPT_IN(opt[0], conv1_bwd_kernel<false>, kLdsPlain);
     const dim3 grid(tuber_conv1_bwd_slabs(M)), block(NTH);
     if (j) hipLaunchKernelGGL(conv1_bwd_kernel<true>, grid, block, kLdsJoin, stream, a);
     else hipLaunchKernelGGL(conv1_bwd_kernel<false>, grid, block, kLdsPlain, stream, a);

@@ -276,12 +276,9 @@ int tuber_conv4_bwd_fused(const void* dz, const void* c4, const void* c3, const 
     Conv4BwdArgs a;
     a.dz = (const bf16*)dz; a.c4 = (const bf16*)c4; a.c3 = (const bf16*)c3; a.w4t = (const bf16*)w4t; a.ldw = ldw;
     a.cA = cA; a.cB = cB; a.cC = cC; a.sc3 = sc3; a.sh3 = sh3; a.dz3 = (bf16*)dz3; a.st0 = st0; a.st1 = st1; a.slab = slab; a.M = M;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv4_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        (void)hipFuncSetAttribute((const void*)conv4_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        attr_done = true;
-    }
+    static LdsOptIn opt[2];
+    TUBER_LDS_OPT_IN(opt[0], conv4_bwd_kernel<false>, kLds);
+    TUBER_LDS_OPT_IN(opt[1], conv4_bwd_kernel<true>, kLds);
     if (plain) hipLaunchKernelGGL(conv4_bwd_kernel<true>, dim3(tuber_conv4_bwd_slabs(M)), dim3(256), kLds, stream, a);
     else hipLaunchKernelGGL(conv4_bwd_kernel<false>, dim3(tuber_conv4_bwd_slabs(M)), dim3(256), kLds, stream, a);
     TUBER_RETURN_LAUNCH();

@@ -414,11 +414,8 @@ int launch_tile(TileArgs& a, hipStream_t stream) {
     const TileGeom& g = a.g;
     dim3 grid(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), block(512);
     const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);       // ring + filter taps + BNG coefficients (wgrad reuses the ring for its reduction)
-    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
-    if (!attr_done[MODE][BNG]) {                            // > 64 KB of dynamic LDS needs the opt-in once per kernel
-        hipFuncSetAttribute((const void*)dwconv_tile_kernel<MODE, BNG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[MODE][BNG] = true;
-    }
+    static LdsOptIn opt;                                   // (one per instantiation) > 64 KB of dynamic LDS needs the opt-in once per kernel and device
+    TUBER_LDS_OPT_IN(opt, (dwconv_tile_kernel<MODE, BNG>), lds);
     hipLaunchKernelGGL((dwconv_tile_kernel<MODE, BNG>), grid, block, lds, stream, a);
     TUBER_RETURN_LAUNCH();
 }
@@ -448,11 +445,8 @@ int tuber_dwconv_tile_fwd(const void* x, const float* sc, const float* sh, const
     if (!sc) {                                   // plain conv (no BatchNorm + ReLU in front): its own instantiation
         const TileGeom& g = a.g;
         const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)dwconv_tile_kernel<M_FWD, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        static LdsOptIn opt;
+        TUBER_LDS_OPT_IN(opt, (dwconv_tile_kernel<M_FWD, false, false>), lds);
         hipLaunchKernelGGL((dwconv_tile_kernel<M_FWD, false, false>), dim3(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), dim3(512), lds, stream, a);
         TUBER_RETURN_LAUNCH();
     }
@@ -531,11 +525,8 @@ int tuber_dwconv_tile_bwd_both_bn(const void* dzu, const void* xu, const float* 
     aw.g = make_geom(N, T, H, W, C, true);
     const int nd = ad.g.N * ad.g.tchunks * ad.g.htiles * ad.g.wtiles, nw = aw.g.N * aw.g.tchunks * aw.g.htiles * aw.g.wtiles;
     const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)dwconv_tile_bwd_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsOptIn opt;
+    TUBER_LDS_OPT_IN(opt, dwconv_tile_bwd_both_kernel, lds);
     hipLaunchKernelGGL(dwconv_tile_bwd_both_kernel, dim3(nd + nw, C / 64), dim3(512), lds, stream, ad, aw, nd);
     TUBER_RETURN_LAUNCH();
 }

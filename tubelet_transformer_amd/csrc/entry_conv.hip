@@ -156,11 +156,8 @@ int tuber_entry_conv_fwd(const void* x, const void* w1, long ldw1, const void* w
     EntryArgs a;
     a.x = (const bf16*)x; a.w1 = (const bf16*)w1; a.ldw1 = ldw1; a.wd = (const bf16*)wd; a.ldwd = ldwd;
     a.c1 = (bf16*)c1; a.cd = (bf16*)cd; a.a0 = a0; a.a1 = a1; a.d0 = d0; a.d1 = d1; a.M = M;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)entry_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        attr_done = true;
-    }
+    static LdsOptIn opt;
+    TUBER_LDS_OPT_IN(opt, entry_conv_kernel, kLds);
     const long tiles = (M + TR - 1) / TR;
     hipLaunchKernelGGL(entry_conv_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(NTH), kLds, stream, a);
     TUBER_RETURN_LAUNCH();

@@ -515,9 +515,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 
 // every output column of every tile exists and every epilogue tensor can be read / written in 16-byte pieces
 static bool nt_full(const GemmNT& p, int bn) {
-    static int on = -1;
-    if (on < 0) on = getenv("TUBER_NT_NO_FULL") ? 0 : 1;       // A/B switch
-    return on && p.N % bn == 0 && !(p.ldc & 7) && !p.out_f32 && (!p.Cm || !(p.ldcm & 7)) && (!p.Ym || !(p.ldym & 7)) && (!p.R || !(p.ldr & 7));
+    return p.N % bn == 0 && !(p.ldc & 7) && !p.out_f32 && (!p.Cm || !(p.ldcm & 7)) && (!p.Ym || !(p.ldym & 7)) && (!p.R || !(p.ldr & 7));
 }
 
 template <int BM, int BN, int WM, int WN, int G, int OCC>
@@ -529,14 +527,9 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
 #define LNT(AM, EP)                                                                                                   \
     do {                                                                                                              \
         if (lds > 65536) { /* more than 64 KB of dynamic LDS needs a one-time opt-in per kernel */                    \
-            static bool done = false;                                                                                 \
-            if (!done) {                                                                                              \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>,                    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC, 0, true>,           \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-                done = true;                                                                                          \
-            }                                                                                                         \
+            static LdsOptIn opt[2];                                                                                   \
+            TUBER_LDS_OPT_IN(opt[0], (gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), 160 * 1024);                   \
+            TUBER_LDS_OPT_IN(opt[1], (gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC, 0, true>), 160 * 1024);          \
         }                                                                                                             \
         if (full) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC, 0, true>), grid, block, lds, s, p);         \
         else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), grid, block, lds, s, p);                \
@@ -583,16 +576,15 @@ static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
 }
 // shapes that take it: plain A, no row gather, at least `min_kt` k-tiles, and few enough 64x64 tiles that they are all resident at once
 static bool nt_use_wsk(const GemmNT& p, int amode) {
-    static const int min_kt = getenv("TUBER_NT_WSK_MIN_KT") ? atoi(getenv("TUBER_NT_WSK_MIN_KT")) : 16;      // 0 = never
+    constexpr int min_kt = 16;
     if (min_kt <= 0 || amode != A_PLAIN || p.gather || p.out_f32) return false;
     const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
     return p.K / 64 >= min_kt && tiles <= 512;
 }
 
 // tile choice: (cfg 0) 128x128, (1) 128x64, (2) 64x64
-static int g_nt_force = -2;
+static int g_nt_force = -1;      // tuber_gemm_nt_set_cfg (tuning runs / kernel tests only)
 static int nt_force_cfg() {
-    if (g_nt_force == -2) { const char* e = getenv("TUBER_NT_CFG"); g_nt_force = e ? atoi(e) : -1; }
     return g_nt_force;
 }
 static int nt_pick_cfg(int M, int N, int K) {
@@ -1409,35 +1401,29 @@ extern "C" {
 // ~14 us for the same work as 512 tiles of gemm_tn2)
 static int tn_tile(int N, int K) { return !((N | K) & 7) ? 64 : (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128 ? 128 : 64; }
 // 128 x 128 transpose-read tiles (gemm_tn3): layer3 / layer4 convs, FFN and class-branch linears, packed in-projections
-static int g_tn_big = -1;
+static const int g_tn_big = 1;
 // Measured (scripts/gemm_bench.py tngroup, round 3): eight layer3 problems 68.2 -> 50.9 us, six layer4 ones 87.5 -> 82.6 us; but the
 // long-M class-branch pair (M = 16896) 132 -> 224 us WITH THE SLAB COUNT OF THE SMALL TILES (2 and 1: few tiles x few slabs underfill
 // the chip at two workgroups per CU; see below) and the short-M encoder FFNs (M = 704: 11 steps) 13.5 -> 20.8 us.
 static bool tn_big(int M, int N, int K) {
-    if (g_tn_big < 0) { const char* e = getenv("TUBER_TN_NO_BIG_TILES"); g_tn_big = e ? 0 : 1; }      // A/B switch
     // long M (the class-branch FFN pair, M = 16896, 256 x 2048 and 2048 x 512): with enough slabs to fill the chip (2112 rows = 33 steps
     // each: 8 slabs) the big tiles win there too -- 130.8 -> 81.8 us for the pair (650 TFLOP/s), 86.8 / 92.6 / 87.4 us with 12 / 6 / 4 slabs
-    static int max_m = -1;
-    if (max_m < 0) { const char* e = getenv("TUBER_TN_BIG_MAX_M"); max_m = e ? atoi(e) : 32768; }
+    constexpr int max_m = 32768;
     if (M > 8192 && (long)N * K < (1L << 19)) return false;
     return g_tn_big && M >= 2048 && M <= max_m && !((N | K) & 127) && (long)N * K >= (1L << 17) && tn_tile(N, K) == 64;
 }
 static int tn_slabs_wanted(int M, int N, int K) {
     const int T = tn_big(M, N, K) ? 128 : tn_tile(N, K);
     const long tiles = (long)ceil_div(N, T) * ceil_div(K, T);
-    static int target = -1;
+    constexpr int target = 256;
     // workgroups aimed for per GEMM: 256 since the weight gradients travel in grouped launches (tuber_gemm_tn_group: 2-8 GEMMs share the
     // chip, so each needs fewer slabs to fill it: 18.87 -> 18.65 ms/step against 512, and half the slab traffic; 128 loses again)
-    if (target < 0) { const char* e = getenv("TUBER_TN_WG_TARGET"); target = e ? atoi(e) : 256; }
     // big tiles: ~22 steps of 64 rows per workgroup measured best on both backbone shapes (layer3 M = 5632: 4 slabs 51 us per eight
     // problems against 56 us with 8 and 75 with 15; layer4 M = 2816: 2 slabs 72 us per six against 82 us with 1) -- fewer steps do not
     // amortise the 64 KB prologue / 64 KB fp32 epilogue of a tile, more leave the chip underfilled
     long S;
     if (tn_big(M, N, K)) {
-        static int big_rows = -1;
-        if (big_rows < 0) { const char* e = getenv("TUBER_TN_BIG_ROWS"); big_rows = e ? atoi(e) : 1408; }
-        static int long_rows = -1;
-        if (long_rows < 0) { const char* e = getenv("TUBER_TN_BIG_ROWS_LONG"); long_rows = e ? atoi(e) : 2112; }
+        constexpr int big_rows = 1408, long_rows = 2112;
         const int rows = M > 8192 ? long_rows : big_rows;
         S = (M + rows / 2) / rows;
     } else {

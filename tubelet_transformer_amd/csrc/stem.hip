@@ -145,7 +145,7 @@ int tuber_stem_pool_fwd(const void* x, const float* sc, const float* sh, void* o
 }
 
 int tuber_stem_pool_bwd_stat_rows(long positions) {
-    static const int cap = getenv("TUBER_STEM_POOL_WG") ? atoi(getenv("TUBER_STEM_POOL_WG")) : 2048;
+    constexpr int cap = 2048;
     long nb = (positions + 255) / 256;
     return (int)(nb > cap ? cap : nb);
 }

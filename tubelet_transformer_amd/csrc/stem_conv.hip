@@ -378,13 +378,13 @@ extern "C" {
 
 // persistent grid of both kernels (= partial-statistics rows of the forward, slabs of the weight gradient)
 int tuber_stem_conv_blocks(int B, int T, int H, int W) {
-    static const int cap = getenv("TUBER_STEM_FWD_WG") ? atoi(getenv("TUBER_STEM_FWD_WG")) : 768;      // 159 VGPRs: three workgroups per CU
+    constexpr int cap = 768;      // 159 VGPRs: three workgroups per CU
     const StemGeom g = stem_geom(B, T, H, W);
     return g.ntiles < cap ? g.ntiles : cap;
 }
 // slabs of the weight gradient (two 8-wave workgroups per CU)
 int tuber_stem_conv_wgrad_blocks(int B, int T, int H, int W) {
-    static const int cap = getenv("TUBER_STEM_WGRAD_WG") ? atoi(getenv("TUBER_STEM_WGRAD_WG")) : 256;
+    constexpr int cap = 256;
     const StemGeom g = stem_geom(B, T, H, W);
     return g.ntiles < cap ? g.ntiles : cap;
 }

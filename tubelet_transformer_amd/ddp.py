@@ -78,7 +78,10 @@ class RcclComm:
         comm = ctypes.c_void_p()
         # deadline on the bootstrap (TUBER_RCCL_INIT_TIMEOUT_S, default 120 s; 0 = none): a missing rank is an error message, not a hang
         timeout_ms = int(float(os.environ.get("TUBER_RCCL_INIT_TIMEOUT_S", "120")) * 1000) if world > 1 else 0
-        self._check(self.lib.tuber_comm_init_timeout(ctypes.addressof(uid), world, rank, idx, timeout_ms, ctypes.addressof(comm)), "tuber_comm_init")
+        rc = self.lib.tuber_comm_init_timeout(ctypes.addressof(uid), world, rank, idx, timeout_ms, ctypes.addressof(comm))
+        if rc == -3:        # TUBER_ETIMEDOUT: a rank never reached the bootstrap.  Fatal for the job: a helper thread is still
+            raise RcclBootstrapTimeout(self.lib.tuber_comm_last_error().decode())      # parked inside RCCL on this device
+        self._check(rc, "tuber_comm_init")
         self.comm = comm.value
         n, r = ctypes.c_int(-1), ctypes.c_int(-1)
         self._check(self.lib.tuber_comm_count(self.comm, ctypes.addressof(n), ctypes.addressof(r)), "tuber_comm_count")
@@ -101,6 +104,10 @@ class RcclComm:
             torch.cuda.synchronize(self.device)
             self.lib.tuber_comm_destroy(self.comm)
             self.comm = None
+
+
+class RcclBootstrapTimeout(RuntimeError):
+    """ncclCommInitRank did not complete before TUBER_RCCL_INIT_TIMEOUT_S: a rank is missing.  Not recoverable in-process."""
 
 
 class FlatGradReducer:
@@ -287,6 +294,8 @@ def attach_reducer(store, force=False):
         if ready:
             try:
                 comm = RcclComm(store.device)
+            except RcclBootstrapTimeout:            # every rank still in the bootstrap hits the same deadline: the job ends, readable
+                raise
             except Exception as e:                  # noqa: BLE001
                 if world <= 1:
                     raise

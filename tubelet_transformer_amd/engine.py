@@ -11,12 +11,11 @@ Layout in HBM (per model, per GPU):
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
 
-from . import lib
+from . import ab, lib
 
 ALIGN = 64
 
@@ -42,13 +41,15 @@ class WgradQueue:
 
     def __init__(self, store):
         self.store, self.q = store, []
-        self.held, self.hold = [], False     # late mode (backbone.py): layer3 / layer4 leaf work parked until the fork onto the side stream
-        self.enabled = not os.environ.get("TUBER_NO_WGRAD_GROUPS")        # A/B switch: one tuber_gemm_tn launch per weight gradient
         # (measured and rejected: running the grouped launches on a second HIP stream next to the data-gradient chain -- ~35 fork /
         #  join points per step inside the hipGraph cost +1.9 ms/step, 18.65 -> 20.53: cross-queue edges serialise the replay)
         self.max = lib.query("tuber_gemm_tn_group_max")
         if lib.query("tuber_gemm_tn_args_bytes") != ctypes.sizeof(TnArgs):
             raise RuntimeError("TuberGemmTNArgs layout drift between engine.py and libtuber_hip.so")
+
+    @property
+    def enabled(self):
+        return not ab.on("no_wgrad_groups")      # A/B switch: one tuber_gemm_tn launch per weight gradient
 
     @staticmethod
     def eligible(M, N, K, ldg, lda):
@@ -57,34 +58,9 @@ class WgradQueue:
 
     def add(self, args, keep, defers):
         """args: TnArgs; keep: tensors that must outlive the launch; defers: DeferredReduce.add argument tuples registered at flush"""
-        if self.hold:
-            self.held.append((args, keep, defers))
-            return
         self.q.append((args, keep, defers))
         if len(self.q) >= self.max:
             self.flush()
-
-    def hold_call(self, fn, keep):
-        """late mode: any other leaf launch (depthwise weight gradient) parked next to the held GEMMs; ``fn()`` launches it"""
-        self.held.append((fn, keep, None))
-
-    def flush_held(self):
-        """launch everything parked by ``hold`` on the CURRENT stream (the caller has switched to the side stream): GEMMs in groups of
-        ``max``, other leaf launches one by one.  Returns the parked operand references -- the caller keeps them until the side
-        stream has been joined (they were allocated on the main stream)."""
-        held, self.held = self.held, []
-        gem = [e for e in held if e[2] is not None]
-        for e in held:
-            if e[2] is None:
-                e[0]()
-        for i in range(0, len(gem), self.max):
-            q = gem[i:i + self.max]
-            arr = (TnArgs * len(q))(*[e[0] for e in q])
-            lib.call("tuber_gemm_tn_group", arr, len(q))
-            for _, _, defers in q:
-                for d in defers:
-                    self.store.defer.add(*d)
-        return held
 
     def flush(self):
         q, self.q = self.q, []
@@ -103,17 +79,20 @@ class DeferredReduce:
     The dW GEMMs, depthwise weight gradients, LayerNorm and bias gradients leave per-workgroup fp32 partials; reducing each right
     away costs ~240 five-microsecond launches per step.  With ``accumulate = 2`` their launchers skip that stage; the partials stay
     in this arena (bump-allocated, same addresses every step, so it is hipGraph-safe) and ``flush()`` reduces all of them with
-    ``tuber_multi_reduce`` -- same summation order as the immediate kernels, bit-identical gradients.  ``TUBER_IMMEDIATE_REDUCE=1``
+    ``tuber_multi_reduce`` -- same summation order as the immediate kernels, bit-identical gradients.  ``TUBER_AB=immediate_reduce``
     restores the per-call reductions."""
     CHUNK = 64 << 20             # floats per arena chunk (256 MB)
     _ENTRY = np.dtype([("P", "<u8"), ("out", "<u8"), ("n", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("mode", "<i4"), ("C", "<i4"), ("next", "<i4")])
 
     def __init__(self, device):
         self.device = device
-        self.enabled = not os.environ.get("TUBER_IMMEDIATE_REDUCE")
         self.chunks, self.ci, self.off = [], 0, 0
         self.entries, self.outs, self.heads, self.cache = [], {}, [], {}
         self.pre_flush = None
+
+    @property
+    def enabled(self):
+        return not ab.on("immediate_reduce")
 
     def reset(self):
         """start of a step: the arena is reused from its first byte (nothing may be pending)."""

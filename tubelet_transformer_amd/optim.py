@@ -197,7 +197,7 @@ def adopt(optimizer, model):
     def bind(load):
         """(re)bind optimizer.state to views of the flat moments; ``load``: first copy what the state holds (resume) into them"""
         step = None
-        for g in groups:
+        for g in optimizer.param_groups:           # (looked up at call time: load_state_dict() REPLACES optimizer.param_groups)
             for p in g["params"]:
                 n = by_ptr.get(p.data_ptr())
                 if n is None:
@@ -227,6 +227,9 @@ def adopt(optimizer, model):
             s["step"] = torch.tensor(t)
 
     def post_load(opt):                            # optimizer.load_state_dict(): loaded tensors replaced the views -> copy in, re-bind
+        # torch's load_state_dict() installs NEW group dicts in optimizer.param_groups: share those again, otherwise
+        # lr_scheduler.step() after a resume would write dicts the fused step no longer reads
+        fused.param_groups = opt.param_groups
         bind(True)
         fused._hyper_host = None
 

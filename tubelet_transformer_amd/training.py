@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from . import ab
 from .ddp import attach_reducer, broadcast_parameters
 from .optim import FusedClipAdamW, adopt, build_param_groups
 
@@ -169,7 +170,6 @@ class GraphedTrainStep:
         # reductions per bottleneck where the captured backward flushes twice): sizes every workspace, builds the reduce tables and
         # the loss-weight / hyper-parameter device tables.  Rolled back afterwards -- a capture is not an optimisation step.
         snap = _Snapshot(model, store, opt)
-        store.no_late = ddp                          # the capture runs with the reducer: the warm-up must take the same launch sequence
         store.reducer = red if in_graph else None
         if in_graph:
             red.dry = True                           # hooks fire (same deferred-reduce flush points as the capture), nothing is sent
@@ -373,7 +373,7 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
     train_tuber_ava.py:58 is adopted (optim.adopt), ``lr_scheduler`` stays bound to that object.
 
     Every batch is one replay of the captured hipGraph step (``GraphedTrainStep``, created on first use and cached on the model;
-    ``graphed=False`` or ``TUBER_EAGER_STEP=1`` forces the eager ``train_step``, which is also the fallback when a capture fails or
+    ``graphed=False`` or ``TUBER_AB=eager_step`` forces the eager ``train_step``, which is also the fallback when a capture fails or
     the optimizer is not AdamW).  The six scalars the reference logs -- ``train/{class_error,totall_loss,loss_bbox,loss_giou,
     loss_ce,loss_ce_b}`` (:215-220), running averages weighted by ``len(targets)`` -- are accumulated on the device for EVERY
     iteration and read back every ``print_freq`` iterations, so the GPU queue stays full; a non-finite loss stops training like
@@ -385,13 +385,16 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
     rank = getattr(cfg.DDP_CONFIG, "GPU_WORLD_RANK", 0)
     if epoch > cfg.CONFIG.LOSS_COFS.WEIGHT_CHANGE:
         criterion.weight_dict["loss_ce"] = cfg.CONFIG.LOSS_COFS.LOSS_CHANGE_COF
-    if graphed is None and not os.environ.get("TUBER_EAGER_STEP"):
+    if graphed is None and not ab.on("eager_step"):
         graphed = _graphed_for(model, criterion, optimizer, max_norm)
     elif graphed is False or graphed is None:
         graphed = None
     meters = _DeviceMeters(dev)
     end = time.time()
     loss = None
+    nonfinite = None
+    import torch.distributed as _dist
+    world = _dist.get_world_size() if _dist.is_available() and _dist.is_initialized() else 1
     n_iter = len(data_loader)
     for idx, data in enumerate(data_loader):
         samples, targets = data[0], data[1]
@@ -414,13 +417,20 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
             lr_scheduler.step_update(epoch * n_iter + idx)
         if rank == 0:
             meters.update(loss, loss_dict, len(targets))
-        if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
-            avg = meters.averages()                            # the only host sync, every print_freq iterations
-            lv = avg["loss"]
-            if lv != lv or lv in (float("inf"), float("-inf")):
-                print("Loss is {}, stopping training".format(lv))
+        # non-finite loss (reference :195-198 checks the rank-reduced loss on every rank, every iteration): a device-side flag updated
+        # on EVERY rank every step, MAX-reduced over the ranks at the print interval and read on every rank, so that all ranks stop
+        # together instead of rank 0 raising while the others wait in the next gradient all-reduce
+        nonfinite = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1) if nonfinite is None else \
+            torch.maximum(nonfinite, (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1))
+        if idx % print_freq == 0 or idx + 1 == n_iter:
+            if world > 1:
+                _dist.all_reduce(nonfinite, op=_dist.ReduceOp.MAX)
+            if int(nonfinite.item()):                          # the only host sync, every print_freq iterations
+                print("Loss is non-finite on some rank, stopping training")
                 print({k: float(v.detach()) if torch.is_tensor(v) else v for k, v in loss_dict.items()})
-                raise FloatingPointError("loss is %r at epoch %d iteration %d" % (lv, epoch, idx))
+                raise FloatingPointError("non-finite loss at epoch %d, iteration <= %d (rank %d of %d)" % (epoch, idx, rank, world))
+        if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
+            avg = meters.averages()
             lr = optimizer.param_groups[-1]["lr"]
             print("Epoch: [%d][%d/%d]" % (epoch, idx + 1, n_iter))
             print("lr: ", lr)
