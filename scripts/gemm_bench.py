@@ -153,6 +153,32 @@ def bench_dw():
               % (N, T, H, W, C, mb, *t, R, C // 64), flush=True)
 
 
+def bench_dw_both():
+    """depthwise backward with the BatchNorm fold: data-gradient kernel + weight-gradient kernel against the one-launch single-pass kernel"""
+    for N, T, H, W, C in [(2, 32, 64, 85, 64), (2, 16, 32, 43, 128), (2, 8, 16, 22, 256), (2, 4, 16, 22, 512)]:
+        M = N * T * H * W
+        x = torch.randn(M, C, device=dev).to(BF)
+        dzu = torch.randn(M, C, device=dev).to(BF)
+        xu = torch.randn(M, C, device=dev).to(BF)
+        w = torch.randn(C, 27, device=dev) / 5
+        sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        gamma, mean, invstd = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+        Rs = 88
+        b0, b1 = torch.randn(Rs, C, device=dev), torch.randn(Rs, C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        out = torch.empty_like(x)
+        R = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+        Rw = lib.query("tuber_dwconv_tile_wgrad_blocks", N, T, H, W, C)
+        st0, st1 = torch.empty(R, C, device=dev), torch.empty(R, C, device=dev)
+        part = torch.empty(max(R, Rw) * 27 * C, device=dev)
+        t = [time_it(lambda: lib.call("tuber_dwconv_tile_bwd_data_bn", dzu, xu, b0, b1, Rs, float(M), gamma, mean, invstd, dg, db, w, x, sc, sh, out, st0, st1, N, T, H, W, C)),
+             time_it(lambda: lib.call("tuber_dwconv_tile_bwd_weight_bn", dzu, xu, b0, b1, Rs, float(M), gamma, mean, invstd, x, sc, sh, part, None, 2, N, T, H, W, C)),
+             time_it(lambda: lib.call("tuber_dwconv_tile_bwd_both_bn", dzu, xu, b0, b1, Rs, float(M), gamma, mean, invstd, dg, db, w, x, sc, sh, out, st0, st1, part, N, T, H, W, C))]
+        mb = 4 * 2 * M * C / 1e6
+        print("dw bwd %dx%dx%dx%d C%d: data %.1f + weight %.1f = %.1f us  ->  one launch, one pass %.1f us  (4-pass alg %.1f MB -> %.2f TB/s)  [WGs %d x %d]"
+              % (N, T, H, W, C, t[0], t[1], t[0] + t[1], t[2], mb, mb / t[2], R, C // 64), flush=True)
+
+
 def bench_dw_scale():
     """Do the small-grid depthwise kernels (layer3: 64 workgroups on 256 CUs) get slower when more workgroups run beside them?"""
     for T, H, W, C in [(8, 16, 22, 256), (16, 32, 43, 128)]:
@@ -229,6 +255,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dwscale":
         bench_dw_scale()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dwboth":
+        bench_dw_both()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dw":
         bench_dw()

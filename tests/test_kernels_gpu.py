@@ -1019,18 +1019,22 @@ def test_dwconv_tile_backward_with_bn_backward_folded_in(dev, N, T, H, W, C, R):
     dwg = torch.zeros(C, 27, device=dev)
     lib.call("tuber_dwconv_tile_bwd_weight_bn", dz3, c3, st0, st1, R, float(M), gamma, mean, invstd, c1, sc1, sh1, part, dwg, 0, N, T, H, W, C)
     close("dw weight gradient with bn3 folded in", dwg, dw_ref, rel=3e-3, abs_=3e-3 * float(dw_ref.abs().max()))
-    # both gradients in ONE launch: bit-identical to the two launches (dz1, its statistics rows, dgamma / dbeta, the partial blocks)
-    part1 = torch.empty(nb * 27 * C, device=dev)
-    lib.call("tuber_dwconv_tile_bwd_weight_bn", dz3, c3, st0, st1, R, float(M), gamma, mean, invstd, c1, sc1, sh1, part1, None, 2, N, T, H, W, C)
+    # both gradients in ONE launch from ONE staged ring (round 4): dz1 and dgamma / dbeta bit-identical to the data-gradient kernel; the
+    # statistics rows and the weight gradient are the same sums in another order (2-channel x 8-column thread map; products grouped by
+    # the position of the activation) -> equal to the two-launch form up to fp32 rounding
     dgm, dbm = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
     m0, m1 = torch.full((Rb, C), float("nan"), device=dev), torch.full((Rb, C), float("nan"), device=dev)
     dz1m = torch.full((M, C), float("nan"), device=dev, dtype=BF)
-    part2 = torch.full((nb * 27 * C,), float("nan"), device=dev)
+    part2 = torch.full((Rb * 27 * C,), float("nan"), device=dev)
     lib.call("tuber_dwconv_tile_bwd_both_bn", dz3, c3, st0, st1, R, float(M), gamma, mean, invstd, dgm, dbm, w, c1, sc1, sh1, dz1m, m0, m1, part2,
              N, T, H, W, C)
     torch.cuda.synchronize()
-    assert torch.equal(dz1m, dz1) and torch.equal(m0, o0) and torch.equal(m1, o1)
-    assert torch.equal(dgm, dg) and torch.equal(dbm, db) and torch.equal(part2, part1)
+    assert torch.equal(dz1m, dz1) and torch.equal(dgm, dg) and torch.equal(dbm, db)
+    for got, want, what in ((m0, o0, "sum dz rows"), (m1, o1, "sum dz*x rows")):
+        close("one-launch " + what, got.sum(0), want.sum(0), abs_=1e-5 * float(want.abs().sum(0).max()))
+    dw_both = part2.view(Rb, 27, C).sum(0).t()
+    close("one-launch weight gradient vs two-launch", dw_both, dwg, abs_=2e-4 * float(dwg.abs().max()))
+    close("one-launch weight gradient vs fp32 reference", dw_both, dw_ref, rel=3e-3, abs_=3e-3 * float(dw_ref.abs().max()))
     # the unfused sequence agrees to the rounding of its bf16 dc3
     dc3_t = torch.empty(M, C, device=dev, dtype=BF)
     dg2, db2 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)

@@ -503,13 +503,12 @@ class CSNRunner:
                 else:
                     dc3 = self._bn_bwd(b3, s0, s1, R3, Mout, dz3, c3, Mout, train=f["bn3"], apply=depth >= 4)
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
-            # (stride-1 blocks with the bn3 fold: both gradients are independent of each other and run as ONE launch -- in the short-T
-            #  stages most of such a kernel's duration is ramp-up / prologue latency / drain)
+            # (stride-1 blocks with the bn3 fold: ONE launch forms both gradients from one staged ring of dc3 -- 4 tensor passes instead of
+            #  the 7 of two kernels; csrc/dwconv_tile.hip: dwconv_tile_bwd_both_kernel)
             both = (not ab.on("no_dw_bwd_one_launch") and fuse3 and f["w3"] and depth >= 5 and self.store.defer.enabled)
             if both:
-                nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P)
+                R1 = nb = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P)      # one [27][P] weight-gradient block per workgroup of the data-gradient grid
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
-                R1 = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P)
                 s0, s1 = self.ws("st0", R1 * P), self.ws("st1", R1 * P)
                 dz1 = torch.empty(Min, P, dtype=BF, device=dev)
                 lib.call("tuber_dwconv_tile_bwd_both_bn", *bn3, b3.dgamma if f["bn3"] else None, b3.dbeta if f["bn3"] else None,

@@ -378,13 +378,263 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
 template <int MODE, bool BNG = false, bool ACT = true>
 __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG, ACT>(a, blockIdx.x, blockIdx.y); }
 
-// Data gradient AND weight gradient of one depthwise conv (both with the BatchNorm backward above folded in) as ONE launch: the two are
-// independent of each other and, in the short-T stages, one round of 256 one-plane workgroups each -- two thirds of such a kernel's
-// duration is ramp-up, the dependent prologue fetch and drain.  Workgroups [0, nd) are the data gradient's grid, the rest the weight
-// gradient's; results are bit-identical to the two launches.
-__global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs ad, TileArgs aw, int nd) {
-    if ((int)blockIdx.x < nd) dwconv_tile_body<M_BWD_DATA, true>(ad, blockIdx.x, blockIdx.y);
-    else dwconv_tile_body<M_BWD_WEIGHT, true>(aw, blockIdx.x - nd, blockIdx.y);
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: data gradient AND weight gradient of a stride-1 depthwise conv from ONE staged ring (with the BatchNorm backward of the
+// layer above folded into the gradient operand).  Both are sums over the same pairs of positions
+//     dx[p]   = sum_off w[off] * g[p - off]            (the data gradient: flipped taps over the ring of g = dc3 with halo)
+//     dW[off] = sum_p   a[p]   * g[p - off]            (a = relu(bn1(x)) at the CENTRE position p, g from the same ring)
+// so a workgroup that has parked g (formed from dzu and xu) with halo and holds x at its own output positions -- the mask operand it
+// needs anyway -- has every operand of both.  The weight-gradient grid of round 3's two-grid launch (which staged x with halo and
+// re-read dzu / xu at the centre: 7 tensor passes, 2.26x the algorithmic traffic by PMC, two rounds of workgroups in layer3) is gone:
+// reads dzu and xu with halo + x, writes dz = the 4 passes of a depthwise backward.  g is zero outside the volume (parked as zero)
+// and a is cleared for the overhang positions of a tile, so every (p, p - off) pair inside the volume is counted exactly once.
+//
+// Thread map: 27 x 4 weight-gradient accumulators per thread (the 4-channel x 4-column map of the kernels above) plus the data
+// gradient's state does not fit 256 VGPRs (415 spilled).  Here a thread owns 2 channels x 8 consecutive columns of one tile row:
+// 54 accumulators, ds_read_b64 operand reads (32 lanes x 8 B = all 64 banks once), packed FMAs on the channel pair.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | taps [27][64] | coef [3][64]
+    const TileGeom g = a.g;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cp = tid & 31, slot = tid >> 5, row = slot >> 1, cg = slot & 1;      // channel pair, tile row, 8-column half
+    const int c0 = by * 64, c = c0 + cp * 2;
+    int b = bx;
+    const int wt = b % g.wtiles; b /= g.wtiles;
+    const int ht = b % g.htiles; b /= g.htiles;
+    const int tk = b % g.tchunks; const int n = b / g.tchunks;
+    const int h0 = ht * TH, w0 = wt * TW;
+    const int t0 = tk * g.tc, t1 = min(g.T, t0 + g.tc);
+
+    // ---- staging slots: thread -> (position, channel quad) of a plane, loop invariant over t (as in dwconv_tile_body) ----
+    int s_off[NLD];
+    bool s_ok[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        const int pos = idx >> 4, q = idx & 15;
+        const int pr = pos / PW, pc = pos % PW;
+        const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
+        s_ok[i] = pos < NPOS && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+        s_off[i] = s_ok[i] ? (hi * g.W + wi) * g.C + c0 + q * 4 : 0;
+    }
+    const long plane_elems = (long)g.H * g.W * g.C;
+    const bf16* in_n = a.in + (long)n * g.T * plane_elems;
+    const bf16* in2_n = a.xu + (long)n * g.T * plane_elems;
+    uint2 regs[NLD], regs_a[NLD], regs_b[NLD], regx[NLD], regx_a[NLD], regx_b[NLD];
+    auto fetch = [&](int t, uint2 (&rg)[NLD], uint2 (&rx)[NLD]) {          // unconditional loads (see dwconv_tile_body)
+        const bool tok = t >= 0 && t < g.T;
+        const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
+        const bf16* p2 = in2_n + (long)(tok ? t : 0) * plane_elems;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) rg[i] = *(const uint2*)(p + s_off[i]);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) rx[i] = *(const uint2*)(p2 + s_off[i]);
+    };
+    auto park = [&](int t, const uint2 (&rg)[NLD], const uint2 (&rx)[NLD]) {      // g = cA*dzu + cB*xu + cC, fp32, zero outside the volume
+        const bool tok = t >= 0 && t < g.T;
+        float* dst = smem + ((t + 3) % 3) * PLANE;
+        const float* coef = smem + 3 * PLANE + 27 * 64 + (tid & 15) * 4;       // this thread's channel quad (the same for all its slots)
+        const float4 cA = *(const float4*)coef, cB = *(const float4*)(coef + 64), cC = *(const float4*)(coef + 128);
+        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kB[4] = {cB.x, cB.y, cB.z, cB.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (i == NLD - 1 && tid + 512 * i >= NPOS * 16) continue;
+            const bf16x4 v = as_bf16x4(rg[i]), u = as_bf16x4(rx[i]);
+            const bool ok = tok && s_ok[i];
+            float4 o;
+            o.x = ok ? fmaf(kA[0], bf2f(v[0]), fmaf(kB[0], bf2f(u[0]), kC[0])) : 0.f;
+            o.y = ok ? fmaf(kA[1], bf2f(v[1]), fmaf(kB[1], bf2f(u[1]), kC[1])) : 0.f;
+            o.z = ok ? fmaf(kA[2], bf2f(v[2]), fmaf(kB[2], bf2f(u[2]), kC[2])) : 0.f;
+            o.w = ok ? fmaf(kA[3], bf2f(v[3]), fmaf(kB[3], bf2f(u[3]), kC[3])) : 0.f;
+            *(float4*)(dst + 4 * (tid + 512 * i)) = o;              // (position * 64 + quad * 4 == 4 * slot index)
+        }
+    };
+    fetch(t0 - 1, regs_a, regx_a);
+    fetch(t0, regs_b, regx_b);
+    fetch(t0 + 1, regs, regx);
+
+    // ---- x at this thread's output positions (mask + statistics operand of the data gradient, activation operand of the weight
+    // gradient): 4 B per column, fetched one plane ahead, the first ones together with the prologue planes ----
+    const int ho = h0 + row, wo0 = w0 + cg * 8;
+    const bool row_ok = ho < g.H;
+    auto side_fetch = [&](int t, uint32_t (&sd)[8]) {          // unconditional, from the clamped position
+        const long ob = (((long)n * g.T + t) * g.H + min(ho, g.H - 1)) * (long)g.W * g.C + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sd[j] = *(const uint32_t*)(a.aux + ob + (long)min(wo0 + j, g.W - 1) * g.C);
+    };
+    uint32_t side_nx[8];
+    side_fetch(t0, side_nx);
+
+    // ---- coefficients of the BatchNorm backward above, derived under the latency of the fetches just issued (identical arithmetic
+    // to dwconv_tile_body<., BNG>: dgamma / dbeta and the coefficients are bit-identical) ----
+    {
+        double* red = (double*)smem;                     // [2][32][64] in the (still empty) ring
+        float* coef = smem + 3 * PLANE + 27 * 64;        // [3][64] behind the filter taps
+        {
+            const int q = tid & 15, rg = tid >> 4;       // 16 channel quads x 32 row groups
+            double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+            const float* p0 = a.bst0 + c0 + q * 4;
+            const float* p1 = a.bst1 + c0 + q * 4;
+            for (int r = rg; r < a.bR; r += 32) {
+                const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
+                sa[0] += u.x; sa[1] += u.y; sa[2] += u.z; sa[3] += u.w;
+                sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[(0 * 32 + rg) * 64 + q * 4 + e] = sa[e]; red[(1 * 32 + rg) * 64 + q * 4 + e] = sb[e]; }
+        }
+        __syncthreads();
+        double* red2 = red + 2 * 32 * 64;                // [2][4][64]
+        {
+            const int which = tid >> 8, part = (tid >> 6) & 3, ch = tid & 63;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[(which * 32 + part * 8 + k) * 64 + ch];
+            red2[(which * 4 + part) * 64 + ch] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const double sa = (red2[(0 * 4 + 0) * 64 + tid] + red2[(0 * 4 + 1) * 64 + tid]) + (red2[(0 * 4 + 2) * 64 + tid] + red2[(0 * 4 + 3) * 64 + tid]);
+            const double sb = (red2[(1 * 4 + 0) * 64 + tid] + red2[(1 * 4 + 1) * 64 + tid]) + (red2[(1 * 4 + 2) * 64 + tid] + red2[(1 * 4 + 3) * 64 + tid]);
+            const int cc = c0 + tid;
+            const double mu = a.bmean[cc], rr = a.binvstd[cc], gm = a.bgamma[cc];
+            const double sum_dz = sa, sum_dz_xhat = (sb - mu * sa) * rr;
+            const double m1 = sum_dz / a.bcount, m2 = sum_dz_xhat / a.bcount;
+            coef[0 * 64 + tid] = (float)(gm * rr);
+            coef[1 * 64 + tid] = (float)(-gm * rr * rr * m2);
+            coef[2 * 64 + tid] = (float)(gm * rr * rr * m2 * mu - gm * rr * m1);
+            if (bx == 0 && a.bdgamma) {
+                a.bdgamma[cc] += (float)sum_dz_xhat;
+                a.bdbeta[cc] += (float)sum_dz;
+            }
+        }
+        __syncthreads();                                  // the ring is written next (and the coefficients read) by every thread
+    }
+
+    // ---- flipped filter taps [27][64] in LDS behind the ring ----
+    float* wl = smem + 3 * PLANE;
+    for (int i = tid; i < 27 * 64; i += 512) {
+        const int cc = i / 27, tap = i % 27;
+        wl[(26 - tap) * 64 + cc] = a.w[(long)c0 * 27 + i];
+    }
+    f32x2 wacc[27];
+    const float2 sc2 = *(const float2*)(a.sc + c), sh2 = *(const float2*)(a.sh + c);      // bn1 scale / shift of the channel pair
+    f32x2 s0 = f32x2{0.f, 0.f}, s1 = f32x2{0.f, 0.f};
+
+    park(t0 - 1, regs_a, regx_a);
+    park(t0, regs_b, regx_b);
+    // the 54 accumulators come to life HERE, behind the prologue's 72 prefetch registers (an ordinary zero initialisation is hoisted to
+    // the top of the kernel, and the allocator then keeps the prefetched planes in scratch memory: every load waited for its store)
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        float z0, z1;
+        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(z0), "=v"(z1));
+        wacc[k] = f32x2{z0, z1};
+    }
+    for (int t = t0; t < t1; ++t) {
+        park(t + 1, regs, regx);
+        if (t + 1 < t1) fetch(t + 2, regs, regx);
+        uint32_t side[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) side[j] = side_nx[j];
+        if (t + 1 < t1) side_fetch(t + 1, side_nx);
+        const long obase = (((long)n * g.T + t) * g.H + ho) * (long)g.W * g.C + c;
+        __syncthreads();
+        f32x2 acc[8], av[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = f32x2{0.f, 0.f};
+            const bf16x2 x2 = __builtin_bit_cast(bf16x2, side[j]);
+            const bool ok = row_ok && wo0 + j < g.W;      // nothing outside the volume enters the weight gradient
+            av[j] = f32x2{ok ? fmaxf(fmaf(bf2f(x2[0]), sc2.x, sh2.x), 0.f) : 0.f, ok ? fmaxf(fmaf(bf2f(x2[1]), sc2.y, sh2.y), 0.f) : 0.f};
+        }
+        // one temporal tap per pass (a real loop: unrolled over dt the compiler keeps far more operand reads in flight than 256 VGPRs
+        // hold -- 255 spilled).  The weight-gradient accumulators are indexed by the tap, so a pass collects its 9 taps in a
+        // zero-initialised group w9 and folds it into the persistent group of its dt: taps (2 - dt) * 9 + (8 - k9).
+#pragma unroll 1
+        for (int dt = 0; dt < 3; ++dt) {
+            const float* pl = smem + ((t + dt - 1 + 3) % 3) * PLANE;
+            const float* wd = wl + dt * 9 * 64 + cp * 2;
+            f32x2 w9[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w9[k] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const float* rp = pl + ((row + dh) * PW + cg * 8) * 64 + cp * 2;
+                f32x2 in[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { const float2 v = *(const float2*)(rp + i * 64); in[i] = f32x2{v.x, v.y}; }
+                f32x2 w3[3];
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) { const float2 wv = *(const float2*)(wd + (dh * 3 + dw) * 64); w3[dw] = f32x2{wv.x, wv.y}; }
+                // column-major issue order: consecutive FMAs go to different accumulators (acc[j] / the three taps of this row), so no
+                // dependent pair is back to back (tap-major order compiled to 8-long dependent chains with a wait state per link)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int k9 = dh * 3 + dw;
+                        acc[j] = in[j + dw] * w3[dw] + acc[j];           // ring position p + d  <->  filter offset -d ...
+                        w9[8 - k9] = av[j] * in[j + dw] + w9[8 - k9];    // ... i.e. weight-gradient tap 26 - tap = (2 - dt) * 9 + (8 - k9)
+                    }
+                }
+            }
+            // the group of this pass is always the LAST register group; the three groups rotate by one per pass, so after the three passes
+            // of a plane every group is back in its place (a branch on dt that adds into one of three groups makes the register
+            // allocator keep copies of all 27 accumulators across the join: 100+ spills)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const f32x2 g2 = wacc[18 + k] + w9[k]; wacc[18 + k] = wacc[9 + k]; wacc[9 + k] = wacc[k]; wacc[k] = g2; }
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (wo0 + j >= g.W) continue;
+                const bf16x2 x2 = __builtin_bit_cast(bf16x2, side[j]);
+                const float x0 = bf2f(x2[0]), x1 = bf2f(x2[1]);
+                const float d0 = fmaf(x0, sc2.x, sh2.x) > 0.f ? acc[j][0] : 0.f;
+                const float d1 = fmaf(x1, sc2.y, sh2.y) > 0.f ? acc[j][1] : 0.f;
+                bf16x2 o;
+                o[0] = f2bf(d0); o[1] = f2bf(d1);
+                s0 = s0 + f32x2{d0, d1};
+                s1 = s1 + f32x2{d0 * x0, d1 * x1};
+                *(uint32_t*)(a.out + obase + (long)(wo0 + j) * g.C) = __builtin_bit_cast(uint32_t, o);
+            }
+        }
+        __syncthreads();                              // ring slot (t-1) mod 3 is overwritten by the next park
+    }
+
+    // ---- workgroup reductions (the ring is dead now): [27][64] weight-gradient block, then the statistics rows ----
+    float* red = smem;
+    {
+        const int wave = tid >> 6;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float v = xor32_sum(wacc[t][e]);          // the two slots of a wave (lane bit 5) share the channel pair
+                if ((tid & 63) < 32) red[(wave * 27 + t) * 64 + cp * 2 + e] = v;
+            }
+    }
+    float* red_s = smem + 8 * 27 * 64;
+    red_s[slot * 64 + cp * 2] = s0[0]; red_s[slot * 64 + cp * 2 + 1] = s0[1];
+    red_s[(16 + slot) * 64 + cp * 2] = s1[0]; red_s[(16 + slot) * 64 + cp * 2 + 1] = s1[1];
+    __syncthreads();
+    for (int i = tid; i < 27 * 64; i += 512) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv8 = 0; wv8 < 8; ++wv8) s += red[wv8 * 27 * 64 + i];
+        const int tap = i >> 6, cc = i & 63;
+        a.P[((long)bx * 27 + tap) * g.C + c0 + cc] = s;
+    }
+    if (tid < 128) {
+        const int which = tid >> 6, cc = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red_s[(which * 16 + k) * 64 + cc];
+        (which ? a.st1 : a.st0)[(long)bx * g.C + c0 + cc] = s;
+    }
 }
 
 TileGeom make_geom(int N, int T, int H, int W, int C, bool wgrad = false) {
@@ -507,27 +757,26 @@ int tuber_dwconv_tile_bwd_weight_bn(const void* dzu, const void* xu, const float
     return tuber_dw_wgrad_reduce(partial, dw, a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C, accumulate, stream);
 }
 
-// tuber_dwconv_tile_bwd_data_bn and tuber_dwconv_tile_bwd_weight_bn of the same conv in ONE launch (same arguments, same results bit for
-// bit; the weight gradient's partial blocks are reduced by the caller: accumulate must be 2).
+// Data and weight gradient of the same conv in ONE launch and ONE pass over the operands (dwconv_tile_bwd_both_kernel): dz and
+// dgamma / dbeta bit-identical to tuber_dwconv_tile_bwd_data_bn; the statistics rows and the weight gradient are the same sums in another
+// order (other thread map; the weight-gradient products are grouped by the position of the ACTIVATION, not of the gradient), i.e. equal to
+// the two-launch form up to fp32 rounding.  `partial` receives tuber_dwconv_tile_blocks(N, T, H, W, C) blocks of [27][C]
+// (NOT ..._wgrad_blocks), reduced by the caller.
 int tuber_dwconv_tile_bwd_both_bn(const void* dzu, const void* xu, const float* bst0, const float* bst1, int R, float count,
                                   const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                   const float* w, const void* x, const float* sc, const float* sh, void* dz, float* st0, float* st1,
                                   float* partial, int N, int T, int H, int W, int C, hipStream_t stream) {
     if ((C & 63) || !sc || !sh || R <= 0 || R > 128 || !bst0 || !bst1 || !partial || !dz || !st0 || !st1) return TUBER_EINVAL;
-    TileArgs ad{}, aw{};
-    ad.in = (const bf16*)dzu; ad.xu = (const bf16*)xu; ad.sc = sc; ad.sh = sh; ad.w = w; ad.out = (bf16*)dz; ad.aux = (const bf16*)x;
-    ad.st0 = st0; ad.st1 = st1;
-    ad.bst0 = bst0; ad.bst1 = bst1; ad.bR = R; ad.bcount = count; ad.bgamma = gamma; ad.bmean = mean; ad.binvstd = invstd;
-    ad.bdgamma = dgamma; ad.bdbeta = dbeta;
-    ad.g = make_geom(N, T, H, W, C);
-    aw.in = (const bf16*)x; aw.sc = sc; aw.sh = sh; aw.aux = (const bf16*)dzu; aw.xu = (const bf16*)xu; aw.P = partial;
-    aw.bst0 = bst0; aw.bst1 = bst1; aw.bR = R; aw.bcount = count; aw.bgamma = gamma; aw.bmean = mean; aw.binvstd = invstd;
-    aw.g = make_geom(N, T, H, W, C, true);
-    const int nd = ad.g.N * ad.g.tchunks * ad.g.htiles * ad.g.wtiles, nw = aw.g.N * aw.g.tchunks * aw.g.htiles * aw.g.wtiles;
+    TileArgs a{};
+    a.in = (const bf16*)dzu; a.xu = (const bf16*)xu; a.sc = sc; a.sh = sh; a.w = w; a.out = (bf16*)dz; a.aux = (const bf16*)x;
+    a.st0 = st0; a.st1 = st1; a.P = partial;
+    a.bst0 = bst0; a.bst1 = bst1; a.bR = R; a.bcount = count; a.bgamma = gamma; a.bmean = mean; a.binvstd = invstd;
+    a.bdgamma = dgamma; a.bdbeta = dbeta;
+    a.g = make_geom(N, T, H, W, C);
     const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
     static LdsOptIn opt;
     TUBER_LDS_OPT_IN(opt, dwconv_tile_bwd_both_kernel, lds);
-    hipLaunchKernelGGL(dwconv_tile_bwd_both_kernel, dim3(nd + nw, C / 64), dim3(512), lds, stream, ad, aw, nd);
+    hipLaunchKernelGGL(dwconv_tile_bwd_both_kernel, dim3(a.g.N * a.g.tchunks * a.g.htiles * a.g.wtiles, C / 64), dim3(512), lds, stream, a);
     TUBER_RETURN_LAUNCH();
 }
 
