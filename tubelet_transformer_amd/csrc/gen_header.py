@@ -76,9 +76,11 @@ DOC = {
                                      "gradient operand: takes bn3's masked output gradient dzu, bn3's input xu (= c3) and the R <= 128 partial rows (sum dz, sum dz*x) "
                                      "instead of a finished dc3; every workgroup derives cA / cB / cC of its 64 channels (fp64) and forms dc3 = cA*dzu + cB*xu + cC "
                                      "in fp32 while staging. dgamma / dbeta of bn3 are accumulated (+=) unless NULL. Replaces tuber_bn_bwd_fa + tuber_dwconv_tile_bwd_data.",
-    "tuber_dwconv_tile_bwd_both_bn": "tuber_dwconv_tile_bwd_data_bn and tuber_dwconv_tile_bwd_weight_bn of the same depthwise conv in ONE launch (the two gradients are "
-                                     "independent; workgroups [0, data grid) run the data gradient, the rest the weight gradient). Bit-identical results; the weight "
-                                     "gradient's partial blocks [tuber_dwconv_tile_wgrad_blocks][27][C] are left for the caller's tuber_multi_reduce.",
+    "tuber_dwconv_tile_bwd_both_bn": "data gradient AND weight gradient of one stride-1 depthwise conv (bn3's backward folded in) in ONE launch and ONE pass over the "
+                                     "operands: both are sums over the same (p, p - off) position pairs, so the ring of dc3 staged for the data gradient also feeds "
+                                     "dW[off] = sum_p relu(bn1(x))[p] * dc3[p - off] -- 4 tensor passes (read dzu, xu, x; write dz). dz / dgamma / dbeta bit-identical to "
+                                     "tuber_dwconv_tile_bwd_data_bn, statistics rows and weight gradient equal up to fp32 summation order; partial = "
+                                     "tuber_dwconv_tile_blocks(...) blocks of [27][C], reduced by the caller. autograd of models/backbones/ir_CSN_152.py:48-56,74-77.",
     "tuber_dwconv_tile_bwd_weight_bn": "tuber_dwconv_tile_bwd_weight with the same fold: the output-position gradient is formed from (dzu, xu, partial rows) on load.",
     "tuber_comm_init_timeout": "tuber_comm_init with a deadline: the bootstrap (a collective) runs on a helper thread and the call returns -3 with a message naming "
                                "the waiting rank when its peers have not arrived after timeout_ms -- a dead rank fails the job loudly instead of hanging it "
