@@ -78,6 +78,44 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
         # pooled features: |logit| ~ 10) gets the cap in proportion
         assert eh <= CAP[kind] * max(1.0, scale[kind] / 3.0), (kind, eh, scale[kind])
         assert eh <= K_ROUNDED * eb + SLACK[kind], "%s: hip %.3e vs %.1f x rounded-oracle %.3e + %.0e" % (kind, eh, K_ROUNDED, eb, SLACK[kind])
+    _decision_flips(case, got, want, FULL[case][3])
+
+
+def _decision_flips(case, got, want, dataset):
+    """What the logit error does to the DECISIONS the post-processors take (VERDICT r03 item 7: settle the tolerance with a measurement).
+    AVA (PostProcessAVA, models/criterion.py:447-482): a query's 80 scores survive iff p_b = softmax(pred_logits_b)[1] > 0.8 -- count the
+    queries whose gate differs between the HIP path and the fp32 oracle, at 0.8 and (the random-weight fixture keeps p_b far from 0.8)
+    at every threshold of a sweep over the observed range; and the queries whose top-scoring class differs.  JHMDB (PostProcess,
+    :413-445): top class of softmax(pred_logits) per tubelet query.  A flip is legitimate only where the fp32 oracle itself is
+    undecided within the stated logit tolerance; any other flip fails."""
+    lg_h, lg_r = got["pred_logits"].float().cpu(), want["pred_logits"].float()
+    top_h, top_r = lg_h.argmax(-1), lg_r.argmax(-1)
+    srt = lg_r.sort(-1, descending=True).values
+    margin = (srt[..., 0] - srt[..., 1])
+    flips_top = top_h != top_r
+    err_lg = float((lg_h - lg_r).abs().max())
+    bad_top = int((flips_top & (margin > 2 * err_lg)).sum())
+    msg = "   decisions, %s: %d queries; top-class flips %d (all with fp32 top-2 margin <= 2 x logit error %.2e: %s)" % (
+        case, top_r.numel(), int(flips_top.sum()), err_lg, bad_top == 0)
+    assert bad_top == 0
+    if dataset == "ava":
+        pb_h = got["pred_logits_b"].float().cpu().softmax(-1)[..., 1]
+        pb_r = want["pred_logits_b"].float().softmax(-1)[..., 1]
+        dpb = float((pb_h - pb_r).abs().max())
+        gate = int(((pb_h > 0.8) != (pb_r > 0.8)).sum())
+        sweep = {round(float(t), 2): int(((pb_h > t) != (pb_r > t)).sum()) for t in torch.linspace(0.05, 0.95, 19)}
+        worst_t = max(sweep, key=sweep.get)
+        near = int(((pb_r - 0.8).abs() <= dpb).sum())
+        msg += "; p_b in [%.3f, %.3f], max |dp_b| %.2e; gate flips at 0.8: %d (queries within |dp_b| of 0.8: %d); worst threshold of the sweep %.2f: %d flips" % (
+            float(pb_r.min()), float(pb_r.max()), dpb, gate, near, worst_t, sweep[worst_t])
+        # a gate can only flip for a query whose fp32 p_b lies within the measured p_b error of the threshold
+        for t, n in sweep.items():
+            assert n <= int(((pb_r - t).abs() <= dpb).sum())
+        assert gate <= near
+        sc_h = lg_h.sigmoid() * ((pb_h > 0.8).float() * pb_h)[..., None]
+        sc_r = lg_r.sigmoid() * ((pb_r > 0.8).float() * pb_r)[..., None]
+        msg += "; max |d score| of PostProcessAVA %.2e" % float((sc_h - sc_r).abs().max())
+    print(msg)
 
 
 def _check_bn_buffers(cfg, model, state, clips):
