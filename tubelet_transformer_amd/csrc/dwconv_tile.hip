@@ -376,7 +376,11 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
 }
 
 template <int MODE, bool BNG = false, bool ACT = true>
-__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG, ACT>(a, blockIdx.x, blockIdx.y); }
+// Workgroup -> tile: the hardware deals consecutive workgroups round-robin over the 8 XCDs, so with bx = blockIdx.x the spatial neighbours
+// of a tile (which share its halo columns / rows) sit on 8 different L2s and every XCD fetches its own copy of every halo from memory.
+// xcd_remap gives each XCD a CONTIGUOUS range of tile ids -- whole planes of spatially adjacent tiles -- so halos are L2 hits.  The tile id
+// also indexes the statistics rows / partial blocks, so results do not depend on the mapping.
+__global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG, ACT>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y); }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Round 4: data gradient AND weight gradient of a stride-1 depthwise conv from ONE staged ring (with the BatchNorm backward of the
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_t
 __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | taps [27][64] | coef [3][64]
     const TileGeom g = a.g;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    const int bx = xcd_remap(blockIdx.x, gridDim.x), by = blockIdx.y;      // XCD-contiguous tile ids (see dwconv_tile_kernel)
     const int tid = threadIdx.x;
     const int cp = tid & 31, slot = tid >> 5, row = slot >> 1, cg = slot & 1;      // channel pair, tile row, 8-column half
     const int c0 = by * 64, c = c0 + cp * 2;
