@@ -105,10 +105,10 @@ def alg_cost(name, a):
     if name == "tuber_blockout_conv1_fwd":       # reads c4 and the shortcut, writes y [M,256] and the next conv1 output [M,pn]
         M, pn = a[12], a[13]
         return "blockout_conv1_kernel<%d>" % pn, 2 * M * (3 * 256 + pn), 2 * M * 256 * pn
-    if name == "tuber_conv1_bwd_fused":          # reads dz1, c1 [M,64], x [M,256] (+ residual gradient, + lower c4), writes [M,256]
-        M = a[14]
-        wide = 2 + (a[7] is not None) + (a[9] is not None)
-        return "conv1_bwd_kernel<%s>" % ("true" if a[9] is not None else "false"), 2 * M * (128 + 256 * wide), 2 * 2 * M * 256 * 64
+    if name == "tuber_conv1_bwd_fused":          # reads dz1, c1 [M,64], x [M,256] (+ residual gradient, + lower c4, + lower projection output), writes [M,256]
+        M = a[16]
+        wide = 2 + (a[7] is not None) + (a[9] is not None) + (a[10] is not None)
+        return "conv1_bwd_kernel<%d>" % (2 if a[10] is not None else 1 if a[9] is not None else 0), 2 * M * (128 + 256 * wide), 2 * 2 * M * 256 * 64
     if name == "tuber_block_out_fwd":
         return "block_out_fwd_kernel", 2 * 3 * a[7] * a[8], 0
     if name == "tuber_block_out_bwd":
@@ -139,7 +139,7 @@ def shape_of(name, a):
         off = 10 if name == "tuber_attn_fwd" else 19
         return "B%d H%d Lq%d Lk%d" % tuple(a[off:off + 4])
     if name in ("tuber_conv4_bwd_fused", "tuber_conv1_bwd_fused"):
-        return "M%d" % a[14]
+        return "M%d" % a[14 if name == "tuber_conv4_bwd_fused" else 16]
     if name == "tuber_entry_conv_fwd":
         return "M%d" % a[11]
     if name == "tuber_blockout_conv1_fwd":

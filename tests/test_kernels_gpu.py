@@ -1186,7 +1186,7 @@ def test_blockout_conv1_fwd_fused(dev, M, PN, proj):
 
 
 @pytest.mark.parametrize("M,join,with_r,with_dw", [(64 * 500, True, True, True), (64 * 23 + 11, True, True, True), (64 * 300, False, True, True),
-                                                   (64 * 40, False, False, False), (30, True, False, True)])
+                                                   (64 * 40, False, False, False), (30, True, False, True), (64 * 310 + 5, 2, True, True)])
 def test_conv1_bwd_fused(dev, M, join, with_r, with_dw):
     """tuber_conv1_bwd_fused (layer1's bn1 backward apply + conv1 data gradient [+ the lower block's residual join] + conv1 weight
     gradient as one persistent kernel) against the kernels it replaces: dc1 = bf16(cA*dz1 + cB*c1 + cC); the data gradient through
@@ -1210,7 +1210,10 @@ def test_conv1_bwd_fused(dev, M, join, with_r, with_dw):
     st0 = torch.full((tiles, C), float("nan"), device=dev) if join else None
     st1 = torch.full((tiles, C), float("nan"), device=dev) if join else None
     slab = torch.full((S, P, C), float("nan"), device=dev) if with_dw else None
-    lib.call("tuber_conv1_bwd_fused", dz1, c1, cA, cB, cC, w1t, ldw, R, X, Cm, out, st0, st1, slab, M)
+    # join == 2: the lower block is a stage's first block -- a third statistics row (sum dz * cd) for its projection shortcut's BatchNorm
+    Cd = rnd(M, C, dev=dev, seed=10).to(BF) if join == 2 else None
+    st2 = torch.full((tiles, C), float("nan"), device=dev) if join == 2 else None
+    lib.call("tuber_conv1_bwd_fused", dz1, c1, cA, cB, cC, w1t, ldw, R, X, Cm, Cd, out, st0, st1, st2, slab, M)
     torch.cuda.synchronize()
     dc1 = (cA * dz1.float() + cB * c1.float() + cC).to(BF)
     dx = dc1.float() @ W1.to(BF).float() + (R.float() if with_r else 0.0)
@@ -1228,6 +1231,11 @@ def test_conv1_bwd_fused(dev, M, join, with_r, with_dw):
         close("conv1 bwd fused dz vs gemm_nt_join", out, dz_j.float(), rel=2 ** -7)
         close("conv1 bwd fused stats sum dz vs gemm_nt_join", st0, j0, abs_=1e-3 * float(j0.abs().max()) + 1e-5)
         close("conv1 bwd fused stats sum dz*c4 vs gemm_nt_join", st1, j1, abs_=1e-3 * float(j1.abs().max()) + 1e-5)
+        if join == 2:
+            want = (out.float() * Cd.float()).view(-1, C)
+            pad = tiles * 64 - M
+            want = torch.cat([want, torch.zeros(pad, C, device=dev)]).view(tiles, 64, C).sum(1)
+            close("conv1 bwd fused stats sum dz*cd (projection shortcut)", st2, want, abs_=1e-3 * float(want.abs().max()) + 1e-5)
     else:
         close("conv1 bwd fused dx (plain)", out, dx)
     if with_dw:

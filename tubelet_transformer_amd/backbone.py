@@ -449,8 +449,8 @@ class CSNRunner:
             depth = 7 if need_dx else (6 if f["w1"] else 5 if f["bn1"] else 4 if f["w3"] else 3 if f["bn3"] else 2 if f["w4"] else 1)
             # join backward: dz + stats of bn4 (and the shortcut BN)
             if pre is not None:
-                dz, sa, sb, R = pre
-                pre, sc_ = None, None
+                dz, sa, sb, sc_, R = pre        # (sc_: the projection shortcut's statistics rows when the join of a stage's first block was fused)
+                pre = None
             else:
                 R = lib.query("tuber_rowblock_count", Mout, C4)
                 sa, sb, sc_ = self.ws("st0", R * C4), self.ws("st1", R * C4), self.ws("st2", R * C4)
@@ -587,27 +587,34 @@ class CSNRunner:
                 # identity block and dx is complete after this GEMM, its join backward (dz = dx * [y > 0] + the bn4 statistics) runs
                 # as the GEMM's epilogue: dx never reaches HBM and the block_out_bwd launch of the next iteration is gone.
                 fuse = not ab.on("no_join_fusion") and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
+                # layer1: the persistent conv1-backward kernel also takes the join of the stage's FIRST block below it (one more LDS image: the
+                # projection shortcut's raw output, for its BatchNorm's statistics row) -- that join was a five-tensor block_out_bwd pass (170 us)
+                fuse_ds = (not ab.on("no_join_fusion") and not ab.on("no_ds_join_fusion") and bi - 1 >= lowest and self.blocks[bi - 1]["ds"]
+                           and not (d["ds"] and strided))
                 if fuse1:
                     part1 = None
                     if f["w1"]:
                         S1 = lib.query("tuber_conv1_bwd_slabs", Min)
                         part1, acc1 = self.store.partial("c1f", S1 * P * cin, self.ws)
                     outx = torch.empty(Min, cin, dtype=BF, device=dev)
-                    if fuse:
+                    cdl, jc = None, None
+                    if fuse or fuse_ds:
                         c4l = sblocks[bi - 1 - base][3]
                         Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                         ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
+                        if fuse_ds:
+                            cdl, jc = sblocks[bi - 1 - base][4], self.ws("stj2", Rj * cin)
                     else:
                         c4l, ja, jb = None, None, None
-                    lib.call("tuber_conv1_bwd_fused", dz1, c1, b1.cA, b1.cB, b1.cC, d["w1t"], d["ld1t"], res, x, c4l, outx, ja, jb, part1, Min)
+                    lib.call("tuber_conv1_bwd_fused", dz1, c1, b1.cA, b1.cB, b1.cC, d["w1t"], d["ld1t"], res, x, c4l, cdl, outx, ja, jb, jc, part1, Min)
                     if part1 is not None:
                         g1 = d["g1"]
                         if acc1 == 2:
                             self.store.defer.add(part1, g1 if isinstance(g1, int) else g1.data_ptr(), P * cin, P * cin, S1, 1)
                         else:
                             lib.call("tuber_reduce_rows", part1, g1, S1, P * cin, 1)
-                    if fuse:
-                        pre = (outx, ja, jb, Rj)
+                    if fuse or fuse_ds:
+                        pre = (outx, ja, jb, jc, Rj)
                         dy = None
                     else:
                         dy = outx
@@ -617,7 +624,7 @@ class CSNRunner:
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
                     lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
-                    pre = (dzl, ja, jb, Rj)
+                    pre = (dzl, ja, jb, None, Rj)
                     dy = None
                 else:
                     dx = torch.empty(Min, cin, dtype=BF, device=dev)

@@ -57,19 +57,24 @@ struct Conv1BwdArgs {
     const bf16* R;                         // [M, C] gradient already flowing into x (identity shortcut / projection data gradient) or NULL
     const bf16* X;                         // [M, C] the block input x (= the lower block's output y)
     const bf16* Cm;                        // join: the lower block's raw conv4 output [M, C]; NULL = plain form (out = dx)
+    const bf16* Cd;                        // join below a stage's FIRST block: the raw output of its projection shortcut [M, C] (statistics of its BatchNorm) or NULL
     bf16* out;                             // [M, C]: dz of the lower block (join) or dx
     float* st0; float* st1;                // join: [tiles][C] statistics rows
+    float* st2;                            // join with Cd: [tiles][C] rows of sum dz * cd
     float* slab;                           // [gridDim.x][P][C] fp32: this workgroup's part of dW1 (NULL: conv1 frozen)
     long M;
 };
 
-template <bool JOIN>
+// JOIN: 0 = plain (out = dx), 1 = with the residual join of the identity block below, 2 = ... of the stage's first block below (a third
+// statistics row for the projection shortcut's BatchNorm: its backward used to be a five-tensor block_out_bwd pass, 170 us in layer1)
+template <int JOIN>
 __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* ximg = (bf16*)smem_raw;                       // [64 m][256 c]
     bf16* rimg = ximg + TR * GP;                        // [64 m][256 c] residual gradient R
     bf16* cimg = rimg + TR * GP;                        // [64 m][256 c] lower block's c4 (join form)
-    bf16* dr = cimg + (JOIN ? TR * GP : 0);             // [64 m][64 p] dc1, row-major reads (data gradient)
+    bf16* dimg = cimg + (JOIN ? TR * GP : 0);           // [64 m][256 c] lower block's projection output (JOIN == 2)
+    bf16* dr = dimg + (JOIN == 2 ? TR * GP : 0);        // [64 m][64 p] dc1, row-major reads (data gradient)
     bf16* dt = dr + TR * 64;                            // [64 m][64 p] dc1, transposed reads (weight gradient)
     float* tab = (float*)(dt + TR * 64);                // [3][64] cA | cB | cC
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 8 waves
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
     const int gr = tid >> 5, gch = tid & 31;             // x staging: rows gr + 16 h (h < 4), chunk gch
     // prefetch registers as named scalars: as arrays (indexed in unrolled loops, in a lambda or a macro) the compiler kept two of the three
     // in scratch memory, which made every prefetch wait for its loads at issue
-    uint4 rz, rc, rx0, rx1, rx2, rx3, rr0, rr1, rr2, rr3, rm0, rm1, rm2, rm3;
+    uint4 rz, rc, rx0, rx1, rx2, rx3, rr0, rr1, rr2, rr3, rm0, rm1, rm2, rm3, rd0, rd1, rd2, rd3;
     const bf16* Rp = a.R ? a.R : a.X;                    // no residual gradient: the loads stay unconditional, zeroed below
     const bool hasR = a.R != nullptr;
 #define LOAD_ROW(h, m0_)                                                          \
@@ -101,7 +106,6 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
         const long mx_ = min((m0_) + gr + 16 * h, a.M - 1);                       \
         rx##h = *(const uint4*)(a.X + mx_ * C + gch * 8);                         \
         rr##h = *(const uint4*)(Rp + mx_ * C + gch * 8);                          \
-        if (JOIN) rm##h = *(const uint4*)(a.Cm + mx_ * C + gch * 8);              \
     } while (0)
 #define LOAD_TILE(tt)                                                             \
     do {                                                                          \
@@ -111,15 +115,38 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
         rc = *(const uint4*)(a.c1 + m_ * P + sch * 8);                            \
         LOAD_ROW(0, m0_); LOAD_ROW(1, m0_); LOAD_ROW(2, m0_); LOAD_ROW(3, m0_);   \
     } while (0)
+// the lower block's conv4 output (JOIN) and projection output (JOIN == 2) are fetched LATE -- behind the MFMA / epilogue section of the previous tile -- so that their
+// registers are not live across that section (as a fifth member of the tile-ahead prefetch set they sent 20 registers to scratch
+// memory and every prefetch waited for its loads: 249 us per launch)
+#define LOAD_D(tt)                                                                \
+    do {                                                                          \
+        const long m0_ = (tt) * TR;                                               \
+        rd0 = *(const uint4*)(a.Cd + min(m0_ + gr, a.M - 1) * C + gch * 8);       \
+        rd1 = *(const uint4*)(a.Cd + min(m0_ + gr + 16, a.M - 1) * C + gch * 8);  \
+        rd2 = *(const uint4*)(a.Cd + min(m0_ + gr + 32, a.M - 1) * C + gch * 8);  \
+        rd3 = *(const uint4*)(a.Cd + min(m0_ + gr + 48, a.M - 1) * C + gch * 8);  \
+    } while (0)
+#define LOAD_M(tt)                                                                \
+    do {                                                                          \
+        const long m0_ = (tt) * TR;                                               \
+        rm0 = *(const uint4*)(a.Cm + min(m0_ + gr, a.M - 1) * C + gch * 8);       \
+        rm1 = *(const uint4*)(a.Cm + min(m0_ + gr + 16, a.M - 1) * C + gch * 8);  \
+        rm2 = *(const uint4*)(a.Cm + min(m0_ + gr + 32, a.M - 1) * C + gch * 8);  \
+        rm3 = *(const uint4*)(a.Cm + min(m0_ + gr + 48, a.M - 1) * C + gch * 8);  \
+    } while (0)
 #define PUT_ROW(h)                                                                \
     do {                                                                          \
         *(uint4*)(ximg + goff(gr + 16 * h, gch * 8)) = rx##h;                     \
         *(uint4*)(rimg + goff(gr + 16 * h, gch * 8)) = hasR ? rr##h : make_uint4(0, 0, 0, 0); \
         if (JOIN) *(uint4*)(cimg + goff(gr + 16 * h, gch * 8)) = rm##h;           \
+        if (JOIN == 2) *(uint4*)(dimg + goff(gr + 16 * h, gch * 8)) = rd##h;      \
     } while (0)
     rm0 = rm1 = rm2 = rm3 = make_uint4(0, 0, 0, 0);
+    rd0 = rd1 = rd2 = rd3 = make_uint4(0, 0, 0, 0);
     long t = blockIdx.x;
     LOAD_TILE(t);                                        // the grid never exceeds the tile count
+    if (JOIN) LOAD_M(t);
+    if (JOIN == 2) LOAD_D(t);
     __syncthreads();                                     // tab
     for (; t < ntiles; t += gridDim.x) {
         const long m0 = t * TR;
@@ -156,9 +183,9 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
             }
         }
         // ---- data gradient per 16-row block: D[c][m] = sum_p W1[p][c] * dc1[m][p]; lane: row m = mb*16 + li, c = cw + n*16 + g*4 + r ----
-        float s0[8], s1[8];
+        float s0[8], s1[8], s2[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+        for (int q = 0; q < 8; ++q) { s0[q] = 0.f; s1[q] = 0.f; s2[q] = 0.f; }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -178,6 +205,8 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
                 if (JOIN) {
                     const bf16x4 yv = as_bf16x4(*(const uint2*)(ximg + goff(row, c0)));
                     const bf16x4 cv = as_bf16x4(*(const uint2*)(cimg + goff(row, c0)));
+                    bf16x4 dv = bf16x4{};
+                    if (JOIN == 2) dv = as_bf16x4(*(const uint2*)(dimg + goff(row, c0)));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like tuber_gemm_nt_join / tuber_block_out_bwd
@@ -186,6 +215,7 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
                         o[r] = f2bf(d);
                         s0[n * 4 + r] += d;
                         s1[n * 4 + r] += d * bf2f(cv[r]);
+                        if (JOIN == 2) s2[n * 4 + r] += d * bf2f(dv[r]);
                     }
                 } else {
 #pragma unroll
@@ -203,9 +233,15 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
                     a.st0[t * C + c] = x;
                     a.st1[t * C + c] = y;
                 }
+                if (JOIN == 2) {
+                    const float z = quad16_sum(s2[q]);
+                    if (li == 0) a.st2[t * C + (cw + (q >> 2) * 16 + g * 4 + (q & 3))] = z;
+                }
             }
         }
         __syncthreads();                                  // the output tile is complete in rimg
+        if (JOIN) LOAD_M(min(t + (long)gridDim.x, ntiles - 1));
+        if (JOIN == 2) LOAD_D(min(t + (long)gridDim.x, ntiles - 1));
 #pragma unroll
         for (int h = 0; h < 4; ++h) {                     // coalesced 16-byte stores (8-byte pieces straight from the MFMA layout ran at 2.9 TB/s)
             const int row = gr + 16 * h;
@@ -225,7 +261,10 @@ __global__ __launch_bounds__(NTH, 1) void conv1_bwd_kernel(Conv1BwdArgs a) {
 }
 
 #undef LOAD_TILE
+#undef LOAD_D
+#undef LOAD_M
 constexpr size_t kLdsJoin = (size_t)(3 * TR * GP + 2 * TR * 64) * sizeof(bf16) + 3 * P * sizeof(float);
+constexpr size_t kLdsJoin2 = (size_t)(4 * TR * GP + 2 * TR * 64) * sizeof(bf16) + 3 * P * sizeof(float);
 constexpr size_t kLdsPlain = (size_t)(2 * TR * GP + 2 * TR * 64) * sizeof(bf16) + 3 * P * sizeof(float);
 
 }  // namespace
@@ -243,21 +282,30 @@ int tuber_conv1_bwd_supported(int cin, int p) { return cin == C && p == P; }
 // dz1, c1 [M, 64] bf16; cA / cB / cC [64] fp32 (tuber_bn_bwd_finalize of bn1); w1t = conv1 weight transposed [256][ldw] bf16;
 // R [M, 256] bf16 or NULL; X [M, 256] bf16 (block input); Cm [M, 256] bf16 (the lower block's raw conv4 output) selects the JOIN form:
 // out = (dc1 . W1 + R) * [X > 0] with statistics rows st0 / st1 [ceil(M / 64)][256] (= tuber_gemm_nt_join); Cm NULL: out = dc1 . W1 + R.
+// Cd [M, 256] bf16 (with Cm): the lower block is a stage's first block -- Cd = the raw output of its projection shortcut, st2 receives the rows
+// sum dz * cd its BatchNorm backward needs (what tuber_block_out_bwd writes as its third statistics buffer).
 // slab [tuber_conv1_bwd_slabs(M)][64][256] fp32 (sum over slabs = dW1, conv1.weight layout) or NULL when conv1 is frozen.
 int tuber_conv1_bwd_fused(const void* dz1, const void* c1, const float* cA, const float* cB, const float* cC, const void* w1t, long ldw,
-                          const void* R, const void* X, const void* Cm, void* out, float* st0, float* st1, float* slab, long M,
-                          hipStream_t stream) {
-    if (!dz1 || !c1 || !cA || !cB || !cC || !w1t || !X || !out || M <= 0 || ldw < P || (ldw & 7) || (Cm && (!st0 || !st1))) return TUBER_EINVAL;
+                          const void* R, const void* X, const void* Cm, const void* Cd, void* out, float* st0, float* st1, float* st2, float* slab,
+                          long M, hipStream_t stream) {
+    if (!dz1 || !c1 || !cA || !cB || !cC || !w1t || !X || !out || M <= 0 || ldw < P || (ldw & 7) || (Cm && (!st0 || !st1)) || (Cd && (!Cm || !st2)))
+        return TUBER_EINVAL;
     Conv1BwdArgs a;
     a.dz1 = (const bf16*)dz1; a.c1 = (const bf16*)c1; a.cA = cA; a.cB = cB; a.cC = cC; a.w1t = (const bf16*)w1t; a.ldw = ldw;
-    a.R = (const bf16*)R; a.X = (const bf16*)X; a.Cm = (const bf16*)Cm; a.out = (bf16*)out; a.st0 = st0; a.st1 = st1; a.slab = slab; a.M = M;
-    static LdsOptIn opt[2];
-    const int j = Cm ? 1 : 0;
-    if (j) TUBER_LDS_OPT_IN(opt[1], conv1_bwd_kernel<true>, kLdsJoin);
-    else TUBER_LDS_OPT_IN(opt[0], conv1_bwd_kernel<false>, kLdsPlain);
+    a.R = (const bf16*)R; a.X = (const bf16*)X; a.Cm = (const bf16*)Cm; a.Cd = (const bf16*)Cd; a.out = (bf16*)out;
+    a.st0 = st0; a.st1 = st1; a.st2 = st2; a.slab = slab; a.M = M;
+    static LdsOptIn opt[3];
     const dim3 grid(tuber_conv1_bwd_slabs(M)), block(NTH);
-    if (j) hipLaunchKernelGGL(conv1_bwd_kernel<true>, grid, block, kLdsJoin, stream, a);
-    else hipLaunchKernelGGL(conv1_bwd_kernel<false>, grid, block, kLdsPlain, stream, a);
+    if (Cd) {
+        TUBER_LDS_OPT_IN(opt[2], conv1_bwd_kernel<2>, kLdsJoin2);
+        hipLaunchKernelGGL(conv1_bwd_kernel<2>, grid, block, kLdsJoin2, stream, a);
+    } else if (Cm) {
+        TUBER_LDS_OPT_IN(opt[1], conv1_bwd_kernel<1>, kLdsJoin);
+        hipLaunchKernelGGL(conv1_bwd_kernel<1>, grid, block, kLdsJoin, stream, a);
+    } else {
+        TUBER_LDS_OPT_IN(opt[0], conv1_bwd_kernel<0>, kLdsPlain);
+        hipLaunchKernelGGL(conv1_bwd_kernel<0>, grid, block, kLdsPlain, stream, a);
+    }
     TUBER_RETURN_LAUNCH();
 }
 

@@ -49,7 +49,8 @@ DOC = {
     "tuber_conv1_bwd_fused": "backward of the bottleneck's first pointwise conv through bn1, for the wide-activation stage (256-channel block input, P = 64: layer1), as ONE persistent kernel: "
                              "dc1 = cA*dz1 + cB*c1 + cC lives only in LDS; dx = dc1 . W1 + R -- with Cm given, the residual join of the identity block below: "
                              "dz = dx * [X > 0] plus the statistics rows of tuber_gemm_nt_join --; dW1 = dc1^T . X from the SAME X tile (one fp32 slab per workgroup). "
-                             "Replaces tuber_bn_bwd_apply + tuber_gemm_nt / tuber_gemm_nt_join + tuber_gemm_tn. autograd of models/backbones/ir_CSN_152.py:72-74,84-90.",
+                             "With Cd (the raw output of the lower block's projection shortcut) the join is that of a stage's FIRST block: st2 receives the rows sum dz*cd of the shortcut BatchNorm's backward "
+                             "(tuber_block_out_bwd's third statistics buffer). Replaces tuber_bn_bwd_apply + tuber_gemm_nt / tuber_gemm_nt_join (+ tuber_block_out_bwd) + tuber_gemm_tn. autograd of models/backbones/ir_CSN_152.py:72-74,84-90.",
     "tuber_conv1_bwd_slabs": "workgroups = fp32 weight-gradient slabs tuber_conv1_bwd_fused produces for M rows.",
     "tuber_conv1_bwd_supported": "1 for the (block-input channels, P) the fused conv1 backward is built for.",
     "tuber_blockout_conv1_fwd": "residual join of one bottleneck + the first pointwise conv of the NEXT one as ONE persistent kernel (256-channel block output: layer1, and layer1 -> layer2): "
