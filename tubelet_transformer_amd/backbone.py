@@ -505,7 +505,7 @@ class CSNRunner:
             # depthwise conv: weight grad, data grad fused with relu/bn1 backward
             # (stride-1 blocks with the bn3 fold: ONE launch forms both gradients from one staged ring of dc3 -- 4 tensor passes instead of
             #  the 7 of two kernels; csrc/dwconv_tile.hip: dwconv_tile_bwd_both_kernel)
-            both = (not ab.on("no_dw_bwd_one_launch") and fuse3 and f["w3"] and depth >= 5 and self.store.defer.enabled)
+            both = not ab.on("no_dw_bwd_one_launch") and fuse3 and f["w3"] and depth >= 5
             if both:
                 R1 = nb = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P)      # one [27][P] weight-gradient block per workgroup of the data-gradient grid
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
@@ -514,7 +514,10 @@ class CSNRunner:
                 lib.call("tuber_dwconv_tile_bwd_both_bn", *bn3, b3.dgamma if f["bn3"] else None, b3.dbeta if f["bn3"] else None,
                          d["w3"], c1, b1.scale, b1.shift, dz1, s0, s1, part, B, Ti, Hi, Wi, P)
                 g3 = d["g3"]
-                self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
+                if acc == 2:
+                    self.store.defer.add(part, g3 if isinstance(g3, int) else g3.data_ptr(), 27 * P, 27 * P, nb, 1, P)
+                else:           # immediate second stage (TUBER_AB=immediate_reduce): the same block sum, launched right here
+                    lib.call("tuber_dw_wgrad_reduce", part, g3, nb, P, 1)
             elif f["w3"]:
                 nb = lib.query("tuber_dwconv_tile_wgrad_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_bwd_weight_blocks", B, To, Hq, Wq)
                 part, acc = self.store.partial("tn", nb * 27 * P, self.ws)
