@@ -428,6 +428,13 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
     const bf16* in2_n = a.xu + (long)n * g.T * plane_elems;
     uint2 regs[NLD], regs_a[NLD], regs_b[NLD], regx[NLD], regx_a[NLD], regx_b[NLD];
     auto fetch = [&](int t, uint2 (&rg)[NLD], uint2 (&rx)[NLD]) {          // unconditional loads (see dwconv_tile_body)
+#if defined(DW_DBG) && DW_DBG == 4      /* timing ablation: no plane loads */
+        if (g.C > 0) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) { rg[i] = make_uint2(t, i); rx[i] = make_uint2(i, t); }
+            return;
+        }
+#endif
         const bool tok = t >= 0 && t < g.T;
         const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
         const bf16* p2 = in2_n + (long)(tok ? t : 0) * plane_elems;
@@ -484,6 +491,9 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
             double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
             const float* p0 = a.bst0 + c0 + q * 4;
             const float* p1 = a.bst1 + c0 + q * 4;
+#if defined(DW_DBG) && DW_DBG == 5      /* timing ablation: no partial-row reads of the coefficient derivation */
+            if (g.C < 0)
+#endif
             for (int r = rg; r < a.bR; r += 32) {
                 const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
                 sa[0] += u.x; sa[1] += u.y; sa[2] += u.z; sa[3] += u.w;
