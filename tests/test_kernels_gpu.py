@@ -848,6 +848,44 @@ def test_gemm_nt_join_equals_dgrad_then_block_out_bwd(dev, M, N, K, res):
     close("join sum dz*c4", b1.sum(0), a1.sum(0), abs_=1e-4 * float((dz0.float() * C4.float()).abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("n,Ti,Hi,Wi,st,ss,N,K", [(2, 8, 16, 22, 2, 2, 512, 128), (2, 4, 9, 11, 2, 2, 256, 64), (1, 8, 16, 22, 2, 1, 1024, 512),
+                                                  (2, 6, 10, 12, 1, 2, 256, 128)])
+def test_gemm_nt_join_strided_residual(dev, n, Ti, Hi, Wi, st, ss, N, K):
+    """tuber_gemm_nt_join_strided (a stage boundary: the join below a block whose projection shortcut is STRIDED) == tuber_gemm_nt followed by
+    tuber_rows_scatter_add of the shortcut's gradient and tuber_block_out_bwd: dz bit-identical, statistics equal after summing their rows.
+    Odd grids (rows that are not sampled at the high end), temporal-only and spatial-only strides (layer4 with LAST_STRIDE False)."""
+    To, Ho, Wo = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
+    M, Mo = n * Ti * Hi * Wi, n * To * Ho * Wo
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    Rs = rnd(Mo, N, dev=dev, seed=3).to(BF)                      # the projection shortcut's data gradient, one row per sampled position
+    Y = rnd(M, N, dev=dev, seed=4).to(BF).relu()
+    C4 = rnd(M, N, dev=dev, seed=5).to(BF)
+    dx = torch.empty(M, N, device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt", A, K, B, K, dx, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+             0, None, None, N, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+    lib.call("tuber_rows_scatter_add", dx, Rs, Mo, To, Ho, Wo, Ti, Hi, Wi, st, ss, N)
+    R0 = lib.query("tuber_rowblock_count", M, N)
+    a0, a1 = torch.zeros(R0, N, device=dev), torch.zeros(R0, N, device=dev)
+    dz0 = torch.empty(M, N, device=dev, dtype=BF)
+    lib.call("tuber_block_out_bwd", dx, Y, C4, None, dz0, a0, a1, None, M, N)
+    R1 = lib.query("tuber_gemm_nt_stat_rows", M, N)
+    b0, b1 = torch.full((R1, N), float("nan"), device=dev), torch.full((R1, N), float("nan"), device=dev)
+    dz1 = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt_join_strided", A, K, B, K, dz1, N, M, N, K, Rs, N, To, Ho, Wo, Ti, Hi, Wi, st, ss, Y, N, C4, N, b0, b1)
+    torch.cuda.synchronize()
+    # (the unfused path rounds dx to bf16 before the scatter-add adds the shortcut's gradient; the fused epilogue adds in fp32 and rounds once)
+    full = torch.zeros(n, Ti, Hi, Wi, N, device=dev)
+    full[:, ::st, ::ss, ::ss] = Rs.float().view(n, To, Ho, Wo, N)
+    ref = (A.float() @ B.float().t() + full.view(M, N)) * (Y.float() > 0)
+    close("strided join dz vs torch", dz1, ref)
+    ndiff = int((dz0 != dz1).sum())
+    assert ndiff <= 0.05 * dz1.numel(), "strided join: dz differs from the three-kernel path in %d of %d elements" % (ndiff, dz1.numel())
+    close("strided join dz vs three kernels", dz1, dz0.float(), rel=2 ** -6)
+    close("strided join sum dz", b0.sum(0), a0.sum(0), abs_=2e-3 * float(dz0.float().abs().sum(0).max()))
+    close("strided join sum dz*c4", b1.sum(0), a1.sum(0), abs_=2e-3 * float((dz0.float() * C4.float()).abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("B,H,W,h,w", [(2, 256, 340, 16, 22), (2, 288, 384, 18, 24), (3, 64, 96, 4, 6), (1, 224, 224, 14, 14), (2, 250, 333, 16, 21)])
 def test_mask_resize_matches_interpolate_nearest(dev, B, H, W, h, w):
     """tuber_mask_resize == F.interpolate(mask[None].float(), size=(h, w)).to(bool)[0] (backbone_builder.py:85-86) for ragged padding masks"""

@@ -12,6 +12,7 @@ KNOWN = {
     "no_wgrad_groups": "one tuber_gemm_tn launch per weight-gradient GEMM instead of the grouped launches (engine.WgradQueue)",
     "immediate_reduce": "second-stage reductions of the weight-gradient partials per call instead of the deferred tuber_multi_reduce",
     "no_join_fusion": "stand-alone block_out_bwd instead of the join backward in the conv1 data-gradient GEMM's epilogue",
+    "no_strided_join_fusion": "gemm + rows_scatter_add + block_out_bwd at the stage boundaries instead of the join GEMM with the strided residual",
     "no_ds_join_fusion": "stand-alone block_out_bwd for the first block of layer1 (the fused conv1 backward takes identity-block joins only)",
     "no_bn_bwd_fa": "BatchNorm backward as finalize + apply launches everywhere (no one-launch form)",
     "no_bn_bwd_fa_after_reduce": "no one-launch BatchNorm backward behind the first-stage row reduction (layer1 / layer2)",

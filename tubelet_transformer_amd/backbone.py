@@ -592,6 +592,8 @@ class CSNRunner:
                 fuse = not ab.on("no_join_fusion") and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"] and not (d["ds"] and strided)
                 # layer1: the persistent conv1-backward kernel also takes the join of the stage's FIRST block below it (one more LDS image: the
                 # projection shortcut's raw output, for its BatchNorm's statistics row) -- that join was a five-tensor block_out_bwd pass (170 us)
+                fuse_sr = (not ab.on("no_join_fusion") and not ab.on("no_strided_join_fusion") and bi - 1 >= lowest and not self.blocks[bi - 1]["ds"]
+                           and d["ds"] and strided and not fuse1 and Min % (Ti * Hi * Wi) == 0)
                 fuse_ds = (not ab.on("no_join_fusion") and not ab.on("no_ds_join_fusion") and bi - 1 >= lowest and self.blocks[bi - 1]["ds"]
                            and not (d["ds"] and strided))
                 if fuse1:
@@ -627,6 +629,18 @@ class CSNRunner:
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
                     lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
+                    pre = (dzl, ja, jb, None, Rj)
+                    dy = None
+                elif fuse_sr:
+                    # a stage's first block above an identity block (layer1 | layer2, layer2 | layer3, layer3 | layer4): the strided projection
+                    # shortcut's gradient dxd is added at its sampled rows INSIDE the join epilogue -- no dx tensor, no scatter-add launch, no
+                    # stand-alone block_out_bwd pass over the previous stage's widest tensors (128 us at the layer1 | layer2 boundary)
+                    c4l = sblocks[bi - 1 - base][3]
+                    Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
+                    ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
+                    dzl = torch.empty(Min, cin, dtype=BF, device=dev)
+                    lib.call("tuber_gemm_nt_join_strided", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, dxd, cin, To, Hq, Wq, Ti, Hi, Wi, st, ss,
+                             x, cin, c4l, cin, ja, jb)
                     pre = (dzl, ja, jb, None, Rj)
                     dy = None
                 else:

@@ -28,7 +28,10 @@ enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4 };
+#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR)
+// EPI_JOIN_SR: EPI_JOIN whose residual R is the gradient of a STRIDED projection shortcut (rows = the sampled positions only; its own
+// instantiation: the row decode cost the hot EPI_JOIN kernel 8 spilled registers when it was a run-time branch in the same epilogue)
 // EPI_JOIN: the data-gradient GEMM of one bottleneck's conv1 fused with the join backward of the bottleneck below it:
 //   dz = (acc + R) * [Ym > 0]   (R = identity-shortcut gradient, Ym = the lower block's output y = relu(bn4(c4) + x))
 //   + BatchNorm-backward partial statistics (sum dz, sum dz * Cm) with Cm = the lower block's raw conv4 output.
@@ -46,6 +49,8 @@ struct GemmNT {
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
     const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
     const bf16* Ym; long ldym;                    // EPI_JOIN: mask source (dz = v * [Ym > 0]); Cm is the statistics operand
+                                                  // EPI_JOIN_SR: R holds one row per STRIDED sample (n, t/st, h/ss, w/ss) of the M = n*Ti*Hi*Wi output
+                                                  // rows (To..ss above): the data gradient of a stage's strided projection shortcut, added where it belongs
     float alpha;                                  // accumulators are scaled by alpha before the epilogue
     uint32_t drop_thresh; float drop_inv_keep; const uint64_t* seed_ptr; uint64_t salt;   // EPI_PLAIN: Dropout after bias/residual/ReLU
 };
@@ -238,10 +243,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         for (int j = 0; j < G; ++j)
             if (j < nk) load_tile(j, ra[j], rb[j], ra2[TWO ? j : 0]);
     }
-    constexpr bool SIDE = EPI == EPI_BWD || EPI == EPI_JOIN;
+    constexpr bool SIDE = EPI == EPI_BWD || IS_JOIN(EPI);
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
-    uint4 sidey[EPI == EPI_JOIN ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
-    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (EPI != EPI_JOIN || (p.ldym & 7) == 0)));
+    uint4 sidey[IS_JOIN(EPI) ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
+    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(EPI) || (p.ldym & 7) == 0)));
     if (SIDE && side_vec) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -249,8 +254,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
             for (int c8 = 0; c8 < NC / 8; ++c8) {
                 side[SIDE ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
-                if (EPI == EPI_JOIN)
-                    sidey[EPI == EPI_JOIN ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (IS_JOIN(EPI))
+                    sidey[IS_JOIN(EPI) ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
             }
         }
     }
@@ -427,26 +432,35 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
             }
-        } else if (EPI == EPI_JOIN) {
+        } else if (IS_JOIN(EPI)) {
             if (mok) {
-                if (p.R) {
+                long rrow = m;
+                bool rok = p.R != nullptr;
+                if constexpr (EPI == EPI_JOIN_SR) {      // the strided projection shortcut's gradient lives at the sampled positions only
+                    const int w = m % p.Wi; int q = m / p.Wi;
+                    const int h = q % p.Hi; q /= p.Hi;
+                    const int t = q % p.Ti; const int n = q / p.Ti;
+                    rok = rok && t % p.st == 0 && h % p.ss == 0 && w % p.ss == 0;
+                    rrow = ((long)(n * p.To + t / p.st) * p.Ho + h / p.ss) * p.Wo + w / p.ss;
+                }
+                if (rok) {
                     if (FULL || (vec_ok && (p.ldr & 7) == 0)) {
 #pragma unroll
                         for (int c8 = 0; c8 < NC / 8; ++c8) {
-                            const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + (long)m * p.ldr + nb + c8 * 8));
+                            const bf16x8 rv = as_bf16x8(*(const uint4*)(p.R + rrow * p.ldr + nb + c8 * 8));
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[c8 * 8 + e] += bf2f(rv[e]);
                         }
                     } else {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += bf2f(p.R[(long)m * p.ldr + nb + c]);
+                        for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += bf2f(p.R[rrow * p.ldr + nb + c]);
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if (FULL || nb + c < p.N) {
                         const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
-                        const float yv = side_vec ? bf2f(as_bf16x8(sidey[EPI == EPI_JOIN ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c]);
+                        const float yv = side_vec ? bf2f(as_bf16x8(sidey[IS_JOIN(EPI) ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c]);
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
                         v[c] = yv > 0.f ? bf2f(f2bf(v[c])) : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
@@ -538,12 +552,13 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
         else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
+        else if (epi == EPI_JOIN_SR) LNT(A_PLAIN, EPI_JOIN_SR);
         else LNT(A_PLAIN, EPI_BWD);
     } else {
         if (amode == A_BN_RELU) {
             if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
-            else if (epi == EPI_JOIN) return TUBER_EINVAL;
+            else if (IS_JOIN(epi)) return TUBER_EINVAL;
             else LNT(A_BN_RELU, EPI_BWD);
         } else if (amode == A_ADD) {
             if (epi != EPI_PLAIN) return TUBER_EINVAL;
@@ -570,6 +585,7 @@ static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
     if (epi == EPI_PLAIN) LWSK(EPI_PLAIN);
     else if (epi == EPI_STATS) LWSK(EPI_STATS);
     else if (epi == EPI_JOIN) LWSK(EPI_JOIN);
+    else if (epi == EPI_JOIN_SR) LWSK(EPI_JOIN_SR);
     else LWSK(EPI_BWD);
 #undef LWSK
     TUBER_RETURN_LAUNCH();
@@ -683,6 +699,27 @@ int tuber_gemm_nt_join(const void* A, long lda, const void* B, long ldb, void* d
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm;
     p.Ym = (const bf16*)Y; p.ldym = ldy;
     return nt_dispatch(p, A_PLAIN, EPI_JOIN, stream);
+}
+
+// tuber_gemm_nt_join where R is the data gradient of a STRIDED projection shortcut (a stage's first block, ir_CSN_152.py:155-161): R has
+// one row per sampled position, Rrows = n * To * Ho * Wo, and is added to the output rows (n, t, h, w) with t % st == h % ss == w % ss == 0
+// (M = n * Ti * Hi * Wi).  Replaces tuber_gemm_nt + tuber_rows_scatter_add + tuber_block_out_bwd at the stage boundaries (layer1 | layer2: a
+// 4-pass elementwise kernel over 178 MB tensors).
+int tuber_gemm_nt_join_strided(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                               const void* R, long ldr, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
+                               const void* Y, long ldy, const void* Cm, long ldcm, float* stat0, float* stat1, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || !Y || !Cm || !stat0 || !stat1 || !R || st < 1 || ss < 1
+        || To != (Ti - 1) / st + 1 || Ho != (Hi - 1) / ss + 1 || Wo != (Wi - 1) / ss + 1 || M % (Ti * Hi * Wi)) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
+    p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm;
+    p.Ym = (const bf16*)Y; p.ldym = ldy;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN_SR, stream);
 }
 
 static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) {

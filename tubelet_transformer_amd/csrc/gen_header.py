@@ -27,6 +27,9 @@ DOC = {
                           "plus the BatchNorm-backward partial rows (sum dz, sum dz*Cm) per 64 output rows (tuber_gemm_nt_stat_rows) -- "
                           "tuber_gemm_nt(epi 0, +R) followed by tuber_block_out_bwd without dx reaching HBM (autograd of "
                           "models/backbones/ir_CSN_152.py:72,86-89 across a block boundary). Y = the lower block's output, Cm = its raw conv4 output; R may be NULL.",
+    "tuber_gemm_nt_join_strided": "tuber_gemm_nt_join at a STAGE boundary: R is the data gradient of the upper stage's strided projection shortcut (one row per sampled "
+                                  "position, n*To*Ho*Wo rows) and is added to the output rows (n, t, h, w) with t % st == h % ss == w % ss == 0 inside the epilogue -- replaces "
+                                  "tuber_gemm_nt + tuber_rows_scatter_add + tuber_block_out_bwd (autograd of models/backbones/ir_CSN_152.py:72,86-89,155-161).",
     "tuber_gemm_tn_group": "n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly one tuber_gemm_tn: dW = G^T f(A) of a 1x1x1 conv, "
                            "autograd of models/backbones/ir_CSN_152.py:41,58,155-161) in ONE launch; args_host = HOST array of struct TuberGemmTNArgs "
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
