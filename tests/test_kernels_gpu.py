@@ -846,6 +846,18 @@ def test_gemm_nt_join_equals_dgrad_then_block_out_bwd(dev, M, N, K, res):
     close("join dz vs torch", dz1, ref)
     close("join sum dz", b0.sum(0), a0.sum(0), abs_=1e-4 * float(dz0.float().abs().sum(0).max()))
     close("join sum dz*c4", b1.sum(0), a1.sum(0), abs_=1e-4 * float((dz0.float() * C4.float()).abs().sum(0).max()))
+    # below a stage's first block: a third statistics row for the projection shortcut's BatchNorm (tuber_gemm_nt_join_ds)
+    Cd = rnd(M, N, dev=dev, seed=6).to(BF)
+    a2 = torch.zeros(R0, N, device=dev)
+    lib.call("tuber_block_out_bwd", dx, Y, C4, Cd, dz0, a0, a1, a2, M, N)
+    d0, d1, d2 = (torch.full((R1, N), float("nan"), device=dev) for _ in range(3))
+    dz2 = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_gemm_nt_join_ds", A, K, B, K, dz2, N, M, N, K, Rr, N, Y, N, C4, N, Cd, N, d0, d1, d2)
+    torch.cuda.synchronize()
+    assert torch.equal(dz2, dz1)
+    close("ds join sum dz", d0.sum(0), a0.sum(0), abs_=1e-4 * float(dz0.float().abs().sum(0).max()))
+    close("ds join sum dz*c4", d1.sum(0), a1.sum(0), abs_=1e-4 * float((dz0.float() * C4.float()).abs().sum(0).max()))
+    close("ds join sum dz*cd", d2.sum(0), a2.sum(0), abs_=1e-4 * float((dz0.float() * Cd.float()).abs().sum(0).max()))
 
 
 @pytest.mark.parametrize("n,Ti,Hi,Wi,st,ss,N,K", [(2, 8, 16, 22, 2, 2, 512, 128), (2, 4, 9, 11, 2, 2, 256, 64), (1, 8, 16, 22, 2, 1, 1024, 512),
@@ -880,7 +892,8 @@ def test_gemm_nt_join_strided_residual(dev, n, Ti, Hi, Wi, st, ss, N, K):
     ref = (A.float() @ B.float().t() + full.view(M, N)) * (Y.float() > 0)
     close("strided join dz vs torch", dz1, ref)
     ndiff = int((dz0 != dz1).sum())
-    assert ndiff <= 0.05 * dz1.numel(), "strided join: dz differs from the three-kernel path in %d of %d elements" % (ndiff, dz1.numel())
+    frac = Mo / M           # only the sampled rows receive a residual, i.e. can round differently
+    assert ndiff <= 0.4 * frac * dz1.numel(), "strided join: dz differs from the three-kernel path in %d of %d elements" % (ndiff, dz1.numel())
     close("strided join dz vs three kernels", dz1, dz0.float(), rel=2 ** -6)
     close("strided join sum dz", b0.sum(0), a0.sum(0), abs_=2e-3 * float(dz0.float().abs().sum(0).max()))
     close("strided join sum dz*c4", b1.sum(0), a1.sum(0), abs_=2e-3 * float((dz0.float() * C4.float()).abs().sum(0).max()))

@@ -13,7 +13,7 @@ KNOWN = {
     "immediate_reduce": "second-stage reductions of the weight-gradient partials per call instead of the deferred tuber_multi_reduce",
     "no_join_fusion": "stand-alone block_out_bwd instead of the join backward in the conv1 data-gradient GEMM's epilogue",
     "no_strided_join_fusion": "gemm + rows_scatter_add + block_out_bwd at the stage boundaries instead of the join GEMM with the strided residual",
-    "no_ds_join_fusion": "stand-alone block_out_bwd for the first block of layer1 (the fused conv1 backward takes identity-block joins only)",
+    "no_ds_join_fusion": "stand-alone block_out_bwd for the first block of every stage (the join kernels take identity-block joins only)",
     "no_bn_bwd_fa": "BatchNorm backward as finalize + apply launches everywhere (no one-launch form)",
     "no_bn_bwd_fa_after_reduce": "no one-launch BatchNorm backward behind the first-stage row reduction (layer1 / layer2)",
     "no_bn3_in_dw": "stand-alone bn_bwd_fa for bn3 instead of forming it inside the depthwise backward kernels",

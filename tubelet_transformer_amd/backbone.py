@@ -631,6 +631,16 @@ class CSNRunner:
                     lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
                     pre = (dzl, ja, jb, None, Rj)
                     dy = None
+                elif fuse_ds:
+                    # the block below is its stage's first block (layer2 / layer3 / layer4): the join epilogue also takes the statistics row of its
+                    # projection shortcut's BatchNorm (sum dz*cd) -- no stand-alone five-tensor block_out_bwd
+                    sv_l = sblocks[bi - 1 - base]
+                    Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
+                    ja, jb, jc = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin), self.ws("stj2", Rj * cin)
+                    dzl = torch.empty(Min, cin, dtype=BF, device=dev)
+                    lib.call("tuber_gemm_nt_join_ds", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, sv_l[3], cin, sv_l[4], cin, ja, jb, jc)
+                    pre = (dzl, ja, jb, jc, Rj)
+                    dy = None
                 elif fuse_sr:
                     # a stage's first block above an identity block (layer1 | layer2, layer2 | layer3, layer3 | layer4): the strided projection
                     # shortcut's gradient dxd is added at its sampled rows INSIDE the join epilogue -- no dx tensor, no scatter-add launch, no

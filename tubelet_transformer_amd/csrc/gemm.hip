@@ -28,8 +28,10 @@ enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4 };
-#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR)
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5 };
+#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS)
+// EPI_JOIN_DS: EPI_JOIN below a stage's FIRST block: a second statistics operand Dm (the raw output of its projection shortcut) and a third
+// row sum dz*Dm (stat2) for the shortcut BatchNorm's backward -- what tuber_block_out_bwd writes for such a block
 // EPI_JOIN_SR: EPI_JOIN whose residual R is the gradient of a STRIDED projection shortcut (rows = the sampled positions only; its own
 // instantiation: the row decode cost the hot EPI_JOIN kernel 8 spilled registers when it was a run-time branch in the same epilogue)
 // EPI_JOIN: the data-gradient GEMM of one bottleneck's conv1 fused with the join backward of the bottleneck below it:
@@ -49,6 +51,7 @@ struct GemmNT {
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
     const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
     const bf16* Ym; long ldym;                    // EPI_JOIN: mask source (dz = v * [Ym > 0]); Cm is the statistics operand
+    const bf16* Dm; long lddm; float* stat2;      // EPI_JOIN_DS
                                                   // EPI_JOIN_SR: R holds one row per STRIDED sample (n, t/st, h/ss, w/ss) of the M = n*Ti*Hi*Wi output
                                                   // rows (To..ss above): the data gradient of a stage's strided projection shortcut, added where it belongs
     float alpha;                                  // accumulators are scaled by alpha before the epilogue
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     constexpr bool SIDE = EPI == EPI_BWD || IS_JOIN(EPI);
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
     uint4 sidey[IS_JOIN(EPI) ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
-    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(EPI) || (p.ldym & 7) == 0)));
+    uint4 sided[EPI == EPI_JOIN_DS ? MT : 1][NC / 8];  // EPI_JOIN_DS: the projection shortcut's raw output
+    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(EPI) || (p.ldym & 7) == 0) && (EPI != EPI_JOIN_DS || (p.lddm & 7) == 0)));
     if (SIDE && side_vec) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -256,6 +260,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                 side[SIDE ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
                 if (IS_JOIN(EPI))
                     sidey[IS_JOIN(EPI) ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (EPI == EPI_JOIN_DS)
+                    sided[EPI == EPI_JOIN_DS ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Dm + (long)m * p.lddm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
             }
         }
     }
@@ -376,10 +382,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     const bool epi_on = true;
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
-    float s0[NC], s1[NC];
+    float s0[NC], s1[NC], s2[EPI == EPI_JOIN_DS ? NC : 1];
     if (EPI != EPI_PLAIN) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; }
+        for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; if (EPI == EPI_JOIN_DS) s2[EPI == EPI_JOIN_DS ? c : 0] = 0.f; }
     }
     float msc[NC], msh[NC];
     if (EPI == EPI_BWD) {
@@ -464,6 +470,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
                         v[c] = yv > 0.f ? bf2f(f2bf(v[c])) : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
+                        if constexpr (EPI == EPI_JOIN_DS) {
+                            const float dv = side_vec ? bf2f(as_bf16x8(sided[i][c >> 3])[c & 7]) : bf2f(p.Dm[(long)m * p.lddm + nb + c]);
+                            s2[c] += v[c] * dv;
+                        }
                     }
                 }
             }
@@ -504,25 +514,33 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     }
     if (EPI != EPI_PLAIN && p.stat0) {
         // one partial row per workgroup tile: reduce the 16 lanes sharing g, then the WM waves via LDS
+        constexpr int NS = EPI == EPI_JOIN_DS ? 3 : 2;
         __syncthreads();
-        float* red = (float*)smem;                       // [WM][BN][2]
+        float* red = (float*)smem;                       // [WM][BN][NS]
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float a = quad16_sum(s0[c]);
             const float b = quad16_sum(s1[c]);
+            float d = 0.f;
+            if constexpr (EPI == EPI_JOIN_DS) d = quad16_sum(s2[c]);
             if (li == 0 && epi_on) {
                 const int col = wn * TN + g * NC + c;
-                red[(wm * BN + col) * 2 + 0] = a;
-                red[(wm * BN + col) * 2 + 1] = b;
+                red[(wm * BN + col) * NS + 0] = a;
+                red[(wm * BN + col) * NS + 1] = b;
+                if constexpr (EPI == EPI_JOIN_DS) red[(wm * BN + col) * NS + 2] = d;
             }
         }
         __syncthreads();
         if (epi_on && tid < BN && (FULL || n0 + tid < p.N)) {
-            float a = 0.f, b = 0.f;
+            float a = 0.f, b = 0.f, d = 0.f;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+            for (int w = 0; w < WM; ++w) {
+                a += red[(w * BN + tid) * NS]; b += red[(w * BN + tid) * NS + 1];
+                if constexpr (EPI == EPI_JOIN_DS) d += red[(w * BN + tid) * NS + 2];
+            }
             p.stat0[(long)tile_m * p.N + n0 + tid] = a;
             p.stat1[(long)tile_m * p.N + n0 + tid] = b;
+            if constexpr (EPI == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
         }
     }
 }
@@ -553,6 +571,7 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
         else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
         else if (epi == EPI_JOIN_SR) LNT(A_PLAIN, EPI_JOIN_SR);
+        else if (epi == EPI_JOIN_DS) LNT(A_PLAIN, EPI_JOIN_DS);
         else LNT(A_PLAIN, EPI_BWD);
     } else {
         if (amode == A_BN_RELU) {
@@ -586,6 +605,7 @@ static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
     else if (epi == EPI_STATS) LWSK(EPI_STATS);
     else if (epi == EPI_JOIN) LWSK(EPI_JOIN);
     else if (epi == EPI_JOIN_SR) LWSK(EPI_JOIN_SR);
+    else if (epi == EPI_JOIN_DS) LWSK(EPI_JOIN_DS);
     else LWSK(EPI_BWD);
 #undef LWSK
     TUBER_RETURN_LAUNCH();
@@ -701,6 +721,23 @@ int tuber_gemm_nt_join(const void* A, long lda, const void* B, long ldb, void* d
     return nt_dispatch(p, A_PLAIN, EPI_JOIN, stream);
 }
 
+// tuber_gemm_nt_join below a stage's FIRST block (layer2 / layer3 / layer4; layer1's runs inside tuber_conv1_bwd_fused): Cd = the raw output of that
+// block's projection shortcut, stat2 receives the rows sum dz*cd of the shortcut BatchNorm's backward (tuber_block_out_bwd's third buffer).
+int tuber_gemm_nt_join_ds(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                          const void* R, long ldr, const void* Y, long ldy, const void* Cm, long ldcm, const void* Cd, long ldcd,
+                          float* stat0, float* stat1, float* stat2, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || !Y || !Cm || !Cd || !stat0 || !stat1 || !stat2) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.stat0 = stat0; p.stat1 = stat1; p.stat2 = stat2; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.Dm = (const bf16*)Cd; p.lddm = ldcd;
+    p.Ym = (const bf16*)Y; p.ldym = ldy;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN_DS, stream);
+}
+
 // tuber_gemm_nt_join where R is the data gradient of a STRIDED projection shortcut (a stage's first block, ir_CSN_152.py:155-161): R has
 // one row per sampled position, Rrows = n * To * Ho * Wo, and is added to the output rows (n, t, h, w) with t % st == h % ss == w % ss == 0
 // (M = n * Ti * Hi * Wi).  Replaces tuber_gemm_nt + tuber_rows_scatter_add + tuber_block_out_bwd at the stage boundaries (layer1 | layer2: a
@@ -727,6 +764,7 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
     int cfg = nt_pick_cfg(M, N, K);
     if (nt_force_cfg() < 0 && cfg == 13 && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
+    if (epi == EPI_JOIN_DS && cfg == 7 && nt_force_cfg() < 0) cfg = 13;   // three side operands spill the 64x128 tile (21 registers at 3 workgroups / CU)
     switch (cfg) {
         case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // class-branch FFN (plain epilogue)
         case 7: return launch_nt_cfg<64, 128, 1, 4, 2, 3>(p, amode, epi, stream);

@@ -30,6 +30,8 @@ DOC = {
     "tuber_gemm_nt_join_strided": "tuber_gemm_nt_join at a STAGE boundary: R is the data gradient of the upper stage's strided projection shortcut (one row per sampled "
                                   "position, n*To*Ho*Wo rows) and is added to the output rows (n, t, h, w) with t % st == h % ss == w % ss == 0 inside the epilogue -- replaces "
                                   "tuber_gemm_nt + tuber_rows_scatter_add + tuber_block_out_bwd (autograd of models/backbones/ir_CSN_152.py:72,86-89,155-161).",
+    "tuber_gemm_nt_join_ds": "tuber_gemm_nt_join below a stage's FIRST block: Cd = the raw output of that block's projection shortcut, stat2 = the rows sum dz*cd of the "
+                             "shortcut BatchNorm's backward (tuber_block_out_bwd's third statistics buffer). autograd of models/backbones/ir_CSN_152.py:86-89,155-161.",
     "tuber_gemm_tn_group": "n <= tuber_gemm_tn_group_max() weight-gradient GEMMs (each exactly one tuber_gemm_tn: dW = G^T f(A) of a 1x1x1 conv, "
                            "autograd of models/backbones/ir_CSN_152.py:41,58,155-161) in ONE launch; args_host = HOST array of struct TuberGemmTNArgs "
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
