@@ -16,6 +16,7 @@ NT_SHAPES = [  # (M, N, K, amode, epi, residual)
     (348160, 64, 256, 0, 1, 0), (348160, 256, 64, 1, 1, 0), (348160, 64, 256, 0, 2, 0), (348160, 256, 64, 0, 0, 0),
     (704, 512, 2048, 0, 1, 0), (704, 2048, 512, 1, 1, 0), (704, 256, 256, 0, 0, 0), (30, 256, 256, 0, 0, 0),
     (16896, 2048, 512, 0, 0, 0),
+    (5632, 256, 2048, 0, 2, 0), (5632, 1024, 512, 0, 0, 0),  # K-concatenated BN-backward variants
     (30, 256, 2048, 0, 0, 0), (704, 256, 2048, 0, 0, 0), (30, 256, 2048, 0, 2, 0), (704, 256, 2048, 0, 2, 0), (30, 2048, 256, 0, 0, 0), (704, 2048, 256, 0, 0, 0),
 ]
 
@@ -128,6 +129,19 @@ def bench_misc():
         out = torch.zeros(C, device=dev)
         part = torch.empty(lib.query("tuber_colsum_blocks", M) * C, device=dev)
         print("colsum M%d C%d: %.1f us" % (M, C, time_it(lambda: lib.call("tuber_colsum", gq, part, out, 1, M, C, C))), flush=True)
+
+
+def bench_bn_fa():
+    """one-launch BatchNorm backward (derive the coefficients from R partial rows + apply) at the model's shapes"""
+    for M, C, R in [(5632, 1024, 88), (5632, 256, 64), (1408, 2048, 22), (44032, 512, 128), (44032, 128, 96), (348160, 256, 128)]:
+        dz, x = torch.randn(M, C, device=dev).to(BF), torch.randn(M, C, device=dev).to(BF)
+        dx = torch.empty_like(x)
+        s0, s1 = torch.randn(R, C, device=dev), torch.randn(R, C, device=dev)
+        gamma, mean, invstd = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        t = time_it(lambda: lib.call("tuber_bn_bwd_fa", s0, s1, R, C, float(M), gamma, mean, invstd, dg, db, dz, x, dx, M))
+        mb = 3 * 2 * M * C / 1e6
+        print("bn_bwd_fa M%d C%d R%d: %.1f us  (3-pass alg %.1f MB -> %.2f TB/s)" % (M, C, R, t, mb, mb / t), flush=True)
 
 
 def bench_dw():
@@ -255,6 +269,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dwscale":
         bench_dw_scale()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bnfa":
+        bench_bn_fa()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dwboth":
         bench_dw_both()

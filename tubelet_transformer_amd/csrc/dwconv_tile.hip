@@ -152,10 +152,21 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
             double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
             const float* p0 = a.bst0 + c0 + q * 4;
             const float* p1 = a.bst1 + c0 + q * 4;
-            for (int r = rg; r < a.bR; r += 32) {
-                const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
-                sa[0] += u.x; sa[1] += u.y; sa[2] += u.z; sa[3] += u.w;
-                sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
+            // four partial rows per trip, all eight loads in flight together (a one-row trip waited for its own L2 round trip: bR = 88
+            // in layer3 was three dependent latencies of a 16 us launch); rows beyond bR are read from row bR - 1 and added as zero
+            for (int r = rg; r < a.bR; r += 128) {
+                float4 u[4], v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long rr = min(r + 32 * k, a.bR - 1);
+                    u[k] = *(const float4*)(p0 + rr * g.C); v[k] = *(const float4*)(p1 + rr * g.C);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = r + 32 * k < a.bR;
+                    sa[0] += ok ? u[k].x : 0.f; sa[1] += ok ? u[k].y : 0.f; sa[2] += ok ? u[k].z : 0.f; sa[3] += ok ? u[k].w : 0.f;
+                    sb[0] += ok ? v[k].x : 0.f; sb[1] += ok ? v[k].y : 0.f; sb[2] += ok ? v[k].z : 0.f; sb[3] += ok ? v[k].w : 0.f;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { red[(0 * 32 + rg) * 64 + q * 4 + e] = sa[e]; red[(1 * 32 + rg) * 64 + q * 4 + e] = sb[e]; }
@@ -465,6 +476,26 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
             *(float4*)(dst + 4 * (tid + 512 * i)) = o;              // (position * 64 + quad * 4 == 4 * slot index)
         }
     };
+    // ---- the SMALL loads go out first: the partial-statistics rows of the coefficient derivation (16 channel quads x 32 row groups,
+    // four rows per thread in flight together) and the filter taps.  Vector loads complete in order, so issued ahead of the three
+    // plane fetches they are waited for alone (an L2 round trip) and the derivation -- three barriers and two fp64 LDS reductions --
+    // runs UNDER the planes' latency; issued behind them (as until round 4) it started when the last plane had landed, one row trip
+    // after the other: 2 - 4 us of every workgroup's 16 - 35 us life
+    const int dq = tid & 15, drg = tid >> 4;
+    const float* const dp0 = a.bst0 + c0 + dq * 4;
+    const float* const dp1 = a.bst1 + c0 + dq * 4;
+    float4 du[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long rr = min(drg + 32 * k, a.bR - 1);
+        du[k] = *(const float4*)(dp0 + rr * g.C); dv[k] = *(const float4*)(dp1 + rr * g.C);
+    }
+    float wreg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wreg[k] = a.w[(long)c0 * 27 + min(tid + 512 * k, 27 * 64 - 1)];
+    const int dch = c0 + (tid & 63);
+    const float d_mu = a.bmean[dch], d_rr = a.binvstd[dch], d_gm = a.bgamma[dch];      // used by threads 0 .. 63 below
+    const float2 sc2 = *(const float2*)(a.sc + c), sh2 = *(const float2*)(a.sh + c);      // bn1 scale / shift of the channel pair
     fetch(t0 - 1, regs_a, regx_a);
     fetch(t0, regs_b, regx_b);
     fetch(t0 + 1, regs, regx);
@@ -487,15 +518,16 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
         double* red = (double*)smem;                     // [2][32][64] in the (still empty) ring
         float* coef = smem + 3 * PLANE + 27 * 64;        // [3][64] behind the filter taps
         {
-            const int q = tid & 15, rg = tid >> 4;       // 16 channel quads x 32 row groups
+            const int q = dq, rg = drg;
             double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-            const float* p0 = a.bst0 + c0 + q * 4;
-            const float* p1 = a.bst1 + c0 + q * 4;
-#if defined(DW_DBG) && DW_DBG == 5      /* timing ablation: no partial-row reads of the coefficient derivation */
-            if (g.C < 0)
-#endif
-            for (int r = rg; r < a.bR; r += 32) {
-                const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {               // rows beyond bR were read from row bR - 1 and are added as zero
+                const bool ok = rg + 32 * k < a.bR;
+                sa[0] += ok ? du[k].x : 0.f; sa[1] += ok ? du[k].y : 0.f; sa[2] += ok ? du[k].z : 0.f; sa[3] += ok ? du[k].w : 0.f;
+                sb[0] += ok ? dv[k].x : 0.f; sb[1] += ok ? dv[k].y : 0.f; sb[2] += ok ? dv[k].z : 0.f; sb[3] += ok ? dv[k].w : 0.f;
+            }
+            for (int r = rg + 128; r < a.bR; r += 32) {      // longer lists than the model's shapes produce
+                const float4 u = *(const float4*)(dp0 + (long)r * g.C), v = *(const float4*)(dp1 + (long)r * g.C);
                 sa[0] += u.x; sa[1] += u.y; sa[2] += u.z; sa[3] += u.w;
                 sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
             }
@@ -516,7 +548,7 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
             const double sa = (red2[(0 * 4 + 0) * 64 + tid] + red2[(0 * 4 + 1) * 64 + tid]) + (red2[(0 * 4 + 2) * 64 + tid] + red2[(0 * 4 + 3) * 64 + tid]);
             const double sb = (red2[(1 * 4 + 0) * 64 + tid] + red2[(1 * 4 + 1) * 64 + tid]) + (red2[(1 * 4 + 2) * 64 + tid] + red2[(1 * 4 + 3) * 64 + tid]);
             const int cc = c0 + tid;
-            const double mu = a.bmean[cc], rr = a.binvstd[cc], gm = a.bgamma[cc];
+            const double mu = d_mu, rr = d_rr, gm = d_gm;
             const double sum_dz = sa, sum_dz_xhat = (sb - mu * sa) * rr;
             const double m1 = sum_dz / a.bcount, m2 = sum_dz_xhat / a.bcount;
             coef[0 * 64 + tid] = (float)(gm * rr);
@@ -532,12 +564,12 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
 
     // ---- flipped filter taps [27][64] in LDS behind the ring ----
     float* wl = smem + 3 * PLANE;
-    for (int i = tid; i < 27 * 64; i += 512) {
-        const int cc = i / 27, tap = i % 27;
-        wl[(26 - tap) * 64 + cc] = a.w[(long)c0 * 27 + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 512 * k;
+        if (i < 27 * 64) wl[(26 - i % 27) * 64 + i / 27] = wreg[k];
     }
     f32x2 wacc[27];
-    const float2 sc2 = *(const float2*)(a.sc + c), sh2 = *(const float2*)(a.sh + c);      // bn1 scale / shift of the channel pair
     f32x2 s0 = f32x2{0.f, 0.f}, s1 = f32x2{0.f, 0.f};
 
     park(t0 - 1, regs_a, regx_a);

@@ -636,7 +636,8 @@ static int nt_pick_cfg(int M, int N, int K) {
 }
 static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream);
 static void nt_cfg_dims(int cfg, int* bm, int* wm) {
-    if (cfg == 0) { *bm = 128; *wm = 2; }
+    if (cfg == 0 || cfg == 21) { *bm = 128; *wm = 2; }
+    else if (cfg == 22) { *bm = 128; *wm = 4; }
     else if (cfg == 7 || cfg == 17) { *bm = 64; *wm = 1; }
     else { *bm = 64; *wm = 2; }
 }
@@ -775,6 +776,8 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
         case 12: return launch_nt_cfg<64, 64, 2, 2, 4, 3>(p, amode, epi, stream);     // 64x64, four-tile prefetch, 3 workgroups / CU
         case 17: return launch_nt_cfg<64, 128, 1, 4, 2, 4>(p, amode, epi, stream);    // round-1 register cap (spills)
         case 2: return launch_nt_cfg<64, 64, 2, 2, 4, 4>(p, amode, epi, stream);      // round-1 default (spills in the fused variants)
+        case 21: return launch_nt_cfg<128, 64, 2, 2, 2, 3>(p, amode, epi, stream);    // round-4 experiment: half the weight re-reads of the long-K layer3 convs
+        case 22: return launch_nt_cfg<128, 64, 4, 1, 2, 3>(p, amode, epi, stream);
 #endif
         default: return TUBER_EINVAL;
     }
@@ -783,7 +786,7 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
 // 1 when tuber_gemm_nt_set_cfg(cfg) names a tile configuration this library was built with
 int tuber_gemm_nt_has_cfg(int cfg) {
 #ifdef TUBER_AB_VARIANTS
-    return cfg == 0 || cfg == 7 || cfg == 13 || cfg == 12 || cfg == 17 || cfg == 2;
+    return cfg == 0 || cfg == 7 || cfg == 13 || cfg == 12 || cfg == 17 || cfg == 2 || cfg == 21 || cfg == 22;
 #else
     return cfg == 0 || cfg == 7 || cfg == 13;
 #endif
