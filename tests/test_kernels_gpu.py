@@ -314,6 +314,47 @@ def test_dwconv_tile(dev, N, T, H, W, C):
     close("dwconv tile bwd weight", dw - 1, wp.grad, rel=2e-3)
 
 
+@pytest.mark.parametrize("N,T,H,W,C,R", [(2, 8, 16, 22, 256, 88), (1, 5, 13, 43, 128, 128), (2, 9, 24, 37, 64, 3), (1, 4, 16, 22, 512, 150)])
+def test_dwconv_tile_forward_finalises_the_batchnorm_in_front_of_it(dev, N, T, H, W, C, R):
+    """tuber_dwconv_tile_fwd_bn = tuber_bn_finalize + tuber_dwconv_tile_fwd in one launch: every output of both -- the conv output, its
+    statistics rows, scale / shift / mean / invstd, the running statistics and num_batches_tracked -- bit for bit (fp64 sums of the fp32
+    partial rows are exact, and the finalisation is the same expression).  reference: nn.BatchNorm3d + ReLU + conv3, ir_CSN_152.py:46-51."""
+    M = N * T * H * W
+    x = rnd(N, T, H, W, C, dev=dev, seed=1, scale=1.5).to(BF)
+    w = rnd(C, 27, dev=dev, seed=2, scale=27 ** -0.5)
+    xf = x.float().view(M, C)
+    bounds = torch.linspace(0, M, R + 1).long().tolist()
+    p0 = torch.stack([xf[bounds[i]:bounds[i + 1]].sum(0) for i in range(R)])
+    p1 = torch.stack([(xf[bounds[i]:bounds[i + 1]] ** 2).sum(0) for i in range(R)])
+    gamma, beta = 1 + 0.1 * rnd(C, dev=dev, seed=3), 0.1 * rnd(C, dev=dev, seed=4)
+    rm, rv = 0.1 * rnd(C, dev=dev, seed=5), 1 + 0.1 * rnd(C, dev=dev, seed=6).abs()
+    nblk = lib.query("tuber_dwconv_tile_blocks", N, T, H, W, C)
+
+    def run(fused):
+        rm2, rv2, nbt = rm.clone(), rv.clone(), torch.full((1,), 41, dtype=torch.int64, device=dev)
+        scale, shift, mean, invstd = (torch.full((C,), float("nan"), device=dev) for _ in range(4))
+        out = torch.empty(N, T, H, W, C, device=dev, dtype=BF)
+        st0, st1 = torch.zeros(nblk, C, device=dev), torch.zeros(nblk, C, device=dev)
+        if fused:
+            lib.call("tuber_dwconv_tile_fwd_bn", x, p0, p1, R, float(M), gamma, beta, rm2, rv2, nbt, 0.1, 1e-3, scale, shift, mean, invstd,
+                     w, out, st0, st1, N, T, H, W, C)
+        else:
+            lib.call("tuber_bn_finalize", p0, p1, R, C, float(M), gamma, beta, rm2, rv2, nbt, 0.1, 1e-3, scale, shift, mean, invstd)
+            lib.call("tuber_dwconv_tile_fwd", x, scale, shift, w, out, st0, st1, N, T, H, W, C)
+        return dict(out=out, st0=st0, st1=st1, scale=scale, shift=shift, mean=mean, invstd=invstd, rmean=rm2, rvar=rv2, nbt=nbt)
+
+    want, got = run(False), run(True)
+    assert int(got["nbt"]) == 42
+    for k in want:
+        assert torch.equal(got[k], want[k]), "%s differs from finalize + forward (max |d| %.3g)" % (k, float((got[k].float() - want[k].float()).abs().max()))
+    # without running statistics (rmean = rvar = nbt = NULL)
+    scale, shift, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
+    out = torch.empty(N, T, H, W, C, device=dev, dtype=BF)
+    lib.call("tuber_dwconv_tile_fwd_bn", x, p0, p1, R, float(M), gamma, beta, None, None, None, 0.1, 1e-3, scale, shift, mean, invstd,
+             w, out, None, None, N, T, H, W, C)
+    assert torch.equal(out, want["out"]) and torch.equal(scale, want["scale"])
+
+
 def test_bn_finalize_and_bwd(dev):
     M, C = 5000, 256
     x = rnd(M, C, dev=dev, seed=1, scale=2.0) + 0.5

@@ -16,6 +16,7 @@ KNOWN = {
     "no_ds_join_fusion": "stand-alone block_out_bwd for the first block of every stage (the join kernels take identity-block joins only)",
     "no_bn_bwd_fa": "BatchNorm backward as finalize + apply launches everywhere (no one-launch form)",
     "no_bn_bwd_fa_after_reduce": "no one-launch BatchNorm backward behind the first-stage row reduction (layer1 / layer2)",
+    "no_bn1_in_dw_fwd": "stand-alone tuber_bn_finalize for bn1 instead of finalising it inside the stride-1 depthwise forward kernel",
     "no_bn3_in_dw": "stand-alone bn_bwd_fa for bn3 instead of forming it inside the depthwise backward kernels",
     "no_dw_bwd_one_launch": "depthwise data and weight gradient of a stride-1 block as two launches",
     "no_conv4_bwd_fused": "layer1's conv4 backward on the separate BatchNorm / GEMM kernels",

@@ -199,14 +199,17 @@ class CSNRunner:
     def _bn_eval(self, bn):
         lib.call("tuber_bn_eval_affine", bn.gamma, bn.beta, bn.rmean, bn.rvar, BN_EPS, bn.scale, bn.shift, bn.C)
 
-    def _gemm_stats(self, A, lda, Wb, ldb, C, M, N, K, amode, sc, sh, gather, bn, train):
-        """conv as GEMM; in training mode also the following BatchNorm's statistics."""
+    def _gemm_stats(self, A, lda, Wb, ldb, C, M, N, K, amode, sc, sh, gather, bn, train, defer=False):
+        """conv as GEMM; in training mode also the following BatchNorm's statistics (``defer``: return the statistics rows (st0, st1, R)
+        instead of finalising them -- the consumer does)."""
         g = gather or (0, 0, 0, 0, 0, 0, 0, 0)
         if train:
             R = lib.query("tuber_gemm_nt_stat_rows", M, N)
             st0, st1 = self.ws("st0", R * N), self.ws("st1", R * N)
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 1, None, None, 0, 0, 0,
                      st0, st1, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+            if defer:
+                return st0, st1, R
             self._bn_train(bn, st0, st1, R, M)
         else:
             lib.call("tuber_gemm_nt", A, lda, Wb, ldb, C, N, M, N, K, amode, sc, sh, 1 if gather else 0, *g, 0, None, None, 0, 0, 0,
@@ -246,6 +249,16 @@ class CSNRunner:
         dev = self.dev
         Ti, Hi, Wi = geom
         pre_c1 = None               # the next block's conv1 output when the previous block's join kernel already produced it
+        pend = None                 # bn1's statistics rows (st0, st1, R, count) when its finalisation is left to the depthwise kernel
+        fold1 = train and not ab.on("no_bn1_in_dw_fwd") and not ab.on("dw_register_tiled")
+
+        def bn1_stats(blk, s0, s1, R, count):
+            """bn1 of a stride-1 block is finalised INSIDE its depthwise forward kernel (tuber_dwconv_tile_fwd_bn): one launch less per block"""
+            if fold1 and blk["st"] == 1 and blk["ss"] == 1:
+                return (s0, s1, R, count)
+            self._bn_train(blk["bn1"], s0, s1, R, count)
+            return None
+
         for bi in range(lo, hi):
             d = self.blocks[bi]
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
@@ -267,23 +280,32 @@ class CSNRunner:
                     a0 = a1 = e0 = e1 = None
                 lib.call("tuber_entry_conv_fwd", x, d["w1"], cin, d["wd"], cin, c1, cd, a0, a1, e0, e1, Min)
                 if train:
-                    self._bn_train(d["bn1"], a0, a1, Rt, Min)
+                    pend = bn1_stats(d, a0, a1, Rt, Min)
                     self._bn_train(d["bnd"], e0, e1, Rt, Min)
                 else:
                     self._bn_eval(d["bn1"])
                     self._bn_eval(d["bnd"])
             else:
                 c1 = torch.empty(Min, P, dtype=BF, device=dev)
-                self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
+                if fold1 and st == 1 and ss == 1:
+                    pend = self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train, defer=True) + (Min,)
+                else:
+                    self._gemm_stats(x, cin, d["w1"], cin, c1, Min, P, cin, 0, None, None, None, d["bn1"], train)
             c3 = torch.empty(Mout, P, dtype=BF, device=dev)
             b1, b3, b4 = d["bn1"], d["bn3"], d["bn4"]
             tile = st == 1 and ss == 1 and not ab.on("dw_register_tiled")        # LDS-staged kernels for the stride-1 blocks (47 of 50)
             if train:
                 R = lib.query("tuber_dwconv_tile_blocks", B, Ti, Hi, Wi, P) if tile else lib.query("tuber_dwconv_fwd_stat_rows", B, To, Hq, Wq)
-                st0, st1 = self.ws("st0", R * P), self.ws("st1", R * P)
+                # (its own pair of buffers when the kernel also READS bn1's rows, which sit in st0 / st1)
+                st0, st1 = (self.ws("st0b", R * P), self.ws("st1b", R * P)) if pend is not None else (self.ws("st0", R * P), self.ws("st1", R * P))
             else:
                 st0 = st1 = None
-            if tile:
+            if pend is not None:
+                p0, p1, pR = self._stat_rows(pend[0], pend[1], pend[2], P)
+                lib.call("tuber_dwconv_tile_fwd_bn", c1, p0, p1, pR, float(pend[3]), b1.gamma, b1.beta, b1.rmean, b1.rvar, b1.nbt, BN_MOM, BN_EPS,
+                         b1.scale, b1.shift, b1.mean, b1.invstd, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, P)
+                pend = None
+            elif tile:
                 lib.call("tuber_dwconv_tile_fwd", c1, b1.scale, b1.shift, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, P)
             else:
                 lib.call("tuber_dwconv_fwd", c1, b1.scale, b1.shift, d["w3"], c3, st0, st1, B, Ti, Hi, Wi, To, Hq, Wq, P, st, ss)
@@ -315,7 +337,7 @@ class CSNRunner:
                     n0 = n1 = None
                 lib.call("tuber_blockout_conv1_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, nxt["w1"], nxt["cin"], pre_c1, n0, n1, Mout, PN)
                 if train:
-                    self._bn_train(nxt["bn1"], n0, n1, Rn, Mout)
+                    pend = bn1_stats(nxt, n0, n1, Rn, Mout)
                 else:
                     self._bn_eval(nxt["bn1"])
             else:

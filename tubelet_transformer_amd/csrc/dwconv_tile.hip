@@ -49,12 +49,19 @@ struct TileArgs {
     const float* bst0; const float* bst1; int bR; float bcount;
     const float* bgamma; const float* bmean; const float* binvstd;
     float* bdgamma; float* bdbeta;      // accumulated (+=) by the workgroups with blockIdx.x == 0 when not NULL
+    // FIN (forward): the training-mode BatchNorm IN FRONT of the conv (bn1) is finalised here instead of by a tuber_bn_finalize launch:
+    // every workgroup derives scale / shift of its 64 channels from the producer's bR partial rows (bst0 = sum x, bst1 = sum x^2,
+    // bcount, bgamma as above); the workgroups with blockIdx.x == 0 publish scale / shift / mean / invstd for the backward and update
+    // the running statistics
+    const float* fbeta; float* frmean; float* frvar; long long* fnbt; float fmom, feps;
+    float* fscale; float* fshift; float* fmean; float* finvstd;
     TileGeom g;
 };
 
 // (bx, by) = the workgroup's position in ITS problem's grid: the kernels below pass blockIdx, the merged backward launch an offset one
-template <int MODE, bool BNG = false, bool ACT = true>
+template <int MODE, bool BNG = false, bool ACT = true, bool FIN = false>
 __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx, const int by) {
+    static_assert(!FIN || (MODE == M_FWD && ACT && !BNG), "FIN: the forward conv behind a training-mode BatchNorm + ReLU");
     extern __shared__ __attribute__((aligned(16))) float smem[];        // ring[3][PLANE] | red
     const TileGeom g = a.g;
     const int tid = threadIdx.x;
@@ -72,7 +79,7 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
     bool s_ok[NLD];
     float sa[4] = {1.f, 1.f, 1.f, 1.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};   // (tid + 512 i) & 15 == cl: one channel quad per thread
     constexpr bool act = MODE != M_BWD_DATA && ACT;     // forward / weight gradient stage relu(bn1(.)); ACT = false: the plain forward conv (no scale / shift given)
-    if (act) {
+    if (act && !FIN) {
         const float4 s = *(const float4*)(a.sc + c), h = *(const float4*)(a.sh + c);
         sa[0] = s.x; sa[1] = s.y; sa[2] = s.z; sa[3] = s.w; sb[0] = h.x; sb[1] = h.y; sb[2] = h.z; sb[3] = h.w;
     }
@@ -139,9 +146,92 @@ __device__ __forceinline__ void dwconv_tile_body(const TileArgs& a, const int bx
 
     // ---- all three planes of the prologue go out together (one memory latency instead of three dependent fetch -> park rounds:
     // the short-T stages run one output plane per workgroup, so the prologue IS the kernel) ----
+    // FIN: the partial-statistics rows (16 channel quads x 32 row groups, four rows per thread in flight together) and the per-channel
+    // constants go out AHEAD of the planes -- vector loads complete in order, so these L2 hits are waited for alone and the
+    // finalisation runs under the planes' latency
+    float4 fu[FIN ? 4 : 1], fv[FIN ? 4 : 1];
+    float f_gam = 0.f, f_bet = 0.f, f_rm = 0.f, f_rv = 0.f;
+    if constexpr (FIN) {
+        const float* p0 = a.bst0 + c0 + (tid & 15) * 4;
+        const float* p1 = a.bst1 + c0 + (tid & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long rr = min((tid >> 4) + 32 * k, a.bR - 1);
+            fu[k] = *(const float4*)(p0 + rr * g.C); fv[k] = *(const float4*)(p1 + rr * g.C);
+        }
+        const int cc = c0 + (tid & 63);
+        f_gam = a.bgamma[cc]; f_bet = a.fbeta[cc];
+        if (a.frmean) { f_rm = a.frmean[cc]; f_rv = a.frvar[cc]; }
+    }
     fetch(t0 - 1, regs_a, regx_a);
     fetch(t0, regs_b, regx_b);
     fetch(t0 + 1, regs, regx);
+
+    if constexpr (FIN) {
+        double* red = (double*)smem;                     // [2][32][64] in the (still empty) ring
+        float* coef = smem + 3 * PLANE + 27 * 64;        // [2][64] behind the filter taps
+        {
+            const int q = tid & 15, rg = tid >> 4;
+            double ua[4] = {0, 0, 0, 0}, ub[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                // rows beyond bR were read from row bR - 1 and are added as zero
+                const bool ok = rg + 32 * k < a.bR;
+                ua[0] += ok ? fu[k].x : 0.f; ua[1] += ok ? fu[k].y : 0.f; ua[2] += ok ? fu[k].z : 0.f; ua[3] += ok ? fu[k].w : 0.f;
+                ub[0] += ok ? fv[k].x : 0.f; ub[1] += ok ? fv[k].y : 0.f; ub[2] += ok ? fv[k].z : 0.f; ub[3] += ok ? fv[k].w : 0.f;
+            }
+            const float* p0 = a.bst0 + c0 + q * 4;
+            const float* p1 = a.bst1 + c0 + q * 4;
+            for (int r = rg + 128; r < a.bR; r += 32) {  // longer lists than the model's shapes produce
+                const float4 u = *(const float4*)(p0 + (long)r * g.C), v = *(const float4*)(p1 + (long)r * g.C);
+                ua[0] += u.x; ua[1] += u.y; ua[2] += u.z; ua[3] += u.w;
+                ub[0] += v.x; ub[1] += v.y; ub[2] += v.z; ub[3] += v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[(0 * 32 + rg) * 64 + q * 4 + e] = ua[e]; red[(1 * 32 + rg) * 64 + q * 4 + e] = ub[e]; }
+        }
+        __syncthreads();
+        double* red2 = red + 2 * 32 * 64;                // [2][4][64]
+        {
+            const int which = tid >> 8, part = (tid >> 6) & 3, ch = tid & 63;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[(which * 32 + part * 8 + k) * 64 + ch];
+            red2[(which * 4 + part) * 64 + ch] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // the arithmetic of bn_finalize_kernel (norm.hip), expression for expression: fp64 sums of the fp32 partial rows are exact,
+            // so scale / shift / mean / invstd and the running statistics are the two-launch path's values
+            const double sx = (red2[(0 * 4 + 0) * 64 + tid] + red2[(0 * 4 + 1) * 64 + tid]) + (red2[(0 * 4 + 2) * 64 + tid] + red2[(0 * 4 + 3) * 64 + tid]);
+            const double sxx = (red2[(1 * 4 + 0) * 64 + tid] + red2[(1 * 4 + 1) * 64 + tid]) + (red2[(1 * 4 + 2) * 64 + tid] + red2[(1 * 4 + 3) * 64 + tid]);
+            const int cc = c0 + tid;
+            const float count = a.bcount;
+            const double mean = sx / (double)count;
+            double var = sxx / (double)count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)a.feps));
+            const float scl = f_gam * invstd;
+            const float shf = f_bet - (float)mean * scl;
+            coef[tid] = scl;
+            coef[64 + tid] = shf;
+            if (bx == 0) {
+                a.fscale[cc] = scl;
+                a.fshift[cc] = shf;
+                a.fmean[cc] = (float)mean;
+                a.finvstd[cc] = invstd;
+                if (a.frmean) {
+                    const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+                    a.frmean[cc] = (1.f - a.fmom) * f_rm + a.fmom * (float)mean;
+                    a.frvar[cc] = (1.f - a.fmom) * f_rv + a.fmom * (float)unbiased;
+                }
+                if (a.fnbt && by == 0 && tid == 0) *a.fnbt += 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sa[e] = coef[cl * 4 + e]; sb[e] = coef[64 + cl * 4 + e]; }
+        __syncthreads();                                  // the ring is written next
+    }
 
     // ---- BNG: coefficients of the BatchNorm backward above, derived under the latency of the fetches just issued ----
     if constexpr (BNG) {
@@ -392,6 +482,8 @@ template <int MODE, bool BNG = false, bool ACT = true>
 // xcd_remap gives each XCD a CONTIGUOUS range of tile ids -- whole planes of spatially adjacent tiles -- so halos are L2 hits.  The tile id
 // also indexes the statistics rows / partial blocks, so results do not depend on the mapping.
 __global__ __launch_bounds__(512) void dwconv_tile_kernel(TileArgs a) { dwconv_tile_body<MODE, BNG, ACT>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y); }
+// the forward conv that also finalises the BatchNorm in front of it (TileArgs: FIN)
+__global__ __launch_bounds__(512) void dwconv_tile_fwd_fin_kernel(TileArgs a) { dwconv_tile_body<M_FWD, false, true, true>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y); }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Round 4: data gradient AND weight gradient of a stride-1 depthwise conv from ONE staged ring (with the BatchNorm backward of the
@@ -756,6 +848,29 @@ int tuber_dwconv_tile_fwd(const void* x, const float* sc, const float* sh, const
         TUBER_RETURN_LAUNCH();
     }
     return launch_tile<M_FWD>(a, stream);
+}
+
+// tuber_dwconv_tile_fwd with the training-mode BatchNorm in front of it (bn1) finalised INSIDE the launch: pst0 / pst1 = the producing
+// conv's R partial rows [R][C] (sum x, sum x^2), count = rows behind them.  Writes scale / shift / mean / invstd [C] and updates
+// rmean / rvar / nbt (NULL: no running statistics) exactly as tuber_bn_finalize does -- that launch disappears from the forward chain.
+int tuber_dwconv_tile_fwd_bn(const void* x, const float* pst0, const float* pst1, int R, float count, const float* gamma, const float* beta,
+                             float* rmean, float* rvar, long long* nbt, float momentum, float eps, float* scale, float* shift,
+                             float* mean, float* invstd, const float* w, void* out, float* st0, float* st1,
+                             int N, int T, int H, int W, int C, hipStream_t stream) {
+    if ((C & 63) || R <= 0 || !pst0 || !pst1 || !gamma || !beta || !scale || !shift || !mean || !invstd || (rmean == nullptr) != (rvar == nullptr))
+        return TUBER_EINVAL;
+    TileArgs a{};
+    a.in = (const bf16*)x; a.w = w; a.out = (bf16*)out; a.st0 = st0; a.st1 = st1;
+    a.bst0 = pst0; a.bst1 = pst1; a.bR = R; a.bcount = count; a.bgamma = gamma;
+    a.fbeta = beta; a.frmean = rmean; a.frvar = rvar; a.fnbt = nbt; a.fmom = momentum; a.feps = eps;
+    a.fscale = scale; a.fshift = shift; a.fmean = mean; a.finvstd = invstd;
+    a.g = make_geom(N, T, H, W, C);
+    const TileGeom& g = a.g;
+    const size_t lds = (3 * PLANE + 27 * 64 + 3 * 64) * sizeof(float);
+    static LdsOptIn opt;
+    TUBER_LDS_OPT_IN(opt, dwconv_tile_fwd_fin_kernel, lds);
+    hipLaunchKernelGGL(dwconv_tile_fwd_fin_kernel, dim3(g.N * g.tchunks * g.htiles * g.wtiles, g.C / 64), dim3(512), lds, stream, a);
+    TUBER_RETURN_LAUNCH();
 }
 
 int tuber_dwconv_tile_bwd_data(const void* gout, const float* w, const void* x, const float* sc, const float* sh, void* dz,

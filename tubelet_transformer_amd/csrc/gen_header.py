@@ -134,6 +134,10 @@ DOC = {
     "tuber_dwconv_fwd_stat_rows": "partial-stat rows written by tuber_dwconv_fwd.",
     "tuber_dwconv_bwd_data_stat_rows": "partial-stat rows written by tuber_dwconv_bwd_data.",
     "tuber_dwconv_bwd_weight_blocks": "blocks (size of `partial` / (27*C)) used by tuber_dwconv_bwd_weight.",
+    "tuber_dwconv_tile_fwd_bn": "tuber_bn_finalize + tuber_dwconv_tile_fwd in ONE launch: the training-mode BatchNorm in front of conv3 (bn1, ir_CSN_152.py:46-51) is "
+                                "finalised inside the conv -- every workgroup derives scale / shift of its 64 channels from the producing conv's R partial rows "
+                                "(pst0 = sum x, pst1 = sum x^2 over `count` rows; fp64 sums, the arithmetic of tuber_bn_finalize expression for expression), the first "
+                                "workgroup of each channel group writes scale / shift / mean / invstd [C] and updates rmean / rvar / nbt (NULL: none). Other arguments as tuber_dwconv_tile_fwd.",
     "tuber_dwconv_tile_fwd": "stride-1 conv3 (ir_CSN_152.py:48-51) with the input planes staged once per workgroup in an LDS ring (activated on the way in): "
                              "same contract as tuber_dwconv_fwd for st = ss = 1; partial-stat rows = tuber_dwconv_tile_blocks.",
     "tuber_dwconv_tile_bwd_data": "LDS-staged data gradient of the stride-1 conv3, fused with the backward of relu(bn1(.)) like tuber_dwconv_bwd_data.",
