@@ -17,6 +17,7 @@ NT_SHAPES = [  # (M, N, K, amode, epi, residual)
     (704, 512, 2048, 0, 1, 0), (704, 2048, 512, 1, 1, 0), (704, 256, 256, 0, 0, 0), (30, 256, 256, 0, 0, 0),
     (16896, 2048, 512, 0, 0, 0),
     (5632, 256, 2048, 0, 2, 0), (5632, 1024, 512, 0, 0, 0),  # K-concatenated BN-backward variants
+    (16896, 2048, 256, 0, 0, 0), (16896, 256, 2048, 0, 0, 0), (16896, 2048, 256, 0, 2, 0), (16896, 256, 256, 0, 0, 0), (16896, 768, 256, 0, 0, 0),  # class branch
     (30, 256, 2048, 0, 0, 0), (704, 256, 2048, 0, 0, 0), (30, 256, 2048, 0, 2, 0), (704, 256, 2048, 0, 2, 0), (30, 2048, 256, 0, 0, 0), (704, 2048, 256, 0, 0, 0),
 ]
 
@@ -59,6 +60,8 @@ def bench_nt(cfgs):
                          0, 0, 0, 0, 0, 0, 0, 0, 0, epi, None, None, 0, 0, 0, st0 if epi else None, st1 if epi else None,
                          Cm if epi == 2 else None, N, sc if epi == 2 else None, sh if epi == 2 else None, 1.0, 0.0, None, 0, None, 0, None)
             row += "  %7.1f" % time_it(fn)
+        if "--blas" in sys.argv:          # the vendor library on the same shape: a yardstick for the tile experiments, never the product path
+            row += "  blas %7.1f" % time_it(lambda: torch.matmul(A, B.t()))
         by = 2 * (M * K + N * K + M * N) + (2 * M * N if epi == 2 else 0)
         print(row + "   | alg %.1f MB, %.2f GF" % (by / 1e6, 2 * M * N * K / 1e9), flush=True)
     lib.call("tuber_gemm_nt_set_cfg", -1)
@@ -129,6 +132,31 @@ def bench_misc():
         out = torch.zeros(C, device=dev)
         part = torch.empty(lib.query("tuber_colsum_blocks", M) * C, device=dev)
         print("colsum M%d C%d: %.1f us" % (M, C, time_it(lambda: lib.call("tuber_colsum", gq, part, out, 1, M, C, C))), flush=True)
+
+
+def bench_ffn():
+    """the FFN GEMMs with their real epilogues (bias / ReLU / residual / dropout), on operands that are NOT cache-resident: each launch of a
+    timed batch works on its own copy (the class-branch tensors are 8.6 - 69 MB; a single repeated copy sits in the 256 MB Infinity Cache)"""
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    for M, N, K in [(16896, 2048, 256), (16896, 256, 2048), (704, 2048, 256), (704, 256, 2048), (30, 256, 2048)]:
+        ncopy = 6 if M > 10000 else 1
+        A = [torch.randn(M, K, device=dev).to(BF) for _ in range(ncopy)]
+        B = torch.randn(N, K, device=dev).to(BF) / K ** 0.5
+        C = [torch.empty(M, N, device=dev, dtype=BF) for _ in range(ncopy)]
+        R = [torch.randn(M, N, device=dev).to(BF) for _ in range(ncopy)]
+        bias = torch.randn(N, device=dev)
+        row = "ffn %5d x %4d x %4d:" % (M, N, K)
+        for name, use_b, use_r, relu, drop in [("plain", 0, 0, 0, 0.0), ("bias", 1, 0, 0, 0.0), ("bias+relu", 1, 0, 1, 0.0), ("bias+relu+drop", 1, 0, 1, 0.1),
+                                               ("bias+res", 1, 1, 0, 0.0), ("bias+res+drop", 1, 1, 0, 0.1)]:
+            it = [0]
+
+            def fn():
+                i = it[0] % ncopy
+                it[0] += 1
+                lib.call("tuber_gemm_nt", A[i], K, B, K, C[i], N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                         bias if use_b else None, R[i] if use_r else None, N, relu, 0, None, None, None, 0, None, None, 1.0, drop, seed, 7, None, 0, None)
+            row += "  %s %.1f" % (name, time_it(fn, iters=12))
+        print(row, flush=True)
 
 
 def bench_bn_fa():
@@ -269,6 +297,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dwscale":
         bench_dw_scale()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ffn":
+        bench_ffn()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bnfa":
         bench_bn_fa()
