@@ -86,6 +86,9 @@ def alg_cost(name, a):
     if name == "tuber_dwconv_tile_bwd_weight_bn":
         N, T, H, W, C = a[15:20]
         return "dwconv_tile_kernel<2,true>", 2 * C * N * T * H * W * 3, 2 * 27 * C * N * T * H * W
+    if name == "tuber_dwconv_tile_fwd_bn":       # the forward conv that also finalises bn1 (kernel name dwconv_tile_fwd_fin_kernel)
+        N, T, H, W, C = a[20:25]
+        return "dwconv_tile_fwd_fin_kernel", 2 * C * N * T * H * W * 2, 2 * 27 * C * N * T * H * W
     if name in ("tuber_dwconv_tile_fwd", "tuber_dwconv_tile_bwd_data", "tuber_dwconv_tile_bwd_weight"):
         off = 8 if name == "tuber_dwconv_tile_bwd_data" else 7
         N, T, H, W, C = a[off:off + 5]

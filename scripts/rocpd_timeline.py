@@ -17,11 +17,11 @@ idx = [i for i, r in enumerate(rows) if "stem_conv_fwd" in names[r[3]]]
 spans = [(rows[(idx[j + 1] if j + 1 < len(idx) else len(rows)) - 1][1] - rows[idx[j]][0], j) for j in range(len(idx) - 1)]
 best = min(spans)[1] if spans else len(idx) - 1
 first, last = idx[best], (idx[best + 1] if best + 1 < len(idx) else len(rows))
-# the weight refresh kernels right before the stem (multi_cast_transpose, cast) belong to the step; the ones before the NEXT stem do not
+# the weight refresh kernels right before the stem (multi_transpose_bf16, cast) belong to the step; the ones before the NEXT stem do not
 lo = first
 while first > 0 and rows[first][0] - rows[first - 1][1] < 50_000 and first > lo - 12:
     first -= 1
-while last > first and last - 1 > idx[best] and any(k in names[rows[last - 1][3]] for k in ("multi_cast_transpose", "cast_f32_bf16", "stem_pack_weight")):
+while last > first and last - 1 > idx[best] and any(k in names[rows[last - 1][3]] for k in ("multi_transpose_bf16", "multi_cast_transpose", "cast_f32_bf16", "stem_pack_weight")):
     last -= 1
 step = rows[first:last]
 t0 = step[0][0]

@@ -46,6 +46,31 @@ def _freeze_like_load_csn_mat(model):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+def test_refresh_writes_the_bf16_and_the_transposed_copy_of_every_gemm_weight(dev):
+    """ParamStore.refresh(): shadow = bf16(flat) and, for every GEMM weight W [N, K] of the model (1x1x1 convs, linears, packed
+    in-projections; rows of 81 classes, 4 box coordinates ... included), tshadow = W^T [K, ldt] with zero padding columns -- bit for bit
+    (tuber_cast_f32_bf16 + tuber_multi_transpose_bf16, 64 x 64 tiles)."""
+    from tubelet_transformer_amd.engine import ParamStore
+    _, model, _ = _model("TubeR_CSN152_AVA21.yaml", dev)
+    store = ParamStore(model, dev)
+    with torch.no_grad():
+        store.flat.copy_(torch.randn(store.total, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+    store.tshadow.fill_(7.0)                       # the kernel owns every element it is responsible for ...
+    store.refresh()
+    assert torch.equal(store.shadow, store.flat.to(torch.bfloat16))
+    assert len(store.tinfo) > 50
+    shapes = set()
+    for name, (toff, N, K, ldt) in store.tinfo.items():
+        o = store.offsets[name]
+        want = store.flat[o:o + N * K].view(N, K).to(torch.bfloat16).t()
+        got = store.tshadow[toff:toff + K * ldt].view(K, ldt)
+        assert torch.equal(got[:, :N], want), name
+        shapes.add((N % 64 != 0, K % 8 != 0))
+        # ... and nothing else: the padding columns N .. ldt-1 inside the last row tile are written as zero, the rest keeps its value
+        assert bool(((got[:, N:] == 0) | (got[:, N:] == 7)).all()), name
+    assert (True, False) in shapes                 # ragged row counts (class / box heads) are part of the model
+
+
 @pytest.mark.parametrize("frozen", [False, True])
 def test_fused_clip_adamw_matches_torch(dev, frozen):
     cfg, model, _ = _model("TubeR_CSN152_AVA21.yaml", dev)

@@ -203,25 +203,45 @@ __global__ void posenc_kernel(const uint8_t* __restrict__ mask, bf16* __restrict
 }
 
 
-// batched W[R][C] fp32 -> W^T[C][ldt] bf16 over a device table of matrices (one launch for every
-// GEMM weight of the model).  table[i] = {src_off, dst_off, R, C, ldt, tile_begin, tiles_x}
+// batched W[R][C] -> W^T[C][ldt], bf16 -> bf16, over a device table of matrices (one launch for every GEMM weight of the model).
+// table[i] = {src_off, dst_off, R, C, ldt, tile_begin, tiles_x}; tiles are 64 x 64.  The source is the bf16 SHADOW of the parameters
+// (tuber_cast_f32_bf16 has just written it: half the bytes of the fp32 masters, and the same rounding); 16-byte loads and stores.
+// Round 1 - 3 transposed 32 x 32 tiles from the fp32 masters with 4-byte loads and 2-byte stores: 48 108 workgroups whose life was a
+// binary search over the table and one 4 KB tile -- 105 us per step for 240 MB.
 struct TrEntry { long src_off, dst_off; int R, C, ldt, tile_begin, tiles_x, pad; };
-__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+__global__ __launch_bounds__(256) void multi_transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
                                                                    const TrEntry* __restrict__ table, int nmat) {
-    __shared__ float t[32][33];
+    constexpr int PITCH = 72;                       // bf16 per row of the TRANSPOSED image: 144 B, 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) bf16 tt[64][PITCH];     // tt[c][r]
     int lo = 0, hi = nmat - 1;
     const int tile = blockIdx.x;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile_begin <= tile) lo = mid; else hi = mid - 1; }
     const TrEntry e = table[lo];
     const int lt = tile - e.tile_begin;
-    const int c0 = (lt % e.tiles_x) * 32, r0 = (lt / e.tiles_x) * 32;
-    const float* W = src + e.src_off;
+    const int c0 = (lt % e.tiles_x) * 64, r0 = (lt / e.tiles_x) * 64;
+    const bf16* W = src + e.src_off;
     bf16* WT = dst + e.dst_off;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8) t[j][tx] = (r0 + j < e.R && c0 + tx < e.C) ? W[(long)(r0 + j) * e.C + c0 + tx] : 0.f;
+    const int q = threadIdx.x & 7, rr = threadIdx.x >> 3;
+    const bool vec = (e.C & 7) == 0;                // rows of W start 16-byte aligned (src_off is a multiple of 64 elements)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = rr + 32 * i;
+        bf16x8 v;
+        if (vec) {
+            v = (r0 + r < e.R && c0 + q * 8 < e.C) ? as_bf16x8(*(const uint4*)(W + (long)(r0 + r) * e.C + c0 + q * 8)) : as_bf16x8(make_uint4(0, 0, 0, 0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (r0 + r < e.R && c0 + q * 8 + k < e.C) ? W[(long)(r0 + r) * e.C + c0 + q * 8 + k] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tt[q * 8 + k][r] = v[k];
+    }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < e.C && r0 + tx < e.R) WT[(long)(c0 + j) * e.ldt + r0 + tx] = f2bf(t[tx][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = rr + 32 * i;                  // output row = source column; 8 consecutive source rows per thread
+        if (c0 + c < e.C && r0 + q * 8 < e.ldt) *(uint4*)(WT + (long)(c0 + c) * e.ldt + r0 + q * 8) = *(const uint4*)&tt[c][q * 8];
+    }
 }
 
 // src[R][C] fp32 -> dst[R][ldd] bf16, columns C..ldd-1 zero filled
@@ -323,9 +343,9 @@ int tuber_posenc(const void* mask, void* out, int B, int T, int H, int W, int hi
     TUBER_RETURN_LAUNCH();
 }
 
-int tuber_multi_cast_transpose(const float* src, void* dst, const void* table, int nmat, int total_tiles, hipStream_t stream) {
+int tuber_multi_transpose_bf16(const void* src, void* dst, const void* table, int nmat, int total_tiles, hipStream_t stream) {
     if (nmat <= 0 || total_tiles <= 0) return TUBER_EINVAL;
-    hipLaunchKernelGGL(multi_cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, stream, src, (bf16*)dst, (const TrEntry*)table, nmat);
+    hipLaunchKernelGGL(multi_transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, (const TrEntry*)table, nmat);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_cast_pad_rows(const float* src, void* dst, int R, int C, int ldd, hipStream_t stream) {

@@ -203,7 +203,8 @@ DOC = {
     "tuber_sigmoid_fwd": "boxes = sigmoid(bbox_embed(hs)) (tuber_ava.py:142).",
     "tuber_sigmoid_bwd": "dx = dy*y*(1-y).",
     "tuber_relu_mask": "dx = dy*[h>0] (ReLU backward from the saved activation; FFN and MLP hidden layers).",
-    "tuber_multi_cast_transpose": "every GEMM weight W[R][C] fp32 -> W^T[C][ldt] bf16 in one launch over a device table {src_off,dst_off,R,C,ldt,tile_begin,tiles_x,pad}.",
+    "tuber_multi_transpose_bf16": "every GEMM weight W[R][C] -> W^T[C][ldt] (bf16 shadow of the parameters -> bf16: the B operand of the data-gradient GEMMs, autograd of "
+                                  "nn.Conv3d(k=1) / nn.Linear) in one launch over a device table {src_off,dst_off,R,C,ldt,tile_begin,tiles_x,pad} of 64 x 64 tiles.",
     "tuber_cast_pad_rows": "src[R][C] fp32 -> dst[R][ldd] bf16 with zero-filled pad columns (stem 441->448 taps, head gradients).",
     "tuber_rows_scatter_add": "dst[map(m)] += src[m] over the strided (n,t*st,h*ss,w*ss) row map: input gradient of a strided down_sample conv (ir_CSN_152.py:155-161).",
     "tuber_posenc": "PositionEmbeddingSine_3D (models/transformer/position_encoding.py:32-72) of a (B,T,H,W) padding mask, token-major bf16.",

@@ -205,7 +205,7 @@ class ParamStore:
                 K = p.numel() // N
                 ldt = _ceil(N, 64)
                 self.tinfo[n] = (toff, N, K, ldt)
-                tx, ty = (K + 31) // 32, (N + 31) // 32
+                tx, ty = (K + 63) // 64, (N + 63) // 64          # 64 x 64 tiles of tuber_multi_transpose_bf16
                 entries.append((self.offsets[n], toff, N, K, ldt, tiles, tx, 0))
                 tiles += tx * ty
                 toff += _ceil(K * ldt, ALIGN)
@@ -290,7 +290,7 @@ class ParamStore:
     def refresh(self):
         lib.call("tuber_cast_f32_bf16", self.flat, self.shadow, self.total)
         if self.nmat:
-            lib.call("tuber_multi_cast_transpose", self.flat, self.tshadow, self.ttable, self.nmat, self.ttiles)
+            lib.call("tuber_multi_transpose_bf16", self.shadow, self.tshadow, self.ttable, self.nmat, self.ttiles)
 
     # -- accessors ---------------------------------------------------------------------------
     def w(self, name):
