@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT, "libtuber_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS = (["-DTN3_DBG=" + os.environ["TN3_DBG"]] if os.environ.get("TN3_DBG") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("TUBER_AB_VARIANTS"):      # also build the measured-and-rejected GEMM tile variants (tuning runs only; not the product library)
     FLAGS.append("-DTUBER_AB_VARIANTS")
 
