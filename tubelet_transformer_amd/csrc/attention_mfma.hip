@@ -145,14 +145,16 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
             const float alpha = mnew == -INFINITY ? 1.f : __expf(mx - mnew);
             float ls = 0.f;
             bf16x8 pf;
+            bool keep[2][4] = {{true, true, true, true}, {true, true, true, true}};     // two runs of four consecutive keys per lane
+            if (a.pdrop > 0.f) {
+                dropout_keep_run<4>(seed, rbase + k0 + c0 + g * 4, a.thresh, keep[0]);
+                dropout_keep_run<4>(seed, rbase + k0 + c0 + 16 + g * 4, a.thresh, keep[1]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float pe = mnew == -INFINITY ? 0.f : __expf(p[e] - mnew);
                 ls += pe;
-                if (a.pdrop > 0.f) {
-                    const int kk = k0 + c0 + (e >> 2) * 16 + g * 4 + (e & 3);
-                    pe = dropout_keep(seed, rbase + kk, a.thresh) ? pe * inv_keep : 0.f;
-                }
+                if (a.pdrop > 0.f) pe = keep[e >> 2][e & 3] ? pe * inv_keep : 0.f;
                 pf[e] = f2bf(pe);
             }
             l = l * alpha + group_sum(ls);
@@ -259,12 +261,14 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
             for (int t = 0; t < 2; ++t) {
                 const f32x4 s = mfma(frag_rm(ks[im], c0 + t * 16, li, g), qf, f32x4{0.f, 0.f, 0.f, 0.f});
                 const f32x4 dp = mfma(frag_rm(vs[im], c0 + t * 16, li, g), dof, f32x4{0.f, 0.f, 0.f, 0.f});
+                bool keep[4] = {true, true, true, true};
+                if (a.pdrop > 0.f) dropout_keep_run<4>(seed, rbase + k0 + c0 + t * 16 + g * 4, a.thresh, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kl = c0 + t * 16 + g * 4 + r;
                     const float p = msk[im][kl] ? 0.f : __expf(s[r] * a.scale - lse);
                     float dpv = dp[r];
-                    if (a.pdrop > 0.f) dpv = dropout_keep(seed, rbase + k0 + kl, a.thresh) ? dpv * inv_keep : 0.f;
+                    if (a.pdrop > 0.f) dpv = keep[r] ? dpv * inv_keep : 0.f;
                     dsf[t * 4 + r] = f2bf(p * (dpv - delta) * a.scale);
                 }
             }

@@ -145,13 +145,38 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    // keep iff hash >= thresh, thresh = p * 2^32.  The inner hash depends on the seed and the HIGH word of the index only: for the
-    // first 2^32 elements of a tensor (all of them, in this model) it is loop-invariant and hoisted; the branch keeps the stream defined
-    // for larger tensors without paying a second hash per element.
-    const uint32_t hi = (uint32_t)(idx >> 32);
+// One 32-bit hash word decides TWO consecutive elements: element idx takes the 16-bit field (idx & 1) of word(idx >> 1) and is kept iff
+// field >= thresh >> 16 (thresh = p * 2^32, so the drop probability is floor(p * 65536) / 65536: 0.099991 for p = 0.1).  The two
+// 32-bit multiplies of the hash are quarter-rate instructions -- the mask of the class-branch FFN activation alone (34.6 M elements) cost
+// 14 us of VALU time per pass with one word per element -- so every site that owns a run of consecutive elements (GEMM epilogue rows,
+// LayerNorm rows, four keys of a score column) calls dropout_keep_run and hashes once per pair.
+__device__ __forceinline__ uint32_t dropout_word(uint64_t seed, uint64_t pair) {
+    // the inner hash depends on the seed and the HIGH word of the pair index only: for the first 2^33 elements of a tensor (all of them,
+    // in this model) it is loop-invariant and hoisted; the branch keeps the stream defined for larger tensors
+    const uint32_t hi = (uint32_t)(pair >> 32);
     uint32_t inner = hash_u32((uint32_t)seed);
     if (__builtin_expect(hi != 0, 0)) inner = hash_u32(hi + (uint32_t)seed);
-    const uint32_t h = hash_u32((uint32_t)idx ^ inner ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
-    return h >= thresh;
+    return hash_u32((uint32_t)pair ^ inner ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    const uint32_t w = dropout_word(seed, idx >> 1);
+    return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= (thresh >> 16);
+}
+// keep[e] = dropout_keep(seed, idx0 + e, thresh) for a run of N (even) consecutive elements: N / 2 words when the run starts on an even
+// element (every call site of the model: row lengths are even), N words otherwise
+template <int N>
+__device__ __forceinline__ void dropout_keep_run(uint64_t seed, uint64_t idx0, uint32_t thresh, bool (&keep)[N]) {
+    static_assert(N % 2 == 0, "runs of pairs");
+    const uint32_t t16 = thresh >> 16;
+    if ((idx0 & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) {
+            const uint32_t w = dropout_word(seed, (idx0 >> 1) + j);
+            keep[2 * j] = (w & 0xFFFFu) >= t16;
+            keep[2 * j + 1] = (w >> 16) >= t16;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) keep[e] = dropout_keep(seed, idx0 + e, thresh);
+    }
 }

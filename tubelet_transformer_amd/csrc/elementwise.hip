@@ -145,8 +145,10 @@ __global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const bf16x8 v = as_bf16x8(((const uint4*)x)[i]);
         bf16x8 o;
+        bool keep[8];
+        dropout_keep_run<8>(seed, (uint64_t)i * 8, thresh, keep);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = dropout_keep(seed, (uint64_t)i * 8 + e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : (bf16)0.f;
+        for (int e = 0; e < 8; ++e) o[e] = keep[e] ? f2bf(bf2f(v[e]) * inv_keep) : (bf16)0.f;
         ((uint4*)y)[i] = as_uint4(o);
     }
 }

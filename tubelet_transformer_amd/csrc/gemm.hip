@@ -429,9 +429,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
             if (p.drop_thresh) {
                 const uint64_t seed = (p.seed_ptr ? *p.seed_ptr : 0ull) * 0x9E3779B97F4A7C15ull + p.salt;
+                bool keep[NC];
+                dropout_keep_run<NC>(seed, (uint64_t)m * p.N + nb, p.drop_thresh, keep);
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    v[c] = dropout_keep(seed, (uint64_t)m * p.N + nb + c, p.drop_thresh) ? v[c] * p.drop_inv_keep : 0.f;
+                for (int c = 0; c < NC; ++c) v[c] = keep[c] ? v[c] * p.drop_inv_keep : 0.f;
             }
         } else if (EPI == EPI_STATS) {
             if (mok) {                                   // rows beyond M hold a copy of row M-1

@@ -403,10 +403,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
         const bf16x4 a = as_bf16x4(*(const uint2*)(x + base + col));
         bf16x4 r = bf16x4{};
         if (res) r = as_bf16x4(*(const uint2*)(res + base + col));
+        bool keep[4] = {true, true, true, true};
+        if (thresh) dropout_keep_run<4>(seed, (uint64_t)(base + col), thresh, keep);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float xv = bf2f(a[e]);
-            if (thresh) xv = dropout_keep(seed, (uint64_t)(base + col + e), thresh) ? xv * inv_keep : 0.f;   // Dropout(x) + res
+            if (thresh) xv = keep[e] ? xv * inv_keep : 0.f;   // Dropout(x) + res
             v[i * 4 + e] = xv + (res ? bf2f(r[e]) : 0.f);
         }
     }
@@ -482,11 +484,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int i = 0; i < EPL / 4; ++i) {
             const int col = (i * 64 + lane) * 4;
             bf16x4 o, od;
+            bool keep[4] = {true, true, true, true};
+            if (thresh) dropout_keep_run<4>(seed, (uint64_t)(base + col), thresh, keep);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float gxe = rs * (d[i * 4 + e] * gm[i * 4 + e] - s1 - h[i * 4 + e] * s2);
                 o[e] = f2bf(gxe);
-                od[e] = (!thresh || dropout_keep(seed, (uint64_t)(base + col + e), thresh)) ? f2bf(gxe * inv_keep) : (bf16)0.f;
+                od[e] = keep[e] ? f2bf(gxe * inv_keep) : (bf16)0.f;
             }
             if (dx) *(uint2*)(dx + base + col) = as_uint2(o);              // gradient of the residual input
             if (dxd) *(uint2*)(dxd + base + col) = as_uint2(od);           // gradient of x through Dropout
