@@ -15,6 +15,7 @@
 // Dropout regenerates the forward mask from (seed, salt, ((b*H+h)*Lq+q)*Lk+k) like the scalar kernels of attention.hip.
 //
 // Two work splits of the same inner loops (template parameter SPLIT):
+//   (backward: dQ and dK / dV are two bodies of ONE launch, attn_mfma_bwd_kernel)
 //   SPLIT = false: workgroup = 64 rows (16 per wave), the four waves share each staged 64-row tile of the other operand
 //                  (class branch: 384 (b, h) pairs x 6 tiles fill the chip).
 //   SPLIT = true : workgroup = 16 rows; all four waves own the SAME 16 rows and take every fourth tile of the loop, each staging
@@ -206,12 +207,17 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // dQ (and delta = dO . O for the dK/dV kernel): workgroup = 64 queries of one (b, h), loop over key tiles
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
+struct BwdLds {                 // staging of ONE backward body (dQ: K, V, key mask;  dK/dV: Q, dO, lse, delta); the merged launch overlays both
+    static constexpr int NI = SPLIT ? 4 : 1;
+    static constexpr int bytes = 2 * NI * TL * RP * (int)sizeof(bf16) + 2 * NI * TL * (int)sizeof(float);
+};
+template <bool SPLIT>
+__device__ __forceinline__ void attn_mfma_bwd_dq_body(const AttnArgs& a, const int bx, char* sm) {
     constexpr int NI = SPLIT ? 4 : 1;
-    __shared__ __attribute__((aligned(16))) bf16 ks[NI][TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 vs[NI][TL][RP];
-    __shared__ uint8_t msk[NI][TL];
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (SPLIT ? 16 : 64);
+    bf16 (*ks)[TL][RP] = (bf16 (*)[TL][RP])sm;
+    bf16 (*vs)[TL][RP] = (bf16 (*)[TL][RP])(sm + NI * TL * RP * sizeof(bf16));
+    uint8_t (*msk)[TL] = (uint8_t (*)[TL])(sm + 2 * NI * TL * RP * sizeof(bf16));
+    const int b = blockIdx.z, h = blockIdx.y, q0 = bx * (SPLIT ? 16 : 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int im = SPLIT ? wave : 0;
     const int qi = q0 + (SPLIT ? 0 : wave * 16) + li;
@@ -301,13 +307,34 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
 }
 
 // dK, dV: workgroup = 64 keys of one (b, h), loop over query tiles
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
+// delta = dO . O of one query row (the dK / dV body computes it itself since round 4: it used to read what the dQ kernel had written,
+// which made the two launches dependent; now they are ONE launch)
+__device__ __forceinline__ float row_delta(const WaveTile& d, const WaveTile& o) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bf16x8 x = as_bf16x8(d.c[c]), y = as_bf16x8(o.c[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(bf2f(x[e]), bf2f(y[e]), acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ WaveTile row_fetch(const bf16* base, const TokMap& m, int b, int h, int r, int L) {
+    WaveTile t;
+    const uint4* p = (const uint4*)(base + trow(m, min(r, L - 1), b) * m.ld + h * 32);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t.c[c] = p[c];
+    return t;
+}
+// OWN: form delta here (merged launch); !OWN: read what the dQ launch in front of this one has written (the two-launch form)
+template <bool SPLIT, bool OWN = true>
+__device__ __forceinline__ void attn_mfma_bwd_dkv_body(const AttnArgs& a, const int bx, char* sm) {
     constexpr int NI = SPLIT ? 4 : 1;
-    __shared__ __attribute__((aligned(16))) bf16 qs[NI][TL][RP];
-    __shared__ __attribute__((aligned(16))) bf16 dos[NI][TL][RP];
-    __shared__ float lse_s[NI][TL], del_s[NI][TL];
-    const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x * (SPLIT ? 16 : 64);
+    bf16 (*qs)[TL][RP] = (bf16 (*)[TL][RP])sm;
+    bf16 (*dos)[TL][RP] = (bf16 (*)[TL][RP])(sm + NI * TL * RP * sizeof(bf16));
+    float (*lse_s)[TL] = (float (*)[TL])(sm + 2 * NI * TL * RP * sizeof(bf16));
+    float (*del_s)[TL] = (float (*)[TL])(sm + 2 * NI * TL * RP * sizeof(bf16) + NI * TL * sizeof(float));
+    const int b = blockIdx.z, h = blockIdx.y, kb = bx * (SPLIT ? 16 : 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int im = SPLIT ? wave : 0;
     const int ki = kb + (SPLIT ? 0 : wave * 16) + li;
@@ -323,31 +350,45 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
     const int qfirst = SPLIT ? wave * TL : 0, qstep = SPLIT ? 4 * TL : TL;
     const int srow = SPLIT ? lane : (int)threadIdx.x;      // which row of the tile this thread carries lse / delta for
     uint4 qr, dr;
-    WaveTile qw, dw;
-    float lr = 0.f, er = 0.f;
-    if (SPLIT) { if (qfirst < a.Lq) { qw = wave_fetch(a.Q, a.mq, b, h, qfirst, a.Lq); dw = wave_fetch(a.dO, a.mdo, b, h, qfirst, a.Lq); } }
-    else { qr = tile_fetch(a.Q, a.mq, b, h, 0, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, 0, a.Lq); }
-    if (srow < TL && qfirst + srow < a.Lq) { lr = a.lse[bh * a.Lq + qfirst + srow]; er = a.delta[bh * a.Lq + qfirst + srow]; }
+    WaveTile qw, dw, ow;                                   // SPLIT: lane = row of the wave's tile: q, dO and O rows (delta = dO . O at park time)
+    WaveTile dro, oro;                                     // !SPLIT: threads 0 .. 63 carry one row of dO and O each for the same purpose
+    float lr = 0.f;
+    if (SPLIT) {
+        if (qfirst < a.Lq) {
+            qw = wave_fetch(a.Q, a.mq, b, h, qfirst, a.Lq); dw = wave_fetch(a.dO, a.mdo, b, h, qfirst, a.Lq);
+            ow = wave_fetch(a.O, a.mo, b, h, qfirst, a.Lq);
+        }
+    } else {
+        qr = tile_fetch(a.Q, a.mq, b, h, 0, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, 0, a.Lq);
+        if (OWN && srow < TL) { dro = row_fetch(a.dO, a.mdo, b, h, srow, a.Lq); oro = row_fetch(a.O, a.mo, b, h, srow, a.Lq); }
+    }
+    float er = 0.f;
+    if (srow < TL && qfirst + srow < a.Lq) { lr = a.lse[bh * a.Lq + qfirst + srow]; if (!OWN) er = a.delta[bh * a.Lq + qfirst + srow]; }
     for (int q0 = qfirst; q0 < a.Lq; q0 += qstep) {
         if (SPLIT) {
             wave_park(qs[im], qw);
             wave_park(dos[im], dw);
-            lse_s[im][lane] = lr; del_s[im][lane] = er;
+            lse_s[im][lane] = lr; del_s[im][lane] = row_delta(dw, ow);         // (rows beyond Lq are zero-filled: delta 0)
             if (q0 + qstep < a.Lq) {
                 qw = wave_fetch(a.Q, a.mq, b, h, q0 + qstep, a.Lq); dw = wave_fetch(a.dO, a.mdo, b, h, q0 + qstep, a.Lq);
+                ow = wave_fetch(a.O, a.mo, b, h, q0 + qstep, a.Lq);
                 const int qn = q0 + qstep + lane;
-                lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f;
+                lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
         } else {
             __syncthreads();
             park_rm(qs[0], qr);
             park_rm(dos[0], dr);
-            if (threadIdx.x < TL) { lse_s[0][threadIdx.x] = lr; del_s[0][threadIdx.x] = er; }
+            if (threadIdx.x < TL) { lse_s[0][threadIdx.x] = lr; del_s[0][threadIdx.x] = !OWN ? er : q0 + (int)threadIdx.x < a.Lq ? row_delta(dro, oro) : 0.f; }
             if (q0 + TL < a.Lq) {
                 qr = tile_fetch(a.Q, a.mq, b, h, q0 + TL, a.Lq); dr = tile_fetch(a.dO, a.mdo, b, h, q0 + TL, a.Lq);
                 const int qn = q0 + TL + threadIdx.x;
-                if (threadIdx.x < TL) { lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f; er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f; }
+                if (threadIdx.x < TL) {
+                    lr = qn < a.Lq ? a.lse[bh * a.Lq + qn] : 0.f;
+                    if (OWN) { dro = row_fetch(a.dO, a.mdo, b, h, qn, a.Lq); oro = row_fetch(a.O, a.mo, b, h, qn, a.Lq); }
+                    else er = qn < a.Lq ? a.delta[bh * a.Lq + qn] : 0.f;
+                }
             }
             __syncthreads();
         }
@@ -409,6 +450,28 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+// dQ and dK / dV of one attention in ONE launch: workgroups [0, nq) are query tiles, [nq, gridDim.x) key tiles.  The two halves share no
+// data (each forms delta itself), so they fill the chip side by side: the encoder's backward was two dependent launches of 352
+// workgroups, 11 + 13 us, twelve times per step.
+template <bool SQ, bool SK>
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(AttnArgs a, int nq) {
+    constexpr int BYTES = BwdLds<SQ>::bytes > BwdLds<SK>::bytes ? BwdLds<SQ>::bytes : BwdLds<SK>::bytes;
+    __shared__ __attribute__((aligned(16))) char sm[BYTES];
+    if ((int)blockIdx.x < nq) attn_mfma_bwd_dq_body<SQ>(a, blockIdx.x, sm);
+    else attn_mfma_bwd_dkv_body<SK>(a, (int)blockIdx.x - nq, sm);
+}
+
+// the two bodies as launches of their own: the 64-row form on grids that fill the chip several times over (class branch: 2 304 workgroups
+// each) -- there the merged kernel's register budget (the larger of the two bodies) costs occupancy: 154.7 vs 127.3 us per backward
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char sm[BwdLds<false>::bytes];
+    attn_mfma_bwd_dq_body<false>(a, blockIdx.x, sm);
+}
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char sm[BwdLds<false>::bytes];
+    attn_mfma_bwd_dkv_body<false, false>(a, blockIdx.x, sm);
+}
+
 }  // namespace
 
 // entry points used by tuber_attn_fwd / tuber_attn_bwd (attention.hip) for Lq >= 32; `args` is an AttnArgs.
@@ -424,8 +487,14 @@ extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_fwd_launch
 }
 extern "C" __attribute__((visibility("hidden"))) void tuber_attn_mfma_bwd_launch(const void* args, hipStream_t stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    if (attn_split(a.Lq, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<true>, dim3(ceil_div(a.Lq, 16), a.H, a.B), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel<false>, dim3(ceil_div(a.Lq, 64), a.H, a.B), dim3(256), 0, stream, a);
-    if (attn_split(a.Lk, a.H, a.B)) hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel<true>, dim3(ceil_div(a.Lk, 16), a.H, a.B), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel<false>, dim3(ceil_div(a.Lk, 64), a.H, a.B), dim3(256), 0, stream, a);
+    const bool sq = attn_split(a.Lq, a.H, a.B), sk = attn_split(a.Lk, a.H, a.B);
+    const int nq = ceil_div(a.Lq, sq ? 16 : 64), nk = ceil_div(a.Lk, sk ? 16 : 64);
+    const dim3 grid(nq + nk, a.H, a.B), block(256);
+    if (sq && sk) hipLaunchKernelGGL((attn_mfma_bwd_kernel<true, true>), grid, block, 0, stream, a, nq);
+    else if (sq) hipLaunchKernelGGL((attn_mfma_bwd_kernel<true, false>), grid, block, 0, stream, a, nq);
+    else if (sk) hipLaunchKernelGGL((attn_mfma_bwd_kernel<false, true>), grid, block, 0, stream, a, nq);
+    else {
+        hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(nq, a.H, a.B), block, 0, stream, a);
+        hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel, dim3(nk, a.H, a.B), block, 0, stream, a);
+    }
 }
