@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn2_kernel(GemmTN p) { gemm_tn2_b
 // until the optimizer, so they are queued and launched together -- one launch gap instead of 2-3 per bottleneck, and for the
 // short-M layer3 / layer4 shapes (512 workgroups of a few 64-row steps each) enough independent workgroups to fill 256 CUs.
 // The argument blocks travel BY VALUE in the kernel argument segment (a captured hipGraph bakes them in like any other launch).
-#define TN_GROUP_MAX 8
+#define TN_GROUP_MAX 16
 struct GemmTNGroup { GemmTN p[TN_GROUP_MAX]; int begin[TN_GROUP_MAX + 1]; int n; };
 __global__ __launch_bounds__(256, 3) void gemm_tn2_group_kernel(GemmTNGroup g) {
     int e = 0;

@@ -35,7 +35,7 @@ class TnArgs(ctypes.Structure):
 
 class WgradQueue:
     """Weight-gradient GEMMs feed nothing until the optimizer: the backbone and the tape queue them here (operand tensors kept
-    alive) and ``flush`` launches up to 8 of them in ONE tuber_gemm_tn_group launch -- fewer launch gaps, and for the short-M
+    alive) and ``flush`` launches up to tuber_gemm_tn_group_max() = 16 of them in ONE tuber_gemm_tn_group launch -- fewer launch gaps, and for the short-M
     layer3 / layer4 / transformer shapes enough independent workgroups in flight to fill 256 CUs.  Flushed before every deferred
     second-stage reduction (DeferredReduce.flush), so gradient windows are complete wherever the old per-call launches had them."""
 
