@@ -11,13 +11,19 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT, "libtuber_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = (["-DTN3_DBG=" + os.environ["TN3_DBG"]] if os.environ.get("TN3_DBG") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("TUBER_AB_VARIANTS"):      # also build the measured-and-rejected GEMM tile variants (tuning runs only; not the product library)
     FLAGS.append("-DTUBER_AB_VARIANTS")
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def _stamp():
+    """compile flags + compiler path: part of every object's staleness key (an object built with other flags is stale
+    even when its source is older)"""
+    return " ".join([HIPCC] + FLAGS)
 
 
 def _stale(target, deps):
@@ -29,6 +35,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OUT, exist_ok=True)
+    stamp_file = os.path.join(OUT, "FLAGS.stamp")
+    if not os.path.exists(stamp_file) or open(stamp_file).read() != _stamp():
+        force = True                                  # objects of another flag set (or of unknown provenance): rebuild all of them
     hdrs = glob.glob(os.path.join(CSRC, "*.h"))
     objs, jobs = [], []
     for src in sources():
@@ -46,6 +55,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
+    with open(stamp_file, "w") as f:
+        f.write(_stamp())
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

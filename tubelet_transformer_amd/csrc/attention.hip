@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 32; ++d) { q[d] *= a.scale; o[d] = 0.f; }
     float mx = -INFINITY, l = 0.f;
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     if (active && kl == 0) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
 #pragma unroll
     for (int d = 0; d < 32; ++d) dq[d] = 0.f;
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     for (int k0 = 0; k0 < a.Lk; k0 += KT) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     load_row32(a.V + tok_row(a.mv, kc, b) * a.mv.ld + h * 32, v);
 #pragma unroll
     for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     for (int q0 = 0; q0 < a.Lq; q0 += KT) {
         __syncthreads();
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a) {
     float l = 0.f;
 #pragma unroll
     for (int d = 0; d < 32; ++d) o[d] = 0.f;
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
 #pragma unroll
     for (int k = 0; k < SMALL_L; ++k) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a) {
     if (t >= (long)a.B * a.H * Lm) return;
     const int i = (int)(t % Lm); const long bh = t / Lm;
     const int h = (int)(bh % a.H), b = (int)(bh / a.H);
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     if (i < a.Lq) {
         float q[32], dov[32], ov[32], dq[32];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__
         }
     }
     float l = 0.f, p[WT_MAX], keep[WT_MAX];
-    const float inv_keep = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(pdrop);
 #pragma unroll
     for (int t = 0; t < WT_MAX; ++t)
         if (t < T) { p[t] = __expf(s[t] - mx); l += p[t]; }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
     const bool qok = qi < a.Lq;
     const int qc = qok ? qi : a.Lq - 1;
     const bf16x8 qf = as_bf16x8(*(const uint4*)(a.Q + trow(a.mq, qc, b) * a.mq.ld + h * 32 + g * 8));
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -235,7 +235,7 @@ __device__ __forceinline__ void attn_mfma_bwd_dq_body(const AttnArgs& a, const i
     }
     const float lse = a.lse[((long)b * a.H + h) * a.Lq + qc];
     if (qok && g == 0 && (!SPLIT || wave == 0)) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
@@ -343,7 +343,7 @@ __device__ __forceinline__ void attn_mfma_bwd_dkv_body(const AttnArgs& a, const 
     const bool kdead = !kin || (a.kpm && a.kpm[(long)b * a.Lk + kc]);
     const bf16x8 kf = as_bf16x8(*(const uint4*)(a.K + trow(a.mk, kc, b) * a.mk.ld + h * 32 + g * 8));
     const bf16x8 vf = as_bf16x8(*(const uint4*)(a.V + trow(a.mv, kc, b) * a.mv.ld + h * 32 + g * 8));
-    const float inv_keep = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+    const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eseed(a.seed_ptr, a.salt) : 0ull;
     const uint64_t bh = (uint64_t)(b * a.H + h);
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};

@@ -98,6 +98,9 @@ int load_api() {
 extern "C" {
 
 // RCCL version code (e.g. 22606) or a negative error when librccl cannot be loaded.
+// the return code tuber_comm_init_timeout uses for "a rank never reached the bootstrap" (callers compare against this, not a literal)
+int tuber_comm_etimedout(void) { return TUBER_ETIMEDOUT; }
+
 int tuber_comm_version(void) {
     if (load_api() != TUBER_OK) return TUBER_ENOLIB;
     int v = 0;

@@ -158,6 +158,12 @@ __device__ __forceinline__ uint32_t dropout_word(uint64_t seed, uint64_t pair) {
     if (__builtin_expect(hi != 0, 0)) inner = hash_u32(hi + (uint32_t)seed);
     return hash_u32((uint32_t)pair ^ inner ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
 }
+// the scale of the kept elements, from the QUANTISED drop probability floor(p * 65536) / 65536 the masks realise (so the expectation of
+// dropout(x) is exactly x, and a p below 2^-16 -- which drops nothing -- scales by 1)
+__host__ __device__ __forceinline__ float dropout_inv_keep(float p) {
+    const uint32_t t16 = (uint32_t)((double)p * 4294967296.0) >> 16;
+    return t16 ? 65536.f / (float)(65536u - t16) : 1.f;
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
     const uint32_t w = dropout_word(seed, idx >> 1);
     return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= (thresh >> 16);

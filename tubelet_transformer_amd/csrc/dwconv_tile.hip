@@ -531,13 +531,6 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
     const bf16* in2_n = a.xu + (long)n * g.T * plane_elems;
     uint2 regs[NLD], regs_a[NLD], regs_b[NLD], regx[NLD], regx_a[NLD], regx_b[NLD];
     auto fetch = [&](int t, uint2 (&rg)[NLD], uint2 (&rx)[NLD]) {          // unconditional loads (see dwconv_tile_body)
-#if defined(DW_DBG) && DW_DBG == 4      /* timing ablation: no plane loads */
-        if (g.C > 0) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) { rg[i] = make_uint2(t, i); rx[i] = make_uint2(i, t); }
-            return;
-        }
-#endif
         const bool tok = t >= 0 && t < g.T;
         const bf16* p = in_n + (long)(tok ? t : 0) * plane_elems;
         const bf16* p2 = in2_n + (long)(tok ? t : 0) * plane_elems;
@@ -547,9 +540,6 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
         for (int i = 0; i < NLD; ++i) rx[i] = *(const uint2*)(p2 + s_off[i]);
     };
     auto park = [&](int t, const uint2 (&rg)[NLD], const uint2 (&rx)[NLD]) {      // g = cA*dzu + cB*xu + cC, fp32, zero outside the volume
-#if defined(DW_DBG) && DW_DBG == 2      /* timing ablation: planes are fetched but not parked */
-        if (g.C > 0) return;
-#endif
         const bool tok = t >= 0 && t < g.T;
         float* dst = smem + ((t + 3) % 3) * PLANE;
         const float* coef = smem + 3 * PLANE + 27 * 64 + (tid & 15) * 4;       // this thread's channel quad (the same for all its slots)
@@ -694,9 +684,6 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
         // one temporal tap per pass (a real loop: unrolled over dt the compiler keeps far more operand reads in flight than 256 VGPRs
         // hold -- 255 spilled).  The weight-gradient accumulators are indexed by the tap, so a pass collects its 9 taps in a
         // zero-initialised group w9 and folds it into the persistent group of its dt: taps (2 - dt) * 9 + (8 - k9).
-#if defined(DW_DBG) && DW_DBG == 1      /* timing ablation: no tap loop */
-        if (a.g.C < 0)
-#endif
 #pragma unroll 1
         for (int dt = 0; dt < 3; ++dt) {
             const float* pl = smem + ((t + dt - 1 + 3) % 3) * PLANE;
@@ -731,9 +718,6 @@ __global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel(TileArgs a) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) { const f32x2 g2 = wacc[18 + k] + w9[k]; wacc[18 + k] = wacc[9 + k]; wacc[9 + k] = wacc[k]; wacc[k] = g2; }
         }
-#if defined(DW_DBG) && DW_DBG == 3      /* timing ablation: no output stores */
-        if (g.C < 0)
-#endif
         if (row_ok) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

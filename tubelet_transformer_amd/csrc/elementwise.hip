@@ -323,7 +323,7 @@ int tuber_axpby(const void* a, const void* b, void* out, long n, float alpha, fl
 int tuber_dropout(const void* x, void* y, long n, float p, const void* seed_ptr, unsigned long long salt, hipStream_t stream) {
     if ((n & 7) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid1(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), (const uint64_t*)seed_ptr, (uint64_t)salt);
+                       (uint32_t)((double)p * 4294967296.0), dropout_inv_keep(p), (const uint64_t*)seed_ptr, (uint64_t)salt);
     TUBER_RETURN_LAUNCH();
 }
 int tuber_sigmoid_fwd(const float* x, float* y, long n, hipStream_t stream) {

@@ -677,7 +677,7 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     GemmNT p;
     p.alpha = alpha;
     p.A2 = (const bf16*)A2; p.lda2 = lda2; p.a_coef2 = a_coef2;
-    p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_inv_keep = 1.f / (1.f - drop_p);
+    p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_inv_keep = dropout_inv_keep(drop_p);
     p.seed_ptr = (const uint64_t*)seed_ptr; p.salt = (uint64_t)salt;
     p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.a_scale = a_scale; p.a_shift = a_shift;
@@ -1247,13 +1247,6 @@ __device__ __forceinline__ bf16x8 tn3_frag(const bf16* img, int m0, int col0, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-#ifdef TN3_DBG
-__device__ unsigned long long tn3_ts[8192 * 8];
-#define TN3_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tn3_ts[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-extern "C" int tuber_tn3_dbg_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tn3_ts), sizeof(unsigned long long) * 8192 * 8); }
-#else
-#define TN3_STAMP(k)
-#endif
 template <int AMODE>
 __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblocks) {
     constexpr int T = 128, TW = 64, FT = 4;             // wave tile 64 x 64 = 4 x 4 MFMA blocks
@@ -1306,13 +1299,7 @@ __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblo
             const bf16* gq = gb0 + so * p.ldg;
             const bf16* aq = ab0 + so * p.lda;
 #pragma unroll
-#if defined(TN3_DBG) && TN3_DBG == 2     /* timing only: the A operand is fetched for the first steps only (stale registers afterwards) */
-            for (int h = 0; h < 4; ++h) { xg[h] = *(const uint4*)(gq + h * g16); if (ms < m_begin + 256) xa[h] = *(const uint4*)(aq + h * a16); ok[h] = true; }
-#elif defined(TN3_DBG) && TN3_DBG == 3   /* timing only: no operand fetches after the first steps */
-            for (int h = 0; h < 4; ++h) { if (ms < m_begin + 256) { xg[h] = *(const uint4*)(gq + h * g16); xa[h] = *(const uint4*)(aq + h * a16); } ok[h] = true; }
-#else
             for (int h = 0; h < 4; ++h) { xg[h] = *(const uint4*)(gq + h * g16); xa[h] = *(const uint4*)(aq + h * a16); ok[h] = true; }
-#endif
             return;
         }
 #pragma unroll
@@ -1354,19 +1341,15 @@ __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblo
         for (int j = 0; j < FT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int buf = 0;
-    TN3_STAMP(0);
 #pragma unroll
     for (int j = 0; j < GS; ++j)
         if (m_begin + 64 * j < m_end) load_step(m_begin + 64 * j, rg[j], ra[j], rok[j]);
-    TN3_STAMP(1);
     for (int ms = m_begin; ms < m_end; ms += 64 * GS) {
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
             if (ms + 64 * j >= m_end) continue;
             store_step(buf, rg[j], ra[j], rok[j]);
-            if (ms == m_begin && j == 0) TN3_STAMP(2);
-            if (ms == m_begin + 64 * GS * 4 && j == 0) TN3_STAMP(3);
-            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
+            if (ms == m_begin && j == 0)            if (ms == m_begin + 64 * GS * 4 && j == 0)            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
             __syncthreads();
             const bf16* gi = smem[buf][0];
             const bf16* ai = smem[buf][1];
@@ -1394,7 +1377,6 @@ __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblo
     // D[row n][col k]: lane holds k = wm*64 + i*16 + li, n = wn*64 + j*16 + g*4 + r.  The tile leaves through LDS in two halves of
     // 64 n-rows (16-byte stores, 512 contiguous bytes per output row)
     float* P = p.P + (long)slab * p.N * p.K;
-    TN3_STAMP(4);
     __syncthreads();
     float* ot = (float*)&smem[0][0][0];                 // [64 n][128 k + 4] fp32 = 33 KB of the 64 KB staging area
     if (do_bias) {
@@ -1432,7 +1414,6 @@ __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblo
             }
         }
     }
-    TN3_STAMP(5);
 }
 
 template <int AMODE>

@@ -42,6 +42,7 @@ DOC = {
     "tuber_comm_version": "RCCL bound at run time (dlopen librccl.so.1: the instance the host process already loaded, else ROCm's): its version code, "
                           "or < 0 when it cannot be loaded. Replaces the NCCL process group the reference's DistributedDataParallel wrapper uses "
                           "(utils/model_utils.py:43-52, pipelines/launch.py:44-49).",
+    "tuber_comm_etimedout": "the (negative) return code of tuber_comm_init_timeout when a rank never reached the bootstrap (fatal for the job).",
     "tuber_comm_last_error": "message of the last failing tuber_comm_* call.",
     "tuber_comm_unique_id": "ncclGetUniqueId: rank 0 fills the 128-byte rendez-vous id (HOST memory) that every rank hands to tuber_comm_init "
                             "(shipped over any side channel: torch.distributed store, MPI, a file).",

@@ -788,7 +788,7 @@ int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, cons
     if (ldy < E || (ldy & 3) || p < 0.f || p >= 1.f) return TUBER_EINVAL;
     dim3 grid(ceil_div(M, 4)), block(256);
     const uint32_t th = (uint32_t)((double)p * 4294967296.0);
-    const float ik = 1.f / (1.f - p);
+    const float ik = dropout_inv_keep(p);
 #define LNF(EPL) hipLaunchKernelGGL(layernorm_fwd_kernel<EPL>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, \
                                     (bf16*)y, ldy, (bf16*)xhat, rstd, M, eps, th, ik, (const uint64_t*)seed_ptr, (uint64_t)salt)
     if (E == 256) LNF(4);
@@ -813,7 +813,7 @@ int tuber_layernorm_bwd(const void* dy, long lddy, const void* xhat, const float
     rpb = ceil_div(rpb, 4) * 4;
     dim3 grid(nb), block(256);
     const uint32_t th = (uint32_t)((double)p * 4294967296.0);
-    const float ik = 1.f / (1.f - p);
+    const float ik = dropout_inv_keep(p);
 #define LNB(EPL) hipLaunchKernelGGL(layernorm_bwd_kernel<EPL>, grid, block, 0, stream, (const bf16*)dy, lddy, (const bf16*)xhat, rstd, gamma, \
                                     (bf16*)dx, (bf16*)dxd, partial, M, rpb, th, ik, (const uint64_t*)seed_ptr, (uint64_t)salt)
     if (E == 256) LNB(4);

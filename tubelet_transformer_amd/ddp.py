@@ -79,7 +79,7 @@ class RcclComm:
         # deadline on the bootstrap (TUBER_RCCL_INIT_TIMEOUT_S, default 120 s; 0 = none): a missing rank is an error message, not a hang
         timeout_ms = int(float(os.environ.get("TUBER_RCCL_INIT_TIMEOUT_S", "120")) * 1000) if world > 1 else 0
         rc = self.lib.tuber_comm_init_timeout(ctypes.addressof(uid), world, rank, idx, timeout_ms, ctypes.addressof(comm))
-        if rc == -3:        # TUBER_ETIMEDOUT: a rank never reached the bootstrap.  Fatal for the job: a helper thread is still
+        if rc == self.lib.tuber_comm_etimedout():        # TUBER_ETIMEDOUT (exported by the library): a rank never reached the bootstrap.  Fatal for the job: a helper thread is still
             raise RcclBootstrapTimeout(self.lib.tuber_comm_last_error().decode())      # parked inside RCCL on this device
         self._check(rc, "tuber_comm_init")
         self.comm = comm.value

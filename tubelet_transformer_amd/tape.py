@@ -140,7 +140,8 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
     if not (wreq or breq or xreq):
         return y
     tp.mark(y)
-    inv_keep = 1.0 / (1.0 - p)
+    t16 = int(p * 4294967296.0) >> 16                    # the quantised drop probability the kernels realise (common.h: dropout_inv_keep)
+    inv_keep = 65536.0 / (65536 - t16) if t16 else 1.0
     if relu:
         tp.mask[id(y)] = inv_keep
 

@@ -418,17 +418,19 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
         if rank == 0:
             meters.update(loss, loss_dict, len(targets))
         # non-finite loss (reference :195-198 checks the rank-reduced loss on every rank, every iteration): a device-side flag updated
-        # on EVERY rank every step, MAX-reduced over the ranks at the print interval and read on every rank, so that all ranks stop
-        # together instead of rank 0 raising while the others wait in the next gradient all-reduce
-        nonfinite = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1) if nonfinite is None else \
-            torch.maximum(nonfinite, (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1))
-        if idx % print_freq == 0 or idx + 1 == n_iter:
-            if world > 1:
-                _dist.all_reduce(nonfinite, op=_dist.ReduceOp.MAX)
-            if int(nonfinite.item()):                          # the only host sync, every print_freq iterations
-                print("Loss is non-finite on some rank, stopping training")
-                print({k: float(v.detach()) if torch.is_tensor(v) else v for k, v in loss_dict.items()})
-                raise FloatingPointError("non-finite loss at epoch %d, iteration <= %d (rank %d of %d)" % (epoch, idx, rank, world))
+        # on EVERY rank every step, MAX-reduced over the ranks and read on every rank, so that all ranks stop together instead of
+        # rank 0 raising while the others wait in the next gradient all-reduce.  The collective is issued at
+        # iterations every rank reaches by construction (idx % print_freq == 0 -- the same idx on every rank as long as the
+        # loaders have one length, which the gradient all-reduce needs anyway) and once more after the loop; NOT at
+        # ``idx + 1 == n_iter``, which would pair with nothing on a rank whose loader is longer.  Up to print_freq
+        # optimizer steps with a non-finite loss may have been applied when this fires (the reference stops before the first):
+        # resume from the last checkpoint, not from the live weights.
+        bad = ~torch.isfinite(loss.detach()).reshape(1)
+        if nonfinite is None:
+            nonfinite = torch.zeros(2, dtype=torch.float32, device=bad.device)       # [flag, first offending iteration + 1]
+        nonfinite = torch.where((nonfinite[:1] == 0) & bad, torch.tensor([1.0, idx + 1.0], device=bad.device), nonfinite)
+        if idx % print_freq == 0:
+            _raise_if_nonfinite(nonfinite, loss_dict, epoch, idx, rank, world, _dist)
         if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
             avg = meters.averages()
             lr = optimizer.param_groups[-1]["lr"]
@@ -446,4 +448,19 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
                 writer.add_scalar("train/loss_ce", avg["loss_ce"], it)
                 writer.add_scalar("train/loss_ce_b", avg["loss_ce_b"], it)
         end = time.time()
+    if nonfinite is not None:
+        _raise_if_nonfinite(nonfinite, loss_dict, epoch, n_iter - 1, rank, world, _dist)
     return loss
+
+
+def _raise_if_nonfinite(state, loss_dict, epoch, idx, rank, world, _dist):
+    """MAX-reduce the [flag, iteration + 1] pair over the ranks and stop every rank together (the only host sync of the loop)."""
+    if world > 1:
+        _dist.all_reduce(state, op=_dist.ReduceOp.MAX)
+    flag, first = state.tolist()
+    if flag:
+        losses = {k: float(v.detach()) if torch.is_tensor(v) else v for k, v in loss_dict.items()}
+        print("Loss is non-finite on some rank, stopping training")
+        print(losses)
+        raise FloatingPointError("non-finite loss first seen at epoch %d, iteration %d (checked at iteration %d, rank %d of %d; this rank's "
+                                 "last loss terms: %s); the weights may already hold non-finite updates" % (epoch, int(first) - 1, idx, rank, world, losses))
