@@ -38,6 +38,20 @@ TRAIN_CASES = {
 }
 
 
+# round 5: non-degenerate ("spread") train fixtures -- synth.SPREAD_GAINS + residual_gain 0.05 + structured clips; the clip / target
+# seeds are chosen by spread_search below so that the reference's Hungarian assignment is as decidable under bf16 noise as it gets
+SPREAD_TRAIN_CASES = {
+    "csn152_ava21_avg_train_spread": ("TubeR_CSN152_AVA21.yaml", [(64, 96), (64, 96)]),
+    "csn50_ava21_decode_train_spread": ("TubeR_CSN50_AVA21.yaml", [(64, 64), (64, 64)]),
+    "csn152_jhmdb_train_spread": ("Tuber_CSN152_JHMDB.yaml", [(64, 64), (64, 64)]),
+}
+SPREAD_EVAL_CASES = {
+    "csn152_ava21_avg_eval_spread": ("TubeR_CSN152_AVA21.yaml", [(64, 96), (64, 96)]),
+}
+SPREAD_RESIDUAL_GAIN = 0.05
+SPREAD_BOXES_PER_CLIP = [1, 2]
+
+
 def log(*a):
     s = " ".join(str(x) for x in a)
     print(s)
@@ -62,13 +76,16 @@ def make_clips(sizes, seed):
     return synth.synthetic_clips(len(sizes), 32, 0, 0, seed=seed, sizes=sizes)
 
 
-def eval_case(name, yaml_name, sizes):
+def eval_case(name, yaml_name, sizes, spread=False):
     rcfg = ref_import.ref_cfg(yaml_name)
     mycfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
     model, _, post = ref_import.build_reference(rcfg)
-    synth.load_name_hashed(model)
+    if spread:
+        synth.load_name_hashed(model, residual_gain=SPREAD_RESIDUAL_GAIN, spread=True)
+    else:
+        synth.load_name_hashed(model)
     model.eval()
-    clips = make_clips(sizes, seed=1234)
+    clips = synth.structured_clips(len(sizes), 32, sizes[0][0], sizes[0][1], seed=1234) if spread else make_clips(sizes, seed=1234)
     with torch.no_grad():
         ref = model(clips)
         state = {k: v.clone() for k, v in model.state_dict().items()}
@@ -76,7 +93,7 @@ def eval_case(name, yaml_name, sizes):
     r, m = flat_outputs(ref), flat_outputs(mine)
     d = maxdiff(r, m)
     log("[eval ] %-32s oracle-vs-reference max|diff| = %.3e" % (name, d))
-    assert d <= 1e-5, name
+    assert d <= (5e-5 if spread else 1e-5), name
     # post-processing on the same outputs
     tsz = torch.tensor([[h * 4, w * 4] for h, w in sizes], dtype=torch.int64)
     pr = post["bbox"](ref, tsz)
@@ -85,23 +102,64 @@ def eval_case(name, yaml_name, sizes):
     log("        %-32s post-process max rel diff (boxes are in pixels) = %.3e" % ("", dp))
     assert dp <= 1e-5
     r.update({"post.scores": pr[0], "post.boxes": pr[1], "post.out_b": pr[2], "post.target_sizes": tsz.numpy()})
+    if spread and mycfg.CONFIG.DATA.DATASET_NAME == "ava":
+        pb = ref["pred_logits_b"].softmax(-1)[..., 1]
+        b = ref["pred_boxes"]
+        log("        %-32s eval spread: p_b in [%.3f, %.3f] (%d of %d queries above the 0.8 gate), box spread (clip 0) %s" % (
+            "", float(pb.min()), float(pb.max()), int((pb > 0.8).sum()), pb.numel(), (b.max(1).values - b.min(1).values)[0].numpy().round(3)))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **r)
 
 
-def train_case(name, yaml_name, sizes):
+def spread_search(mycfg, state, sizes, ava, clip_seeds=(99, 100, 101, 102), target_seeds=range(200)):
+    """Choose (clip seed, target seed) for a spread fixture: the pair for which the fp32 assignment of every (layer, clip) problem is
+    the most decidable under the noise of a bf16-ROUNDED execution of the oracle (tests/parity_util.assignment_margin: worst ratio
+    gap / realised gap perturbation over all alternatives of all problems), among those the rounded oracle assigns like fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_util import run_oracle, matcher_problems, assignment_margin
+    best = None
+    for cs in clip_seeds:
+        clips = synth.structured_clips(len(sizes), 32, sizes[0][0], sizes[0][1], seed=cs)
+        o32, _ = run_oracle(mycfg, state, clips, train=True, rounded=False)
+        obf, _ = run_oracle(mycfg, state, clips, train=True, rounded=True)
+        for ts in target_seeds:
+            tg = synth.synthetic_targets(len(sizes), "ava" if ava else "jhmdb", mycfg.CONFIG.DATA.NUM_CLASSES, seed=ts, hw=sizes[0],
+                                         boxes_per_clip=SPREAD_BOXES_PER_CLIP if ava else None)
+            p32, pbf = matcher_problems(mycfg, o32, tg), matcher_problems(mycfg, obf, tg)
+            ratios, same = [], True
+            for la, lb in zip(p32, pbf):
+                for (C1, a1), (C2, a2) in zip(la, lb):
+                    ratios.append(assignment_margin(C1, a1, C2)[1])
+                    same = same and np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1])
+            if same and (best is None or min(ratios) > best[0]):
+                best = (min(ratios), cs, ts, sorted(ratios))
+    return best
+
+
+def train_case(name, yaml_name, sizes, spread=False):
     rcfg = ref_import.ref_cfg(yaml_name)
     mycfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
     # the published JHMDB yaml ships EVAL_ONLY: True; keep it (it only affects the AVA loss)
     ava = mycfg.CONFIG.DATA.DATASET_NAME == "ava"
     model, crit, _ = ref_import.build_reference(rcfg)
-    synth.load_name_hashed(model)
+    if spread:
+        synth.load_name_hashed(model, residual_gain=SPREAD_RESIDUAL_GAIN, spread=True)
+    else:
+        synth.load_name_hashed(model)
     ref_import.zero_dropout(model)
     model.train()
     crit.train()
     state0 = {k: v.clone() for k, v in model.state_dict().items()}
-    clips = make_clips(sizes, seed=99)
-    targets = synth.synthetic_targets(len(sizes), "ava" if ava else "jhmdb", mycfg.CONFIG.DATA.NUM_CLASSES,
-                                      seed=7, hw=sizes[0], boxes_per_clip=[2, 3] if ava else None)
+    if spread:
+        worst, clip_seed, target_seed, ratios = spread_search(mycfg, state0, sizes, ava)
+        log("[spread] %-30s chosen clip seed %d, target seed %d: worst decidability ratio (gap / bf16-rounded-oracle perturbation) %.2f; "
+            "per problem %s" % (name, clip_seed, target_seed, worst, " ".join("%.1f" % r for r in ratios)))
+        clips = synth.structured_clips(len(sizes), 32, sizes[0][0], sizes[0][1], seed=clip_seed)
+        targets = synth.synthetic_targets(len(sizes), "ava" if ava else "jhmdb", mycfg.CONFIG.DATA.NUM_CLASSES,
+                                          seed=target_seed, hw=sizes[0], boxes_per_clip=SPREAD_BOXES_PER_CLIP if ava else None)
+    else:
+        clips = make_clips(sizes, seed=99)
+        targets = synth.synthetic_targets(len(sizes), "ava" if ava else "jhmdb", mycfg.CONFIG.DATA.NUM_CLASSES,
+                                          seed=7, hw=sizes[0], boxes_per_clip=[2, 3] if ava else None)
     out = model(clips)
     ld = crit(out, targets)
     wd = crit.weight_dict
@@ -121,14 +179,15 @@ def train_case(name, yaml_name, sizes):
     d_out = maxdiff(flat_outputs(out), flat_outputs(mo))
     d_loss = max(abs(ref_losses[k] - float(mld[k])) for k in ref_losses)
     log("[train] %-32s outputs %.3e  losses %.3e  total %.6f vs %.6f" % (name, d_out, d_loss, float(loss), float(mloss)))
-    assert d_out <= 1e-5 and d_loss <= 1e-4 * max(1.0, abs(float(loss)))
+    # spread fixtures: head gains x2 / x3 and sharper attention scale the fp32 summation-order noise of the outputs with them
+    assert d_out <= (5e-5 if spread else 1e-5) and d_loss <= 1e-4 * max(1.0, abs(float(loss)))
     worst = 0.0
     for n, g in ref_grads.items():
         og = st[n].grad
         assert og is not None, n
         # scale: the param's own grad magnitude, floored (params whose true grad is ~0, e.g. the q/k rows of a
         # 1-key softmax in the LSTR pool decoder, carry only rounding noise)
-        scale = max(float(g.abs().max()), 1e-4)
+        scale = max(float(g.abs().max()), 1e-3 if spread else 1e-4)
         rel = float((g - og).abs().max()) / scale
         if rel > 1e-3:
             log("        note: %s rel %.3e (|g|max %.3e)" % (n, rel, float(g.abs().max())))
@@ -163,6 +222,32 @@ def train_case(name, yaml_name, sizes):
               "backbone.body.layer3.1.bn3.running_var", "backbone.body.layer4.0.down_sample.1.running_mean"):
         gold["buf." + k] = ref_state1[k].numpy()
     gold.update({"out." + k: v for k, v in flat_outputs(out).items()})
+    if spread:
+        # what the test needs to judge decidability per problem: the reference's cost matrices, and how far a bf16-rounded execution
+        # of the oracle moves every alternative's gap (ratio); the spread actually reached
+        from parity_util import run_oracle, matcher_problems, assignment_margin
+        obf, _ = run_oracle(mycfg, state0, clips, train=True, rounded=True)
+        pref = matcher_problems(mycfg, {k: v for k, v in out.items()}, targets)
+        pbf = matcher_problems(mycfg, obf, targets)
+        for li, (la, lb) in enumerate(zip(pref, pbf)):
+            for b, ((C1, a1), (C2, a2)) in enumerate(zip(la, lb)):
+                assert np.array_equal(a1[0], gold["match.%d.%d.src" % (li, b)]) and np.array_equal(a1[1], gold["match.%d.%d.tgt" % (li, b)])
+                assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1]), "the bf16-rounded oracle must keep the reference's assignment"
+                m, r, nz = assignment_margin(C1, a1, C2)
+                gold["cost.%d.%d" % (li, b)] = C1
+                gold["margin.%d.%d" % (li, b)] = np.float64(m)
+                gold["ratio.%d.%d" % (li, b)] = np.float64(r)
+                gold["noise.%d.%d" % (li, b)] = np.float64(nz)
+        gold["clip_seed"], gold["target_seed"] = np.int64(clip_seed), np.int64(target_seed)
+        gold["boxes_per_clip"] = np.array(SPREAD_BOXES_PER_CLIP if ava else [1] * len(sizes))
+        b = out["pred_boxes"].detach()
+        gold["box_spread"] = (b.max(1).values - b.min(1).values).numpy()
+        if ava:
+            pb = out["pred_logits_b"].detach().softmax(-1)[..., 1]
+            gold["p_b_range"] = np.array([float(pb.min()), float(pb.max())])
+            log("        %-32s box spread over the queries (clip 0) %s, p_b in [%.3f, %.3f]" % ("", gold["box_spread"][0].round(3), float(pb.min()), float(pb.max())))
+        for k in ("pred_logits", "pred_boxes", "pred_logits_b"):
+            gold["rounded_err." + k] = np.float64(float((out[k].detach() - obf[k]).abs().max()))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **gold)
 
 
@@ -241,7 +326,7 @@ def main():
     assert ref_import.available(), "run in the build container: /root/reference is required"
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["crit", "eval", "train"]
+    which = sys.argv[1:] or ["crit", "eval", "train", "spread"]
     if "crit" in which:
         criterion_case("criterion_ava", "TubeR_CSN152_AVA21.yaml", 11)
         criterion_case("criterion_jhmdb", "Tuber_CSN152_JHMDB.yaml", 12)
@@ -251,6 +336,11 @@ def main():
     if "train" in which:
         for n, (y, s) in TRAIN_CASES.items():
             train_case(n, y, s)
+    if "spread" in which:
+        for n, (y, s) in SPREAD_TRAIN_CASES.items():
+            train_case(n, y, s, spread=True)
+        for n, (y, s) in SPREAD_EVAL_CASES.items():
+            eval_case(n, y, s, spread=True)
     with open(os.path.join(GOLD, "GENERATION_LOG.txt"), "a") as f:
         f.write("\n".join(LOG) + "\n")
     json.dump({"torch": torch.__version__, "numpy": np.__version__}, open(os.path.join(GOLD, "versions.json"), "w"))

@@ -56,6 +56,39 @@ def test_oracle_forward_matches_reference_golden(golden_dir, name, yaml_name, si
         assert np.abs(a - gold[k]).max() <= 1e-5 * max(1.0, float(np.abs(gold[k]).max()))
 
 
+def test_spread_fixture_is_decidable_for_the_oracle_and_its_bf16_rounded_execution(golden_dir):
+    """The non-degenerate ("spread") train fixture (synth.SPREAD_GAINS + residual_gain 0.05 + structured clips; seeds chosen by
+    oracle/gen_golden.py: spread_search): the fp32 oracle AND a bf16-rounded execution of it reproduce the reference's Hungarian
+    assignment on every (decoder layer, clip) -- the property the plain name-hashed fixtures lack (a rounded run flips 12 / 12 there)
+    -- the queries are spread (boxes >= 0.05), and the golden's stored cost matrices / margins are the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from parity_util import run_oracle, matcher_problems, assignment_margin
+    name, yaml_name, sizes = "csn50_ava21_decode_train_spread", "TubeR_CSN50_AVA21", [(64, 64), (64, 64)]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfg_of(yaml_name)
+    model, _, _ = build_model(cfg)
+    synth.load_name_hashed(model, residual_gain=0.05, spread=True)
+    synth.zero_dropout(model)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    clips = synth.structured_clips(2, 32, sizes[0][0], sizes[0][1], seed=int(gold["clip_seed"]))
+    targets = synth.synthetic_targets(2, "ava", cfg.CONFIG.DATA.NUM_CLASSES, seed=int(gold["target_seed"]), hw=sizes[0],
+                                      boxes_per_clip=[int(v) for v in gold["boxes_per_clip"]])
+    assert float(gold["box_spread"].max()) >= 0.05
+    worst = float("inf")
+    for rounded in (False, True):
+        out, _ = run_oracle(cfg, state, clips, train=True, rounded=rounded)
+        for li, per in enumerate(matcher_problems(cfg, out, targets)):
+            for b, (C, (qi, ti)) in enumerate(per):
+                assert np.array_equal(qi, gold["match.%d.%d.src" % (li, b)]) and np.array_equal(ti, gold["match.%d.%d.tgt" % (li, b)]), (rounded, li, b)
+                if not rounded:
+                    assert np.abs(C - gold["cost.%d.%d" % (li, b)]).max() <= 1e-4
+                    m = assignment_margin(C, (qi, ti))[0]
+                    assert abs(m - float(gold["margin.%d.%d" % (li, b)])) <= 1e-3
+                    worst = min(worst, float(gold["ratio.%d.%d" % (li, b)]))
+    assert worst >= 2.0          # every problem's gap is at least twice what the rounded oracle's noise moves it
+
+
 @pytest.mark.parametrize("name,yaml_name", [("criterion_ava", "TubeR_CSN152_AVA21"), ("criterion_jhmdb", "Tuber_CSN152_JHMDB")])
 def test_oracle_criterion_matches_reference_golden(golden_dir, name, yaml_name):
     gold = np.load(os.path.join(golden_dir, name + ".npz"))

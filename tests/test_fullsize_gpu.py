@@ -37,13 +37,17 @@ FULL = {
     "cfg3_csn152_avg": ("TubeR_CSN152_AVA21.yaml", 2, (256, 340), "ava"),
     "cfg4_csn152_decode": ("TubeR_CSN152_AVA22.yaml", 1, (256, 340), "ava"),
     "cfg5_csn152_jhmdb": ("Tuber_CSN152_JHMDB.yaml", 2, (288, 384), "jhmdb"),
+    # round 5: config 3 on the NON-DEGENERATE fixture (synth.SPREAD_GAINS, residual_gain 0.05, structured clips): the 30 queries' actor
+    # probabilities spread over ~[0.64, 0.83] with several within the bf16 noise of the 0.8 gate of PostProcessAVA -- the gate-flip
+    # count of _decision_flips is a measurement on queries that CAN flip here (the bf16-rounded oracle itself flips 2 of 30)
+    "cfg3_csn152_avg_spread": ("TubeR_CSN152_AVA21.yaml", 2, (256, 340), "ava"),
 }
 
 
-def _build(yaml_name, dev, train=False, dropout=False, residual_gain=None):
+def _build(yaml_name, dev, train=False, dropout=False, residual_gain=None, spread=False):
     cfg = load_cfg(os.path.join(ROOT, "configuration", yaml_name))
     model, crit, post = build_model(cfg)
-    synth.load_name_hashed(model, residual_gain=residual_gain)
+    synth.load_name_hashed(model, residual_gain=residual_gain, spread=spread)
     if not dropout:
         synth.zero_dropout(model)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -57,8 +61,9 @@ def _build(yaml_name, dev, train=False, dropout=False, residual_gain=None):
 @pytest.mark.parametrize("case", list(FULL))
 def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
     yaml_name, B, hw, _ = FULL[case]
-    cfg, model, _, state = _build(yaml_name, dev)
-    clips = synth.synthetic_clips(B, 32, hw[0], hw[1], seed=1234)
+    spread = case.endswith("_spread")
+    cfg, model, _, state = _build(yaml_name, dev, residual_gain=0.05 if spread else None, spread=spread)
+    clips = synth.structured_clips(B, 32, hw[0], hw[1], seed=1234) if spread else synth.synthetic_clips(B, 32, hw[0], hw[1], seed=1234)
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     t0 = time.time()
     want, _ = run_oracle(cfg, state, clips, train=False)
@@ -76,12 +81,13 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
     for kind, (eh, eb) in errs.items():
         # absolute caps were stated for O(1..3) logits; an output with a larger range (the JHMDB 2048->2 visibility head on
         # pooled features: |logit| ~ 10) gets the cap in proportion
-        assert eh <= CAP[kind] * max(1.0, scale[kind] / 3.0), (kind, eh, scale[kind])
+        gain = synth.SPREAD_GAINS["class_embed_b"] if (spread and kind == "pred_logits_b") else 1.0     # the head's weight gain scales logits and error alike
+        assert eh <= CAP[kind] * max(1.0, scale[kind] / 3.0) * gain, (kind, eh, scale[kind])
         assert eh <= K_ROUNDED * eb + SLACK[kind], "%s: hip %.3e vs %.1f x rounded-oracle %.3e + %.0e" % (kind, eh, K_ROUNDED, eb, SLACK[kind])
-    _decision_flips(case, got, want, FULL[case][3])
+    _decision_flips(case, got, want, FULL[case][3], rnd=rnd)
 
 
-def _decision_flips(case, got, want, dataset):
+def _decision_flips(case, got, want, dataset, rnd=None):
     """What the logit error does to the DECISIONS the post-processors take (VERDICT r03 item 7: settle the tolerance with a measurement).
     AVA (PostProcessAVA, models/criterion.py:447-482): a query's 80 scores survive iff p_b = softmax(pred_logits_b)[1] > 0.8 -- count the
     queries whose gate differs between the HIP path and the fp32 oracle, at 0.8 and (the random-weight fixture keeps p_b far from 0.8)
@@ -112,6 +118,9 @@ def _decision_flips(case, got, want, dataset):
         for t, n in sweep.items():
             assert n <= int(((pb_r - t).abs() <= dpb).sum())
         assert gate <= near
+        if rnd is not None:      # the same count for the bf16-ROUNDED execution of the oracle: what ideal bf16 arithmetic does to the gate
+            pb_b = rnd["pred_logits_b"].float().softmax(-1)[..., 1]
+            msg += "; bf16-rounded oracle: max |dp_b| %.2e, gate flips at 0.8: %d" % (float((pb_b - pb_r).abs().max()), int(((pb_b > 0.8) != (pb_r > 0.8)).sum()))
         sc_h = lg_h.sigmoid() * ((pb_h > 0.8).float() * pb_h)[..., None]
         sc_r = lg_r.sigmoid() * ((pb_r > 0.8).float() * pb_r)[..., None]
         msg += "; max |d score| of PostProcessAVA %.2e" % float((sc_h - sc_r).abs().max())
