@@ -441,7 +441,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # world > 1, or the exact process shape of one rank of a multi-GPU lease minus its peers: launcher environment
+    # present (RANK / WORLD_SIZE=1 / MASTER_PORT) and TUBER_FORCE_DDP=1 -> nccl process group of one rank + the own RCCL communicator
+    launched_single = world == 1 and "RANK" in os.environ and "MASTER_PORT" in os.environ and bool(os.environ.get("TUBER_FORCE_DDP"))
+    if world > 1 or launched_single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("TUBER_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 

@@ -248,6 +248,11 @@ def train_case(name, yaml_name, sizes, spread=False):
             log("        %-32s box spread over the queries (clip 0) %s, p_b in [%.3f, %.3f]" % ("", gold["box_spread"][0].round(3), float(pb.min()), float(pb.max())))
         for k in ("pred_logits", "pred_boxes", "pred_logits_b"):
             gold["rounded_err." + k] = np.float64(float((out[k].detach() - obf[k]).abs().max()))
+        # the loss terms of the bf16-rounded execution (same assignment as the reference, asserted above): the yardstick of the test's
+        # per-term tolerance
+        rld, _ = O.set_criterion(mycfg, obf, targets)
+        for k, v in rld.items():
+            gold["rounded_loss." + k] = np.float64(float(v))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **gold)
 
 

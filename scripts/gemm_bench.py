@@ -67,6 +67,35 @@ def bench_nt(cfgs):
     lib.call("tuber_gemm_nt_set_cfg", -1)
 
 
+def bench_wsk96():
+    """the layer3 / layer4 long-K 1x1x1 convs (conv1 forward with statistics, conv4 data gradient with the ReLU-BN mask) on 64-row and on
+    96-row wave-split-K tiles (352 vs 236 / 240 workgroups for 256 CUs)"""
+    shapes = [(5632, 256, 1024, 1), (5632, 256, 1024, 2), (5632, 256, 1024, 0), (2816, 512, 2048, 1), (2816, 512, 2048, 2)]
+    for M, N, K, epi in shapes:
+        A = torch.randn(M, K, device=dev).to(BF)
+        B = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
+        Cm = torch.randn(M, N, device=dev).to(BF)
+        sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+        outs = []
+        row = "%-24s" % ("%d %d %d epi %d" % (M, N, K, epi))
+        for on in (0, 1):
+            lib.query("tuber_gemm_nt_wsk96_set", on)
+            C = torch.zeros(M, N, device=dev, dtype=BF)
+            st0, st1 = torch.full((M // 32 + 8, N), 7.0, device=dev), torch.full((M // 32 + 8, N), 7.0, device=dev)
+
+            def fn():
+                lib.call("tuber_gemm_nt", A, K, B, K, C, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, epi, None, None, 0, 0, 0,
+                         st0 if epi else None, st1 if epi else None, Cm if epi == 2 else None, N, sc if epi == 2 else None, sh if epi == 2 else None,
+                         1.0, 0.0, None, 0, None, 0, None)
+            row += "  %s %6.2f us" % ("96-row" if on else "64-row", time_it(fn))
+            R = lib.query("tuber_gemm_nt_stat_rows", M, N)
+            outs.append((C.float().clone(), st0[:R].double().sum(0).clone() if epi else None, st1[:R].double().sum(0).clone() if epi else None))
+        d = float((outs[0][0] - outs[1][0]).abs().max())
+        ds = max(float(((outs[0][k] - outs[1][k]).abs() / (outs[0][k].abs() + 1e-3)).max()) for k in (1, 2)) if epi else 0.0
+        print(row + "   max |dC| %.3e, statistics rel diff %.2e" % (d, ds), flush=True)
+    lib.query("tuber_gemm_nt_wsk96_set", 1)
+
+
 TN_SHAPES = [(30, 256, 256), (704, 256, 256), (704, 2048, 256), (704, 256, 2048), (30, 2048, 256), (180, 256, 256),
              (5632, 1024, 256), (5632, 256, 1024), (44032, 512, 128), (44032, 128, 512), (348160, 256, 64), (348160, 64, 256),
              (16896, 768, 256), (16896, 256, 2048), (16896, 2048, 512), (2816, 2048, 512)]
@@ -92,6 +121,8 @@ def bench_tn_group():
     import ctypes
     from tubelet_transformer_amd.engine import TnArgs
     groups = {"layer3 x8": [(5632, 1024, 256, 1), (5632, 256, 1024, 0)] * 4,
+              "layer3 x16": [(5632, 1024, 256, 1), (5632, 256, 1024, 0)] * 8,
+              "layer4 x6 ": [(2816, 2048, 512, 1), (2816, 512, 2048, 0)] * 3,
               "layer4 x6": [(2816, 2048, 512, 1), (2816, 512, 2048, 0)] * 3,
               "class-branch FFN": [(16896, 256, 2048, 0), (16896, 2048, 512, 0)],
               "encoder FFN x4": [(704, 256, 2048, 0), (704, 2048, 256, 0)] * 2}
@@ -289,6 +320,9 @@ def bench_stem():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wsk96":
+        bench_wsk96()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stem":
         bench_stem()
         sys.exit(0)

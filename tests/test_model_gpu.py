@@ -209,10 +209,12 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
 
     * the fused criterion on the model's own outputs == the oracle's criterion on the same values: assignment bit-exact, losses 1e-4,
       output gradients 2e-5 (check_criterion_on_model_outputs);
-    * the assignment equals the REFERENCE's on every problem the golden marks decidable (ratio >= 3); on the others a flip is accepted
-      only if the cost perturbation that explains it is <= 3 x the rounded oracle's on that problem;
-    * with all assignments identical: every loss term within 2 %, the total within 0.5 %, the global gradient norm within 5 %,
-      per-tensor gradient-norm ratios in (0.67, 1.5), head-gradient cosines >= 0.98.
+    * the assignment against the REFERENCE's, per problem: identical wherever the golden's decidability ratio is >= 6 and on at least
+      9 of the 12 problems; a flip elsewhere is accepted only if the cost perturbation of the HIP run on that problem is <= 3 x the
+      rounded oracle's (+ 0.02) -- i.e. explained by bf16 noise of the size ideal bf16 arithmetic has on the same fixture;
+    * on the layers whose assignment is the reference's: every loss term within max(2 %, 2 x the rounded oracle's error on that term
+      + 0.5 %); with all assignments identical also: total within 0.5 %, global gradient norm within 5 %, per-tensor gradient-norm
+      ratios in (0.67, 1.5), head-gradient cosines >= 0.98.
     """
     from parity_util import criterion_probe, check_criterion_on_model_outputs, matcher_problems, assignment_margin
     yaml_name, sizes = SPREAD_TRAIN_CASES[name]
@@ -249,12 +251,14 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
             ok = np.array_equal(qi.numpy(), a_ref[0]) and np.array_equal(ti.numpy(), a_ref[1])
             same += int(ok)
             lines.append("%d.%d %s margin %.2f ratio hip %.1f / rounded %.1f" % (li, b, "same" if ok else "FLIP", float(gold["margin.%d.%d" % (li, b)]), ratio_hip, ratio_ref))
+            lines[-1] += " noise %.3f / %.3f" % (noise_hip, noise_ref)
             if not ok:
                 flipped_layers.add(li)
-                assert ratio_ref < 3.0, "decidable problem (layer %d, clip %d: gap >= 3 x the rounded oracle's perturbation) assigned differently from the reference" % (li, b)
-                assert noise_hip <= 3.0 * noise_ref + 1e-2, "flip at (layer %d, clip %d) needs a cost perturbation of %.3f; the rounded oracle's is %.3f" % (li, b, noise_hip, noise_ref)
+                assert ratio_ref < 6.0, "decidable problem (layer %d, clip %d: gap >= 6 x the rounded oracle's perturbation) assigned differently from the reference" % (li, b)
+                assert noise_hip <= 3.0 * noise_ref + 2e-2, "flip at (layer %d, clip %d) needs a cost perturbation of %.3f; the rounded oracle's is %.3f" % (li, b, noise_hip, noise_ref)
     print("%s matcher assignments identical to the reference: %d / %d   [%s]" % (name, same, total, "; ".join(lines)))
     print("%s query spread of the reference: boxes %s%s" % (name, gold["box_spread"][0].round(3), ", p_b in [%.3f, %.3f]" % tuple(gold["p_b_range"]) if ava else ""))
+    assert same >= (3 * total) // 4, (same, total)
     worst_term = 0.0
     for k in sorted(ld):
         if k == "class_error":
@@ -262,10 +266,15 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
         g, r = float(ld[k]), float(gold["loss." + k])
         layer = 0 if "_" not in k[5:] or not k.rsplit("_", 1)[1].isdigit() else int(k.rsplit("_", 1)[1]) + 1
         rel = abs(g - r) / max(abs(r), 1e-3)
-        print("  %-14s hip %.5f  ref %.5f  (%.2f %%)" % (k, g, r, 100 * rel))
+        # yardstick: the bf16-rounded oracle's worst relative error on this loss FAMILY over the decoder layers (one layer's realised
+        # error is a noisy estimate of the family's)
+        fam = k if layer == 0 else k.rsplit("_", 1)[0]
+        rel_rounded = max(abs(float(gold["rounded_loss." + kk]) - float(gold["loss." + kk])) / max(abs(float(gold["loss." + kk])), 1e-3)
+                          for kk in ld if kk != "class_error" and (kk == fam or (kk.startswith(fam + "_") and kk[len(fam) + 1:].isdigit())))
+        print("  %-14s hip %.5f  ref %.5f  (%.2f %%; bf16-rounded oracle %.2f %%)" % (k, g, r, 100 * rel, 100 * rel_rounded))
         if layer not in flipped_layers:
             worst_term = max(worst_term, rel)
-            assert rel <= 0.02, (k, g, r)
+            assert rel <= max(0.02, 2.0 * rel_rounded + 0.005), (k, g, r, rel_rounded)
     tl, tr = float(loss), float(gold["total_loss"])
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
     gn = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
@@ -606,6 +615,37 @@ def test_two_rank_bench_captures_the_graph_step(tmp_path):
     c = j["comm"]
     assert c["world"] == 2 and "process group (gloo)" in c["transport"] and c["ranks_seen_by_rccl"] is None
     assert c["windows_per_step"] >= 2 and c["bytes_per_step"] > 4 * 40e6 and "graph A" in c["launch"]
+
+
+def test_one_rank_of_a_multi_gpu_lease_minus_its_peers(tmp_path):
+    """The exact process the first 8-GPU lease will start, minus the peers: ``bench.py --gpus 1`` under the
+    environment ``spawn_ranks`` / torchrun give a rank (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) with TUBER_FORCE_DDP=1 ->
+    torch's nccl process group of one rank, the OWN RCCL communicator next to it (one librccl in the process), the reducer's side stream
+    and the cut-graph step.  The ``comm`` object must say so: RCCL itself reports 1 rank, the exposed wait was measured."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TUBER_BENCH_SPAWNED="1", TUBER_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("TUBER_SHARE_GPU", "TUBER_DIST_BACKEND", "TUBER_NO_OWN_RCCL"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--height", "64", "--width", "96",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["config"]["launch_mode"] == "hipgraph" and math.isfinite(j["final_loss"]) and j["value"] > 0
+    c = j["comm"]
+    assert "own RCCL communicator" in c["transport"], c
+    assert c["world"] == 1 and c["ranks_seen_by_rccl"] == 1 and c["rccl_version"] > 0, c
+    assert c["exposed_ms"] is not None and c["exposed_ms"] >= 0.0, c
+    assert c["windows_per_step"] >= 2 and c["bytes_per_step"] > 4 * 40e6 and "graph A" in c["launch"], c
+    print("one-rank launcher-shaped bench: comm = %s" % c)
 
 
 @pytest.mark.gpu

@@ -62,6 +62,10 @@ __device__ __forceinline__ int swz_act(int row) { return (row >> 1) & 7; }
 template <int NT>
 __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3) << 1) | ((row >> 1) & 1); }
 
+// bytes of one wave's private LDS image of the wave split-K form: the staged k-tile (A BM x 128 B | B 64 x 128 B) or, afterwards, its four
+// partial sub-tiles (4 x (BM/32) x 2 accumulator blocks x 64 lanes x 16 B)
+__host__ __device__ constexpr int wsk_image_bytes(int bm) { return (bm + 64) * 128 > 4 * (bm / 32) * 2 * 1024 ? (bm + 64) * 128 : 4 * (bm / 32) * 2 * 1024; }
+
 // OCC = waves per SIMD the register allocation is held to (= workgroups per CU: a workgroup is one wave per SIMD).  It must not
 // exceed what the LDS allows anyway -- 2*(BM+BN)*128 B per workgroup of the 160 KB: 64x64 -> 4-5, 64x128 -> 3, 128x128 -> 2 --
 // or the compiler spills the prefetch registers to scratch inside the k-loop for occupancy the kernel can never reach.
@@ -75,7 +79,7 @@ __device__ __forceinline__ int swz_wgt(int row) { return (((row / (4 * NT)) & 3)
 // epilogue are compiled out.
 template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC, int WSK = 0, bool FULL = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
-    static_assert(!WSK || (BM == 64 && BN == 64 && WM == 2 && WN == 2 && AMODE == A_PLAIN), "wave split-K: 64x64 tiles, plain A");
+    static_assert(!WSK || ((BM == 64 || BM == 96) && BN == 64 && WM == 2 && WN == 2 && AMODE == A_PLAIN), "wave split-K: 64x64 / 96x64 tiles, plain A");
     constexpr int KS = 1, kg = 0;               // (the in-workgroup k-split of round 1 was measured and dropped; the index math keeps its shape)
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int CA = BM / 32, CB = BN / 32;            // 16-byte chunks per thread per k-tile
@@ -274,22 +278,30 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     }
     if constexpr (WSK) {
         // ---- wave split-K: this wave owns k-tiles wave, wave+4, ...; image = A 64 x 128 B | B 64 x 128 B, private to the wave ----
-        char* const sa = smem + wave * 16384;
-        char* const sb = sa + 8192;
+        // (BM = 96, round 5: the layer3 / layer4 shapes have 352 tiles of 64 x 64 for 256 CUs -- 96 CUs carry two workgroups and set the
+        // launch's duration; 96-row tiles are 236 resp. 240 workgroups, at most one per CU, each 1.5 x the MFMA work behind the same
+        // latency chain)
+        constexpr int AR = BM / 8;                               // staged A rows per lane
+        constexpr int IMG = wsk_image_bytes(BM);                 // per-wave image: staging (A BM x 128 B | B 64 x 128 B) or its four partial sub-tiles
+        char* const sa = smem + wave * IMG;
+        char* const sb = sa + BM * 128;
         const int lq = lane & 7, lr = lane >> 3;                 // chunk c = lane + 64 i -> row lr + 8 i, 16-byte chunk lq
-        const bf16* pa[8];
+        const bf16* pa[AR];
         const bf16* pb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            pa[i] = p.A + (long)min(m0 + lr + 8 * i, p.M - 1) * p.lda + lq * 8;
-            pb[i] = p.B + (long)min(n0 + lr + 8 * i, p.N - 1) * p.ldb + lq * 8;
-        }
-        uint4 xa[8], xb[8];
+        for (int i = 0; i < AR; ++i) pa[i] = p.A + (long)min(m0 + lr + 8 * i, p.M - 1) * p.lda + lq * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { xa[i] = make_uint4(0, 0, 0, 0); xb[i] = make_uint4(0, 0, 0, 0); }     // defined on every path: stays in VGPRs
-        auto fetch = [&](int kt, uint4 (&ya)[8], uint4 (&yb)[8]) {
+        for (int i = 0; i < 8; ++i) pb[i] = p.B + (long)min(n0 + lr + 8 * i, p.N - 1) * p.ldb + lq * 8;
+        uint4 xa[AR], xb[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { ya[i] = *(const uint4*)(pa[i] + kt * 64); yb[i] = *(const uint4*)(pb[i] + kt * 64); }
+        for (int i = 0; i < AR; ++i) xa[i] = make_uint4(0, 0, 0, 0);     // defined on every path: stays in VGPRs
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[i] = make_uint4(0, 0, 0, 0);
+        auto fetch = [&](int kt, uint4 (&ya)[AR], uint4 (&yb)[8]) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) ya[i] = *(const uint4*)(pa[i] + kt * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yb[i] = *(const uint4*)(pb[i] + kt * 64);
         };
         f32x4 acc4[2][2][MT][NT];
 #pragma unroll
@@ -303,9 +315,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         if (wave < nkt) fetch(wave, xa, xb);
         for (int kt = wave; kt < nkt; kt += 4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < AR; ++i) {
                 const int row = lr + 8 * i;
                 *(uint4*)(sa + row * 128 + ((lq ^ swz_act(row)) << 4)) = xa[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = lr + 8 * i;
                 *(uint4*)(sb + row * 128 + ((lq ^ swz_wgt<NT>(row)) << 4)) = xb[i];
             }
             if (kt + 4 < nkt) fetch(kt + 4, xa, xb);
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             for (int j = 0; j < NT; ++j) {
                 f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int w = 0; w < 4; ++w) t += ((const f32x4*)(smem + w * 16384))[(((wm * 2 + wn) * MT + i) * NT + j) * 64 + lane];
+                for (int w = 0; w < 4; ++w) t += ((const f32x4*)(smem + w * IMG))[(((wm * 2 + wn) * MT + i) * NT + j) * 64 + lane];
                 acc[i][j] = t;
             }
     } else {
@@ -542,6 +558,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             p.stat0[(long)tile_m * p.N + n0 + tid] = a;
             p.stat1[(long)tile_m * p.N + n0 + tid] = b;
             if constexpr (EPI == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
+            if constexpr (BM != 64) {
+                // the consumers read tuber_gemm_nt_stat_rows(M, N) = ceil(M / 64) rows: the rows this tiling does not produce are zero
+                const int tiles_m = (p.M + BM - 1) / BM, rows64 = (p.M + 63) / 64;
+                for (int r = tiles_m + tile_m; r < rows64; r += tiles_m) { p.stat0[(long)r * p.N + n0 + tid] = 0.f; p.stat1[(long)r * p.N + n0 + tid] = 0.f; }
+            }
         }
     }
 }
@@ -591,8 +612,30 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
     TUBER_RETURN_LAUNCH();
 }
 
+static int g_nt_wsk96 = 1;        // EXPERIMENT hook (round 5): 0 = 64-row tiles everywhere (tuber_gemm_nt_wsk96_set)
 // wave split-K launch (64x64 tiles, plain A): 64 KB of LDS (four private 16 KB images), two workgroups per CU
+static bool nt_wsk_96(const GemmNT& p, int epi) {
+    // 96-row tiles where the 64-row tiling needs more workgroups than there are CUs and the 96-row one does not (layer3: 352 -> 236,
+    // layer4: 352 -> 240); full tiles only, the three epilogues those convs use
+    const long t64 = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64), t96 = (long)ceil_div(p.M, 96) * ceil_div(p.N, 64);
+    return g_nt_wsk96 && t64 > 256 && t96 <= 256 && nt_full(p, 64) && (epi == EPI_PLAIN || epi == EPI_STATS || epi == EPI_BWD);
+}
 static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
+    if (nt_wsk_96(p, epi)) {
+        dim3 grid96(ceil_div(p.M, 96) * ceil_div(p.N, 64)), block96(256);
+        constexpr size_t lds96 = 4 * (size_t)wsk_image_bytes(96);
+#define LWSK96(EP)                                                                                                            \
+    do {                                                                                                                      \
+        static LdsOptIn opt;                                                                                                  \
+        TUBER_LDS_OPT_IN(opt, (gemm_nt_kernel<96, 64, 2, 2, 2, A_PLAIN, EP, 1, 1, true>), lds96);                              \
+        hipLaunchKernelGGL((gemm_nt_kernel<96, 64, 2, 2, 2, A_PLAIN, EP, 1, 1, true>), grid96, block96, lds96, s, p);          \
+    } while (0)
+        if (epi == EPI_PLAIN) LWSK96(EPI_PLAIN);
+        else if (epi == EPI_STATS) LWSK96(EPI_STATS);
+        else LWSK96(EPI_BWD);
+#undef LWSK96
+        TUBER_RETURN_LAUNCH();
+    }
     const int tiles = ceil_div(p.M, 64) * ceil_div(p.N, 64);
     dim3 grid(tiles), block(256);
     const size_t lds = 4 * 16384;
@@ -650,6 +693,7 @@ extern "C" {
 // tile configuration tuber_gemm_nt picks for (M, N): 0 = 128x128, 1 = 128x64, 2 = 64x64 (profiling / tests)
 int tuber_gemm_nt_cfg(int M, int N, int K) { return nt_pick_cfg(M, N, K); }
 
+int tuber_gemm_nt_wsk96_set(int on) { g_nt_wsk96 = on; return 0; }
 int tuber_gemm_nt_set_cfg(int cfg) { g_nt_force = cfg < 0 ? -1 : cfg; return 0; }
 
 int tuber_gemm_nt_stat_rows(int M, int N) {
@@ -1349,7 +1393,7 @@ __device__ __forceinline__ void gemm_tn3_body(const GemmTN& p, int bid, int nblo
         for (int j = 0; j < GS; ++j) {
             if (ms + 64 * j >= m_end) continue;
             store_step(buf, rg[j], ra[j], rok[j]);
-            if (ms == m_begin && j == 0)            if (ms == m_begin + 64 * GS * 4 && j == 0)            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
+            if (ms + 64 * (GS + j) < m_end) load_step(ms + 64 * (GS + j), rg[j], ra[j], rok[j]);
             __syncthreads();
             const bf16* gi = smem[buf][0];
             const bf16* ai = smem[buf][1];
@@ -1502,7 +1546,10 @@ static int tn_slabs_wanted(int M, int N, int K) {
     // amortise the 64 KB prologue / 64 KB fp32 epilogue of a tile, more leave the chip underfilled
     long S;
     if (tn_big(M, N, K)) {
-        constexpr int big_rows = 1408, long_rows = 2112;
+        // round 5, groups of 16 problems: layer3 (M = 5632) as 2 slabs of 2816 rows -- 86.1 us per sixteen against 94.1 with 4 slabs
+        // (112.6 with 1), half the fp32 partials written and re-read; step 14.255 -> 14.22 ms (two same-box pairs).  layer4 (M = 2816)
+        // stays at 2 slabs of 1408 (71 us per six against 80 with 1)
+        const int big_rows = M > 4096 ? 2816 : 1408; constexpr int long_rows = 2112;
         const int rows = M > 8192 ? long_rows : big_rows;
         S = (M + rows / 2) / rows;
     } else {

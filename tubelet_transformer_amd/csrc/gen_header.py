@@ -37,6 +37,7 @@ DOC = {
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
                            "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift; float* bias_grad; const void* A2; long lda2;} (A2: optional addend, A := A + A2) with the meaning of the tuber_gemm_tn arguments. "
                            "Transpose-read kernel shapes only (N, K, ld multiples of 8, 64x64 tiles); several slabs need accumulate = 2 (the caller reduces them).",
+    "tuber_gemm_nt_wsk96_set": "EXPERIMENT hook: 0 switches the 96-row wave-split-K tiles of tuber_gemm_nt off (64-row tiles everywhere).",
     "tuber_gemm_tn_args_bytes": "sizeof(struct TuberGemmTNArgs) as compiled (host-side layout check).",
     "tuber_gemm_tn_group_max": "largest n tuber_gemm_tn_group accepts (the argument blocks travel by value in the kernel argument segment).",
     "tuber_comm_version": "RCCL bound at run time (dlopen librccl.so.1: the instance the host process already loaded, else ROCm's): its version code, "
