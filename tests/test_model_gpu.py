@@ -214,7 +214,7 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
       rounded oracle's (+ 0.02) -- i.e. explained by bf16 noise of the size ideal bf16 arithmetic has on the same fixture;
     * on the layers whose assignment is the reference's: every loss term within max(2 %, 2 x the rounded oracle's error on that term
       + 0.5 %); with all assignments identical also: total within 0.5 %, global gradient norm within 5 %, per-tensor gradient-norm
-      ratios in (0.67, 1.5), head-gradient cosines >= 0.98.
+      ratios in (0.67, 1.5), gradient cosines >= 0.98 (heads) / >= 0.85 (every stored tensor, incl. the stem's conv1).
     """
     from parity_util import criterion_probe, check_criterion_on_model_outputs, matcher_problems, assignment_margin
     yaml_name, sizes = SPREAD_TRAIN_CASES[name]
@@ -291,7 +291,9 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
             a, b = grads[n].flatten().double(), torch.as_tensor(gold[k]).flatten().double()
             cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
             print("  cos(grad %-44s) = %.4f   |hip| %.3e |ref| %.3e" % (n, cos, float(a.norm()), float(b.norm())))
-            if n in ("class_embed_b.weight", "class_fc.bias", "query_embed.weight") and cos < 0.98:
+            # heads (closest to the loss) >= 0.98; every stored tensor -- down to the stem's conv1 through 50 bottlenecks -- >= 0.85
+            # (the plain name-hashed fixture reaches 0.007 there: the deep gradient is only testable on this fixture)
+            if cos < (0.98 if n in ("class_embed_b.weight", "class_fc.bias") else 0.85):
                 cos_low.append((n, cos))
     for k in gold.files:
         if k.startswith("buf."):

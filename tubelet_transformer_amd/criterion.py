@@ -73,10 +73,36 @@ class PaddedTargets:
         if len(sizes) != self.B or max(sizes + [0]) > self.tmax:
             raise ValueError("batch of %d clips with up to %d targets does not fit the captured [%d, %d] layout" % (len(sizes), max(sizes + [0]), self.B, self.tmax))
         self.sizes = sizes
+        if self._pack(targets):
+            return
         self.tboxes.zero_()
         self.tlabels.zero_()
         self.tcount.copy_(torch.tensor(sizes, dtype=torch.int32), non_blocking=True)
         self.fill(targets)
+
+    def _pack(self, targets):
+        """the whole refill as ONE launch (tuber_targets_pack) when every per-clip tensor already sits on the device in the layout the
+        reference's collate gives it (boxes fp32 [n,5], labels fp32 [n,C] / int64 [n]); False -> the per-clip copies above."""
+        dev = self.tboxes.device
+        if dev.type != "cuda" or self.B > lib.query("tuber_targets_pack_max"):
+            return False
+        ldt = torch.float32 if self.ava else torch.int64
+        C = self.tlabels.shape[2] if self.ava else 1
+        for t, n in zip(targets, self.sizes):
+            bx, lb = t["boxes"], t["labels"]
+            if not (torch.is_tensor(bx) and torch.is_tensor(lb) and bx.device == dev and lb.device == dev and bx.dtype == torch.float32 and lb.dtype == ldt
+                    and bx.is_contiguous() and lb.is_contiguous() and tuple(bx.shape) == (n, 5) and tuple(lb.shape) == ((n, C) if self.ava else (n,))):
+                return False
+        import ctypes
+        P = ctypes.c_void_p * self.B
+        boxes = P(*[t["boxes"].data_ptr() if n else None for t, n in zip(targets, self.sizes)])
+        labels = P(*[t["labels"].data_ptr() if n else None for t, n in zip(targets, self.sizes)])
+        sizes = (ctypes.c_int * self.B)(*self.sizes)
+        lib.call("tuber_targets_pack", boxes, labels, sizes, self.B, self.tmax, C, 1 if self.ava else 0, self.tboxes, self.tlabels, self.tcount)
+        if not self.ava:
+            self.key_pos.copy_(torch.stack([torch.as_tensor(t["key_pos"]).reshape(()) for t in targets]).to(self.key_pos), non_blocking=True)
+            self.vis.copy_(torch.stack([torch.as_tensor(t["vis"]).reshape(()) for t in targets]).to(self.vis), non_blocking=True)
+        return True
 
 
 class HungarianMatcher(nn.Module):

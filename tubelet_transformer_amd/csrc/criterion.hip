@@ -352,6 +352,37 @@ __global__ void mask_resize_kernel(const uint8_t* __restrict__ mask, uint8_t* __
     out[i] = mask[((long)b * H + yy) * W + xx] ? 1 : 0;
 }
 
+
+// ---- padded target layout of one batch in ONE launch (criterion.PaddedTargets.refill) ----------------------------------------------
+// The captured step reads the targets from static [B, Tmax] device buffers; refilling them from the per-clip target tensors was two
+// memsets and two sliced copies per clip (7+ launches a step).  The per-clip pointers travel by value in the kernel arguments.
+#define TP_MAX_CLIPS 16
+struct TargetPack {
+    const float* boxes[TP_MAX_CLIPS];      // [n_b][5] fp32 (column 0 = key-frame index, dropped: matcher.py:64)
+    const void* labels[TP_MAX_CLIPS];      // AVA: [n_b][C] fp32 multi-hot;  JHMDB: [n_b] int64 class ids
+    int n[TP_MAX_CLIPS];
+    int B, Tmax, C, ava;
+    float* tboxes; float* tlabels; int* tcount;
+};
+__global__ void targets_pack_kernel(TargetPack a) {
+    const int b = blockIdx.x;
+    const int n = a.n[b];
+    if (threadIdx.x == 0) a.tcount[b] = n;
+    for (int i = threadIdx.x; i < a.Tmax * 4; i += blockDim.x) {
+        const int t = i >> 2, c = i & 3;
+        a.tboxes[((long)b * a.Tmax + t) * 4 + c] = t < n ? a.boxes[b][t * 5 + 1 + c] : 0.f;
+    }
+    if (a.ava) {
+        for (int i = threadIdx.x; i < a.Tmax * a.C; i += blockDim.x) {
+            const int t = i / a.C;
+            a.tlabels[(long)b * a.Tmax * a.C + i] = t < n ? ((const float*)a.labels[b])[i] : 0.f;
+        }
+    } else {
+        for (int t = threadIdx.x; t < a.Tmax; t += blockDim.x)
+            a.tlabels[(long)b * a.Tmax + t] = t < n ? (float)((const long long*)a.labels[b])[t] : 0.f;
+    }
+}
+
 extern "C" {
 
 int tuber_criterion_cost(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
@@ -396,6 +427,22 @@ int tuber_class_error(const float* logits, const int* match, const float* tlabel
 }
 
 // mask [B,H,W] (bool / uint8, nonzero = padding) -> out [B,h,w] uint8
+// boxes / labels / sizes: HOST arrays of B device pointers / target counts (B <= tuber_targets_pack_max()); writes tboxes [B][Tmax][4],
+// tlabels [B][Tmax][C] (AVA) or [B][Tmax] (class ids as float), tcount [B] -- zero padding included
+int tuber_targets_pack_max(void) { return TP_MAX_CLIPS; }
+int tuber_targets_pack(const void* const* boxes, const void* const* labels, const int* sizes, int B, int Tmax, int C, int ava,
+                       float* tboxes, float* tlabels, int* tcount, hipStream_t stream) {
+    if (B <= 0 || B > TP_MAX_CLIPS || Tmax <= 0 || C <= 0 || !boxes || !labels || !sizes || !tboxes || !tlabels || !tcount) return TUBER_EINVAL;
+    TargetPack a{};
+    for (int b = 0; b < B; ++b) {
+        if (sizes[b] < 0 || sizes[b] > Tmax || (sizes[b] > 0 && (!boxes[b] || !labels[b]))) return TUBER_EINVAL;
+        a.boxes[b] = (const float*)boxes[b]; a.labels[b] = labels[b]; a.n[b] = sizes[b];
+    }
+    a.B = B; a.Tmax = Tmax; a.C = C; a.ava = ava; a.tboxes = tboxes; a.tlabels = tlabels; a.tcount = tcount;
+    hipLaunchKernelGGL(targets_pack_kernel, dim3(B), dim3(256), 0, stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
 int tuber_mask_resize(const void* mask, void* out, int B, int H, int W, int h, int w, hipStream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return TUBER_EINVAL;
     const int n = B * h * w;

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             p.stat0[(long)tile_m * p.N + n0 + tid] = a;
             p.stat1[(long)tile_m * p.N + n0 + tid] = b;
             if constexpr (EPI == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
-            if constexpr (BM != 64) {
+            if constexpr (WSK && BM == 96) {
                 // the consumers read tuber_gemm_nt_stat_rows(M, N) = ceil(M / 64) rows: the rows this tiling does not produce are zero
                 const int tiles_m = (p.M + BM - 1) / BM, rows64 = (p.M + 63) / 64;
                 for (int r = tiles_m + tile_m; r < rows64; r += tiles_m) { p.stat0[(long)r * p.N + n0 + tid] = 0.f; p.stat1[(long)r * p.N + n0 + tid] = 0.f; }
@@ -694,6 +694,13 @@ extern "C" {
 int tuber_gemm_nt_cfg(int M, int N, int K) { return nt_pick_cfg(M, N, K); }
 
 int tuber_gemm_nt_wsk96_set(int on) { g_nt_wsk96 = on; return 0; }
+// rows per tile of the wave-split-K form tuber_gemm_nt takes for a plain-A (M, N, K) with a 16-byte addressable output: 0 = not taken, 64 or 96
+int tuber_gemm_nt_wsk_tile_rows(int M, int N, int K) {
+    GemmNT p{};
+    p.M = M; p.N = N; p.K = K; p.ldc = N;
+    if (nt_force_cfg() >= 0 || nt_pick_cfg(M, N, K) != 13 || !nt_use_wsk(p, A_PLAIN)) return 0;
+    return nt_wsk_96(p, EPI_STATS) ? 96 : 64;
+}
 int tuber_gemm_nt_set_cfg(int cfg) { g_nt_force = cfg < 0 ? -1 : cfg; return 0; }
 
 int tuber_gemm_nt_stat_rows(int M, int N) {

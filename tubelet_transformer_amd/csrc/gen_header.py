@@ -21,6 +21,11 @@ DOC = {
     "tuber_bn_bwd_fa_max_rows": "largest R tuber_bn_bwd_fa accepts.",
     "tuber_class_error": "class_error of the matched queries of one decoder layer, on the device: 100 - exact-set accuracy (AVA, utils/misc.py:497-518 "
                          "via models/criterion.py:76-78) or top-1 accuracy (JHMDB, utils/misc.py:521-539 via criterion.py:258-260).",
+    "tuber_targets_pack": "the padded [B, Tmax] target layout of one batch in ONE launch: boxes (column 0 = key-frame index dropped, models/detr/matcher.py:64, "
+                          "models/criterion.py:106), labels (multi-hot rows for AVA, class ids for JHMDB) and the per-clip counts from B per-clip device tensors "
+                          "whose pointers travel by value (HOST arrays boxes[B], labels[B], sizes[B]); zero padding included. Replaces the two memsets + two sliced "
+                          "copies per clip the captured step issued before every replay.",
+    "tuber_targets_pack_max": "largest B tuber_targets_pack accepts.",
     "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "
                          "clip padding mask to the feature grid = the transformer's key-padding mask, ATen's source-index rule.",
     "tuber_gemm_nt_join": "conv1 data gradient of one bottleneck fused with the join backward of the bottleneck below it: dz = (A.B^T + R) * [Y > 0] "
@@ -37,6 +42,8 @@ DOC = {
                            "{const void* G; long ldg; const void* A; long lda; float* partial; float* out; int accumulate, M, N, K, amode, gather, "
                            "To, Ho, Wo, Ti, Hi, Wi, st, ss; const float* a_scale; const float* a_shift; float* bias_grad; const void* A2; long lda2;} (A2: optional addend, A := A + A2) with the meaning of the tuber_gemm_tn arguments. "
                            "Transpose-read kernel shapes only (N, K, ld multiples of 8, 64x64 tiles); several slabs need accumulate = 2 (the caller reduces them).",
+    "tuber_gemm_nt_wsk_tile_rows": "rows per tile of the wave-split-K form tuber_gemm_nt takes for a plain-A (M, N, K): 0 (not taken), 64, or 96 (shapes whose "
+                                   "64-row tiling has more workgroups than the chip has CUs while the 96-row one does not: the layer3 / layer4 long-K convs).",
     "tuber_gemm_nt_wsk96_set": "EXPERIMENT hook: 0 switches the 96-row wave-split-K tiles of tuber_gemm_nt off (64-row tiles everywhere).",
     "tuber_gemm_tn_args_bytes": "sizeof(struct TuberGemmTNArgs) as compiled (host-side layout check).",
     "tuber_gemm_tn_group_max": "largest n tuber_gemm_tn_group accepts (the argument blocks travel by value in the kernel argument segment).",

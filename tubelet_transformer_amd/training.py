@@ -259,6 +259,15 @@ class GraphedTrainStep:
         g.ranges = store.trainable_ranges()
         return g
 
+    def input_buffers(self, clips_shape):
+        """(clips, mask) buffers the captured step for this clip shape reads, or None before its first call: a producer that fills them in
+        place and passes them back to ``__call__`` saves the step its 67 MB device-to-device copy."""
+        store, _ = self.model.engine()
+        for k, g in self.graphs.items():
+            if k[:3] == (tuple(clips_shape), store.trainable_signature(), self.criterion.training):
+                return g.clips, g.mask
+        return None
+
     # -- replay --------------------------------------------------------------------------------------------------------------
     def __call__(self, samples, targets):
         """``samples``: NestedTensor (clips + padding mask) or a plain [B,3,T,H,W] tensor (no padding)."""
@@ -289,8 +298,12 @@ class GraphedTrainStep:
             self.graphs[key] = g
         else:
             self.graphs.move_to_end(key)
-        g.clips.copy_(clips, non_blocking=True)
-        g.mask.copy_(mask, non_blocking=True)
+        # a producer that writes straight into the captured buffers (``input_buffers``: the input pre-pass, bench.py's resident synthetic
+        # clips) hands those very tensors back: nothing to copy then
+        if clips.data_ptr() != g.clips.data_ptr():
+            g.clips.copy_(clips, non_blocking=True)
+        if mask.data_ptr() != g.mask.data_ptr():
+            g.mask.copy_(mask, non_blocking=True)
         g.pt.refill(targets)
         self.optimizer.sync_hyper()
         self.optimizer.mark_stepped()
