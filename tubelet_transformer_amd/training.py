@@ -132,6 +132,21 @@ class GraphedTrainStep:
 
     # -- capture -------------------------------------------------------------------------------------------------------------
     def _capture(self, clips, mask, targets, tmax):
+        """capture with the cyclic garbage collector parked: a collection that runs INSIDE a stream capture may destroy the hipGraph /
+        device tensors of an earlier step object (reference cycles through autograd nodes keep them until the collector runs), and the
+        runtime aborts the process on such a call while a capture is open (seen in the GPU suite: "Fatal Python error: Aborted",
+        Garbage-collecting, under test_deferred_weight_gradient_reductions_are_bit_identical).  Collected once up front instead."""
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._capture_impl(clips, mask, targets, tmax)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_impl(self, clips, mask, targets, tmax):
         from .criterion import PaddedTargets
         from .misc import NestedTensor
         model, crit, opt = self.model, self.criterion, self.optimizer
