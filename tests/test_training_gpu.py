@@ -546,7 +546,7 @@ def _ab_names():
 # tiny batch training-mode BatchNorm amplifies a one-ulp activation change through the whole body (the default path against itself
 # is bit-stable; these three measure median 4-7 % / p99 20-50 % on the gradients), so they are held tightly on the eval-mode outputs
 # and to the chaos level on the training gradients; every other switch only regroups launches and measures <= 8 % on single tensors.
-_AB_FORWARD = {"dw_register_tiled", "no_blockout_conv1", "no_entry_conv"}
+_AB_FORWARD = {"dw_register_tiled", "no_blockout_conv1", "no_entry_conv", "no_decoder_coop"}
 
 
 @pytest.mark.parametrize("name", _ab_names())
@@ -580,3 +580,81 @@ def test_every_ab_switch_reproduces_the_default_path(dev, name):
     for n in b0:
         assert torch.allclose(b0[n], b1[n], rtol=2e-2 if fwd else 1e-5, atol=2e-3 if fwd else 1e-6), n
     print("TUBER_AB=%s: loss %.6f vs %.6f, median / worst gradient relerr %.2e / %.2e (%s)" % (name, l1, l0, med, rels[0][0], rels[0][1]))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 5: the decoder stack as ONE cooperative launch (csrc/decoder_coop.hip) against the launch chain it replaces
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dropout", [False, True])
+def test_cooperative_decoder_launch_equals_the_launch_chain(dev, dropout):
+    """tuber_decoder_coop_fwd fills the tensors a DRY run of the decoder's op sequence allocated (tape.Tape.dry), so the launch chain's
+    backward closures run on them unchanged.  Held against ``TUBER_AB=no_decoder_coop`` on the same model / inputs / seed:
+    * eval outputs within bf16 rounding of the chain's (other accumulation order in linear2 and the self-attention, same rounding points);
+    * training forward WITH dropout on: the fused kernel draws the chain's masks (same seed, salts, element indices) -- a wrong stream
+      would move the outputs by O(0.1), not by bf16 noise;
+    * every parameter gradient of a smooth surrogate loss: median relative difference <= 2e-2, no tensor above 0.3, norms within 10 %;
+    * the synchronisation words are zero after every launch (no barrier timed out, the last workgroup out reset them), also on the
+      second and third launch and from a captured hipGraph."""
+    from parity_util import surrogate
+    from tubelet_transformer_amd import ab, lib
+
+    def run(names):
+        with ab.override(*names):
+            cfg, model, crit = _model("TubeR_CSN152_AVA21.yaml", dev, dropout=dropout)
+            store, _ = model.engine()
+            assert lib.query("tuber_decoder_coop_supported", 256, 8, 2048, 2, 15, 6) == 1
+            clips = synth.synthetic_clips(2, 32, 64, 96, seed=21, device=dev)
+            model.eval()
+            with torch.no_grad():
+                ev = {k: v.detach().float().clone() for k, v in model(clips).items() if k in ("pred_logits", "pred_boxes", "pred_logits_b")}
+            model.train()
+            res = []
+            for rep in range(2):                                  # twice: the second launch finds the words the first one left
+                store.manual_seed(1234)
+                store.zero_grad()
+                out = model(clips)
+                tr = {k: v.detach().float().clone() for k, v in out.items() if k in ("pred_logits", "pred_boxes", "pred_logits_b")}
+                loss = surrogate(out)
+                loss.backward()
+                torch.cuda.synchronize()
+                grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+                res.append((tr, grads))
+            sync = store.coop_sync.cpu().tolist()
+            assert sync == [0, 0, 0, 0], sync
+            for k in res[0][0]:
+                assert torch.equal(res[0][0][k], res[1][0][k]), "the same step twice must be bit-identical (%s)" % k
+            g = None
+            if not names:
+                # the launch inside a captured graph
+                g = torch.cuda.CUDAGraph()
+                model.eval()
+                static = clips.clone()
+                with torch.no_grad():
+                    model(static)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        go = model(static)
+                    g.replay(); g.replay()
+                    torch.cuda.synchronize()
+                for k in ev:
+                    assert torch.equal(go[k].float(), ev[k]), k
+                assert store.coop_sync.cpu().tolist() == [0, 0, 0, 0]
+            return ev, res[0][0], res[0][1]
+    e1, t1, g1 = run(())
+    e0, t0, g0 = run(("no_decoder_coop",))
+    for k in e0:
+        err, terr = float((e1[k] - e0[k]).abs().max()), float((t1[k] - t0[k]).abs().max())
+        print("cooperative decoder vs launch chain, dropout %s: %-14s eval max |diff| %.3e   train max |diff| %.3e  (|value| max %.2f)" % (
+            dropout, k, err, terr, float(e0[k].abs().max())))
+        assert err <= 2e-2 and terr <= (6e-2 if dropout else 3e-2), (k, err, terr)
+    rels = []
+    for n in g0:
+        den = float(g0[n].norm())
+        if den < 1e-12:
+            continue
+        rels.append((float((g1[n] - g0[n]).norm()) / den, n))
+        assert 0.9 < float(g1[n].norm()) / den < 1.1, (n, float(g1[n].norm()) / den)
+    rels.sort(reverse=True)
+    med = rels[len(rels) // 2][0]
+    print("   gradients: median relative difference %.3e, worst %.3e (%s) over %d tensors" % (med, rels[0][0], rels[0][1], len(rels)))
+    assert med <= 2e-2 and rels[0][0] <= 0.3, (med, rels[:3])

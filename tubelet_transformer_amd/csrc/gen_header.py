@@ -26,6 +26,15 @@ DOC = {
                           "whose pointers travel by value (HOST arrays boxes[B], labels[B], sizes[B]); zero padding included. Replaces the two memsets + two sliced "
                           "copies per clip the captured step issued before every replay.",
     "tuber_targets_pack_max": "largest B tuber_targets_pack accepts.",
+    "tuber_decoder_coop_fwd": "the DETR decoder stack forward (TransformerDecoder.forward / TransformerDecoderLayer.forward_post, models/transformer/transformer.py:99-128,"
+                              "218-249) as ONE cooperative launch: 16 workgroups on one XCD split every weight matrix by output columns, exchange the <= 32 x 256 activations "
+                              "through that XCD's L2 and meet at 8 XCD-local barriers per layer. layer_ptrs: HOST array, tuber_decoder_coop_ptrs_per_layer() device pointers per "
+                              "layer (6 bf16 weights: self in-proj, self out-proj, cross q rows, cross out-proj, linear1, linear2; their 6 fp32 biases; norm1 / norm2 / norm3 weight, "
+                              "bias; the layer's packed memory projection [(memory + pos) W_k | memory W_v]; then the 21 tensors the launch chain saves for its backward: qkv, o1, lse1, "
+                              "a1, y1, xhat1, rstd1, q, o2, lse2, a2, y2, xhat2, rstd2, h, f2, y3, xhat3, rstd3, xhatN, rstdN). layer_salts: HOST array, 6 dropout salts per layer. "
+                              "sync: 4 zeroed 32-bit device words, left zero by a clean run; sync[2] != 0 afterwards = a barrier timed out (results invalid).",
+    "tuber_decoder_coop_supported": "1 when tuber_decoder_coop_fwd takes this decoder (d_model 256, 8 heads, FFN 2048, batch * 8 == 16 attention units, batch * queries <= 32, <= 6 layers).",
+    "tuber_decoder_coop_ptrs_per_layer": "device pointers per layer in tuber_decoder_coop_fwd's layer_ptrs (40).",
     "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "
                          "clip padding mask to the feature grid = the transformer's key-padding mask, ATen's source-index rule.",
     "tuber_gemm_nt_join": "conv1 data gradient of one bottleneck fused with the join backward of the bottleneck below it: dz = (A.B^T + R) * [Y > 0] "

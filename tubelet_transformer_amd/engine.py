@@ -222,6 +222,8 @@ class ParamStore:
         self.reducer = None              # ddp.FlatGradReducer when gradients are all-reduced (attach_reducer)
         # dropout seed lives in DEVICE memory (read by the kernels), so a captured hipGraph draws new masks every replay
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # tuber_decoder_coop_fwd's synchronisation words (arrival counter, XCC census, error word, departure counter): zero between launches
+        self.coop_sync = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.defer = DeferredReduce(self.device)
         self.wq = WgradQueue(self)
         self.defer.pre_flush = self.wq.flush

@@ -53,6 +53,8 @@ class Tape:
         self.mask = {}         # id(h) -> 1/(1-p): h = Dropout(ReLU(.)) whose backward mask the consumer's dgrad GEMM applies
         self.premasked = set()
         self.stack = {}        # id(tensor) -> list of gradient tensors summed lazily by the producer's backward
+        self.dry = False       # dry run: the ops allocate their outputs, draw their dropout salts and record their backward closures, but do
+        self.dry_log = []      # not launch the forward kernel -- (kind, dict) per op, for a fused launch that fills those outputs (tuber.py)
         self.req = set()       # ids of tensors whose gradient is needed (they depend on a trainable parameter): the backward pass
         #                        skips weight gradients of frozen parameters and data gradients nobody consumes, like autograd does
 
@@ -130,8 +132,11 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
     y = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF, device=dev)
     p = float(drop)
     salt = tp.salt() if p > 0.0 else 0
-    lib.call("tuber_gemm_nt", x, K, wb, K, y, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-             0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt, None, 0, None)
+    if tp.dry:
+        tp.dry_log.append(("linear", dict(x=x, y=y, w=wb, b=bias, relu=relu, p=p, salt=salt, out_f32=out_f32)))
+    else:
+        lib.call("tuber_gemm_nt", x, K, wb, K, y, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 0, bias, None, 0, 1 if relu else 0, 1 if out_f32 else 0, None, None, None, 0, None, None, 1.0, p, st.seed, salt, None, 0, None)
     if not tp.train:
         return y
     wreq = st.trainable(wname)
@@ -248,7 +253,10 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
     wb = st.shadow.data_ptr() + 2 * (st.offsets[wname] + r0 * K)
     bias = st.flat.data_ptr() + 4 * (st.offsets[bname] + r0)
     y = torch.empty(M, N, dtype=BF, device=dev)
-    lib.call("tuber_gemm_nt_addproj", x, K, addend, K, add_cols, wb, K, y, N, M, N, K, bias)
+    if tp.dry:
+        tp.dry_log.append(("in_proj", dict(x=x, addend=addend, y=y, w=wb, b=bias, add_cols=add_cols)))
+    else:
+        lib.call("tuber_gemm_nt_addproj", x, K, addend, K, add_cols, wb, K, y, N, M, N, K, bias)
     if not tp.train:
         return y
     wreq, breq = st.trainable(wname), st.trainable(bname)
@@ -350,7 +358,10 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
     salt = tp.salt() if p > 0.0 else 0
     xhat = torch.empty(M, E, dtype=BF, device=dev) if tp.train else None
     rstd = torch.empty(M, dtype=torch.float32, device=dev) if tp.train else None
-    lib.call("tuber_layernorm_fwd", x, res, gamma, beta, yptr, ldy, xhat, rstd, M, E, 1e-5, p, st.seed, salt)
+    if tp.dry:
+        tp.dry_log.append(("layer_norm", dict(x=x, res=res, yptr=yptr, ldy=ldy, xhat=xhat, rstd=rstd, gamma=gamma, beta=beta, p=p, salt=salt)))
+    else:
+        lib.call("tuber_layernorm_fwd", x, res, gamma, beta, yptr, ldy, xhat, rstd, M, E, 1e-5, p, st.seed, salt)
     if not tp.train:
         return y
     preq = st.trainable(prefix + ".weight") or st.trainable(prefix + ".bias")
@@ -412,8 +423,11 @@ def attention(tp, roles, geom, kpm, pdrop, *tensors):
     scale = 32 ** -0.5
     p = float(pdrop)
     salt = tp.salt()
-    lib.call("tuber_attn_fwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
-             tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(p), st.seed, salt)
+    if tp.dry:
+        tp.dry_log.append(("attention", dict(tensors=tensors, roles=roles, o=o, lse=lse, kpm=kpm, geom=geom, p=p, salt=salt)))
+    else:
+        lib.call("tuber_attn_fwd", tq.data_ptr() + 2 * qo, mq.ctypes.data, tk.data_ptr() + 2 * ko, mk.ctypes.data,
+                 tv.data_ptr() + 2 * vo, mv.ctypes.data, o, mo.ctypes.data, lse, kpm, B, H, Lq, Lk, scale, float(p), st.seed, salt)
     if not tp.train:
         return o
     treq = [tp.needs(t) for t in tensors]

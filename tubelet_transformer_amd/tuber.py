@@ -17,7 +17,7 @@ import copy
 import torch
 from torch import nn
 
-from . import lib
+from . import ab, lib
 from . import tape as T
 from .backbone import build_CSN, CSNRunner
 from .engine import ParamStore
@@ -223,6 +223,44 @@ class DETR(nn.Module):
         h = T.linear(tp, x, prefix + ".linear1.weight", prefix + ".linear1.bias", relu=True, drop=p)
         return T.linear(tp, h, prefix + ".linear2.weight", prefix + ".linear2.bias")
 
+    def _decoder_coop_launch(self, st, log, kvs, qpos, hs, kpm, B, Q, Lm, lay_n, pdrop, pattn):
+        """tuber_decoder_coop_fwd over what the dry run of the decoder's op sequence logged (12 ops per layer: in-proj, attention, out-proj,
+        norm1, q-proj, attention, out-proj, norm2, linear1, linear2, norm3, decoder.norm)."""
+        import ctypes
+        assert len(log) == 12 * lay_n, len(log)
+        dev = st.device
+        ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+        scratch = []
+
+        def ln(d, with_y=True):
+            xh, rs = d["xhat"], d["rstd"]
+            if xh is None:                                      # eval: nothing is saved, the kernel still writes somewhere
+                xh, rs = torch.empty(B * Q, self.hidden_dim, dtype=BF, device=dev), torch.empty(B * Q, dtype=torch.float32, device=dev)
+                scratch.extend((xh, rs))
+            return ([d["yptr"]] if with_y else []) + [ptr(xh), ptr(rs)]
+        ptrs, salts = [], []
+        for i in range(lay_n):
+            o = [d for _, d in log[12 * i: 12 * i + 12]]
+            kinds = [k for k, _ in log[12 * i: 12 * i + 12]]
+            assert kinds == ["in_proj", "attention", "linear", "layer_norm", "in_proj", "attention", "linear", "layer_norm", "linear", "linear",
+                             "layer_norm", "layer_norm"], kinds
+            w = [o[0]["w"], o[2]["w"], o[4]["w"], o[6]["w"], o[8]["w"], o[9]["w"]]
+            b = [o[0]["b"], o[2]["b"], o[4]["b"], o[6]["b"], o[8]["b"], o[9]["b"]]
+            lnp = [o[3]["gamma"], o[3]["beta"], o[7]["gamma"], o[7]["beta"], o[10]["gamma"], o[10]["beta"]]
+            saved = ([ptr(o[0]["y"]), ptr(o[1]["o"]), ptr(o[1]["lse"]), ptr(o[2]["y"])] + ln(o[3]) +
+                     [ptr(o[4]["y"]), ptr(o[5]["o"]), ptr(o[5]["lse"]), ptr(o[6]["y"])] + ln(o[7]) +
+                     [ptr(o[8]["y"]), ptr(o[9]["y"])] + ln(o[10]) + ln(o[11], with_y=False))
+            ptrs += w + b + lnp + [ptr(kvs[i])] + saved
+            salts += [o[1]["salt"], o[3]["salt"], o[5]["salt"], o[7]["salt"], o[8]["salt"], o[10]["salt"]]
+        n = lib.query("tuber_decoder_coop_ptrs_per_layer")
+        assert len(ptrs) == n * lay_n, (len(ptrs), n)
+        P = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        S = (ctypes.c_ulonglong * len(salts))(*salts)
+        gN = st.flat.data_ptr() + 4 * st.offsets["transformer.decoder.norm.weight"]
+        eN = st.flat.data_ptr() + 4 * st.offsets["transformer.decoder.norm.bias"]
+        lib.call("tuber_decoder_coop_fwd", P, S, lay_n, qpos, gN, eN, hs, kpm, B, Q, Lm, float(pdrop), float(pattn), st.seed, st.coop_sync)
+        del scratch
+
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, samples):
         if not isinstance(samples, NestedTensor):
@@ -296,18 +334,33 @@ class DETR(nn.Module):
         tgt = torch.zeros(B * Q, E, dtype=BF, device=dev)
         lay_n = self.transformer.decoder.num_layers
         hs = torch.empty(lay_n * B * Q, E, dtype=BF, device=dev)                    # rows (layer, b, q)
-        for i in range(lay_n):
-            L = "transformer.decoder.layers.%d" % i
-            a = self._mha_self(tp, tgt, qpos, L + ".self_attn", B, Q, None, pattn)
-            tgt = T.layer_norm(tp, a, tgt, L + ".norm1", drop=pdrop)
-            P = L + ".multihead_attn"
-            q = T.in_proj(tp, tgt, qpos, P + ".in_proj_weight", P + ".in_proj_bias", (0, E), E)                  # (tgt + query_pos) W_q
-            kv = T.in_proj(tp, memory, pos, P + ".in_proj_weight", P + ".in_proj_bias", (E, 3 * E), E)          # [(memory + pos) W_k | memory W_v]
-            a = T.attention(tp, ((0, 0), (1, 0), (1, E)), (B, H, Q, Lm, (1, Q, 0, 1), (1, Lm, 0, 1)), kpm, pattn, q, kv)
-            a = T.linear(tp, a, P + ".out_proj.weight", P + ".out_proj.bias")
-            tgt = T.layer_norm(tp, a, tgt, L + ".norm2", drop=pdrop)
-            tgt = T.layer_norm(tp, self._ffn(tp, tgt, L, pdrop), tgt, L + ".norm3", drop=pdrop)
-            T.layer_norm(tp, tgt, None, "transformer.decoder.norm", out=(hs, i * B * Q, 0))
+        coop = (not ab.on("no_decoder_coop") and lib.query("tuber_decoder_coop_supported", E, H, self.transformer.decoder.layers[0].linear1.out_features, B, Q, lay_n) == 1)
+        if coop:
+            # the decoder stack as ONE cooperative launch (csrc/decoder_coop.hip): the memory-side projections first (they do not depend on
+            # the decoder state), then a DRY run of the same op sequence -- it allocates every saved tensor, draws the dropout salts and
+            # records the backward closures of the launch chain -- and the fused kernel fills what the dry run allocated
+            kvs = []
+            for i in range(lay_n):
+                P = "transformer.decoder.layers.%d.multihead_attn" % i
+                kvs.append(T.in_proj(tp, memory, pos, P + ".in_proj_weight", P + ".in_proj_bias", (E, 3 * E), E))
+            tp.dry, tp.dry_log = True, []
+        try:
+            for i in range(lay_n):
+                L = "transformer.decoder.layers.%d" % i
+                a = self._mha_self(tp, tgt, qpos, L + ".self_attn", B, Q, None, pattn)
+                tgt = T.layer_norm(tp, a, tgt, L + ".norm1", drop=pdrop)
+                P = L + ".multihead_attn"
+                q = T.in_proj(tp, tgt, qpos, P + ".in_proj_weight", P + ".in_proj_bias", (0, E), E)                  # (tgt + query_pos) W_q
+                kv = kvs[i] if coop else T.in_proj(tp, memory, pos, P + ".in_proj_weight", P + ".in_proj_bias", (E, 3 * E), E)          # [(memory + pos) W_k | memory W_v]
+                a = T.attention(tp, ((0, 0), (1, 0), (1, E)), (B, H, Q, Lm, (1, Q, 0, 1), (1, Lm, 0, 1)), kpm, pattn, q, kv)
+                a = T.linear(tp, a, P + ".out_proj.weight", P + ".out_proj.bias")
+                tgt = T.layer_norm(tp, a, tgt, L + ".norm2", drop=pdrop)
+                tgt = T.layer_norm(tp, self._ffn(tp, tgt, L, pdrop), tgt, L + ".norm3", drop=pdrop)
+                T.layer_norm(tp, tgt, None, "transformer.decoder.norm", out=(hs, i * B * Q, 0))
+        finally:
+            log, tp.dry, tp.dry_log = tp.dry_log, False, []
+        if coop:
+            self._decoder_coop_launch(st, log, kvs, qpos, hs, kpm, B, Q, Lm, lay_n, pdrop, pattn)
 
         # ---- heads (tuber_ava.py:121-125,142) ----
         if self.dataset_mode == "ava":
