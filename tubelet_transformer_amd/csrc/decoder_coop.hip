@@ -77,9 +77,12 @@ __device__ __forceinline__ void coop_barrier(Ctx& c) {
         const unsigned target = (c.phase + 1) * G;
         // bounded: ~0.1 s, then the error word is raised and every later barrier of every workgroup falls through at once
         if (c.same_xcd) {
-            __hip_atomic_fetch_add(c.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // executes in the XCD's L2
+            // arrival: an atomic that executes in the L2; poll: a relaxed AGENT-scope load (= an sc1 load: served by the L2, never by this CU's L1
+            // -- a workgroup-scope "fetch_add 0" poll is folded into a plain load by the compiler and re-reads a stale L1 line: 130 us per
+            // barrier in the first version of this kernel)
+            __hip_atomic_fetch_add(c.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spins = 0;
-            while (__hip_atomic_fetch_add(c.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            while (__hip_atomic_load(c.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 1023) == 0 && (spins > 1000000 || __hip_atomic_load(c.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     __hip_atomic_store(c.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
