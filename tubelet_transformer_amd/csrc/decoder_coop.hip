@@ -113,13 +113,14 @@ __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __bui
 // acc[rt] += W[col0 + li][k0 .. k0 + KS*32) . X^T for the two 16-row activation tiles: weights straight from the row-major bf16 matrix
 // (one 16-byte load per lane and k-step = the MFMA A fragment), activations from an LDS image (XL = true) or from global rows.
 // Issued swapped (weights = A operand), so lane (li, g) ends with acc[rt][r] = out[row rt*16 + li][col0 + g*4 + r].
-template <int KS, bool XL>
-__device__ __forceinline__ void gemm_cols(const bf16* __restrict__ W, long ldw, int col0, int k0, const bf16* X, long ldx, int rows_ok,
-                                          int li, int g, f32x4 (&acc)[2]) {
-    uint4 wf[KS];
+template <int KS>
+__device__ __forceinline__ void wload(const bf16* __restrict__ W, long ldw, int col0, int k0, int li, int g, uint4 (&wf)[KS]) {
     const bf16* wp = W + (long)(col0 + li) * ldw + k0 + g * 8;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) wf[kk] = *(const uint4*)(wp + kk * 32);
+}
+template <int KS, bool XL>
+__device__ __forceinline__ void wmma(const uint4 (&wf)[KS], int k0, const bf16* X, long ldx, int rows_ok, int li, int g, f32x4 (&acc)[2]) {
     uint4 xf[2][KS];
     if constexpr (!XL) {
 #pragma unroll
@@ -138,6 +139,13 @@ __device__ __forceinline__ void gemm_cols(const bf16* __restrict__ W, long ldw, 
             acc[rt] = mma(as_bf16x8(wf[kk]), x, acc[rt]);
         }
     }
+}
+template <int KS, bool XL>
+__device__ __forceinline__ void gemm_cols(const bf16* __restrict__ W, long ldw, int col0, int k0, const bf16* X, long ldx, int rows_ok,
+                                          int li, int g, f32x4 (&acc)[2]) {
+    uint4 wf[KS];
+    wload<KS>(W, ldw, col0, k0, li, g, wf);
+    wmma<KS, XL>(wf, k0, X, ldx, rows_ok, li, g, acc);
 }
 
 // out[r][col0 + g*4 .. +3] = bf16(f(acc + bias)) for the rows r < R this lane holds
@@ -171,14 +179,26 @@ __device__ __forceinline__ void store_cols(const f32x4 (&acc)[2], const float* _
 // into the LDS image `dst` (bf16, what the launch chain would have stored and re-read); `save`: also to y / xhat / rstd in global.
 template <bool DROP>
 __device__ __forceinline__ void ln_rows(const bf16* __restrict__ x, const bf16* resl, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                        bf16* dst, int R, bool save, bf16* __restrict__ y, long ldy, bf16* __restrict__ xhat, float* __restrict__ rstd_out,
-                                        uint64_t seed, uint32_t thresh, float inv_keep, bool x_is_lds) {
+                                        bf16* dst, int R, int save_j, bf16* __restrict__ y, long ldy, bf16* __restrict__ xhat, float* __restrict__ rstd_out,
+                                        uint64_t seed, uint32_t thresh, float inv_keep, bool x_is_lds, bool only_mine = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane * 4;
     const float4 gq = *(const float4*)(gamma + col), bq = *(const float4*)(beta + col);
     const float gg[4] = {gq.x, gq.y, gq.z, gq.w}, bb[4] = {bq.x, bq.y, bq.z, bq.w};
-    for (int row = wave; row < R; row += NT / 64) {
-        const bf16x4 a = as_bf16x4(x_is_lds ? *(const uint2*)(x + (long)row * PX + col) : *(const uint2*)(x + (long)row * E + col));
+    // the wave's rows (wave, wave + 4, ...: at most 8) are fetched TOGETHER: one row per trip exposed one L2 round trip per row (~0.8 us x 8)
+    uint2 xin[MR / 4];
+#pragma unroll
+    for (int i = 0; i < MR / 4; ++i) {
+        const int row = min(wave + 4 * i, R - 1);
+        xin[i] = x_is_lds ? *(const uint2*)(x + (long)row * PX + col) : *(const uint2*)(x + (long)row * E + col);
+    }
+#pragma unroll
+    for (int i = 0; i < MR / 4; ++i) {
+        const int row = wave + 4 * i;
+        if (row >= R) break;
+        const bool save = (row & (G - 1)) == save_j;             // workgroup j stores rows j and j + 16
+        if (only_mine && !save) continue;
+        const bf16x4 a = as_bf16x4(xin[i]);
         bf16x4 r = bf16x4{};
         if (resl) r = as_bf16x4(*(const uint2*)(resl + (long)row * PX + col));
         bool keep[4] = {true, true, true, true};
@@ -205,7 +225,7 @@ __device__ __forceinline__ void ln_rows(const bf16* __restrict__ x, const bf16* 
             xh[e] = f2bf(hh);
             o[e] = f2bf(fmaf(hh, gg[e], bb[e]));
         }
-        *(uint2*)(dst + (long)row * PX + col) = as_uint2(o);
+        if (dst) *(uint2*)(dst + (long)row * PX + col) = as_uint2(o);
         if (save) {
             if (y) *(uint2*)(y + (long)row * ldy + col) = as_uint2(o);
             *(uint2*)(xhat + (long)row * E + col) = as_uint2(xh);
@@ -255,13 +275,17 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
     at.kpm = nullptr; at.B = a.B; at.H = NH; at.Lq = a.Q; at.scale = 0.17677669529663687f;     // 32 ** -0.5
     at.pdrop = DROP ? a.pattn : 0.f; at.thresh = (uint32_t)((double)at.pdrop * 4294967296.0); at.seed_ptr = a.seed_ptr;
 
+    uint4 win_next[8];                                            // this wave's in-projection weight tile of the coming layer
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) win_next[kk] = make_uint4(0, 0, 0, 0);
     for (int l = 0; l < a.nl; ++l) {
         const DLayer& W = a.L[l];
         // ---- A: packed self-attention in-projection: q | k rows see tgt + query_pos, v rows see tgt (tape.in_proj) ----
         if (wave < 3) {
             const int t = wave * G + j;                           // 48 column tiles of 16: tile t
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            gemm_cols<8, true>(W.w_in, E, t * 16, 0, t < 32 ? XPs : Xs, PX, R, li, g, acc);
+            if (l == 0) wload<8>(W.w_in, E, t * 16, 0, li, g, win_next);
+            wmma<8, true>(win_next, 0, t < 32 ? XPs : Xs, PX, R, li, g, acc);
             store_cols<false, false>(acc, W.b_in, W.qkv, 3 * E, 3 * E, t * 16, R, li, g, 0, 0, 1.f);
         }
         coop_barrier(c);
@@ -272,6 +296,8 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
         at.O = W.o1; at.mo = tmap(E, 1, a.Q);
         at.lse = W.lse1; at.kpm = nullptr; at.Lk = a.Q; at.salt = W.salt_a1;
         attn_mfma_fwd_body<true>(at, 0, uh, ub);
+        // (measured and rejected: fetching the weights of the next GEMM stage BEFORE the barrier that starts it -- the barrier's own
+        // store drain then waits for them: out-proj 4.0 -> 3.3 us, but the attention stages + 1 us and linear1 / linear2 + 2.3 / + 3.8 us)
         coop_barrier(c);
         // ---- C: self-attention out-projection (column tile j; the operand rows come straight from global) ----
         if (wave == 0) {
@@ -281,7 +307,9 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
         }
         coop_barrier(c);
         // ---- D: norm1 (every workgroup, workgroup 0 saves) + cross-attention q-projection of tgt + query_pos ----
-        ln_rows<DROP>(W.a1, Xs, W.g1, W.e1, Xs, R, j == 0, W.y1, E, W.xh1, W.rs1, seed0 + W.salt_n1, th, ik, false);
+        uint4 wq[8];
+        if (wave == 0) wload<8>(W.w_q, E, j * 16, 0, li, g, wq);           // the weight fetch runs under the LayerNorm
+        ln_rows<DROP>(W.a1, Xs, W.g1, W.e1, Xs, R, j, W.y1, E, W.xh1, W.rs1, seed0 + W.salt_n1, th, ik, false);
         __syncthreads();
         for (int i = tid; i < MR * (E / 8); i += NT) {            // XPs = bf16(tgt + query_pos), as gemm_nt's A_ADD operand forms it
             const int r = i / (E / 8), q8 = (i % (E / 8)) * 8;
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
         __syncthreads();
         if (wave == 0) {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            gemm_cols<8, true>(W.w_q, E, j * 16, 0, XPs, PX, R, li, g, acc);
+            wmma<8, true>(wq, 0, XPs, PX, R, li, g, acc);
             store_cols<false, false>(acc, W.b_q, W.q, E, E, j * 16, R, li, g, 0, 0, 1.f);
         }
         coop_barrier(c);
@@ -314,21 +342,27 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
         }
         coop_barrier(c);
         // ---- G: norm2 + FFN linear1 (ReLU, Dropout): hidden columns [j * 128, j * 128 + 128), two tiles per wave ----
-        ln_rows<DROP>(W.a2, Xs, W.g2, W.e2, Xs, R, j == 0, W.y2, E, W.xh2, W.rs2, seed0 + W.salt_n2, th, ik, false);
+        uint4 wf1[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wload<8>(W.w_f1, E, j * 128 + (wave * 2 + u) * 16, 0, li, g, wf1[u]);      // both tiles' weights under the LayerNorm
+        ln_rows<DROP>(W.a2, Xs, W.g2, W.e2, Xs, R, j, W.y2, E, W.xh2, W.rs2, seed0 + W.salt_n2, th, ik, false);
         __syncthreads();
-#pragma unroll 1
+#pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int col0 = j * 128 + (wave * 2 + u) * 16;
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            gemm_cols<8, true>(W.w_f1, E, col0, 0, Xs, PX, R, li, g, acc);
+            wmma<8, true>(wf1[u], 0, Xs, PX, R, li, g, acc);
             store_cols<true, DROP>(acc, W.b_f1, W.h, FF, FF, col0, R, li, g, seed0 + W.salt_f, th, ik);
         }
         coop_barrier(c);
         // ---- H: FFN linear2, column tile j; the four waves take K = 2048 in quarters and are summed in wave order ----
         {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-            for (int kq = 0; kq < 2; ++kq) gemm_cols<8, false>(W.w_f2, FF, j * 16, wave * 512 + kq * 256, W.h, FF, R, li, g, acc);
+            uint4 w2[2][8];
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) wload<8>(W.w_f2, FF, j * 16, wave * 512 + kq * 256, li, g, w2[kq]);      // all 16 fragments in flight together
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) wmma<8, false>(w2[kq], wave * 512 + kq * 256, W.h, FF, R, li, g, acc);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) *(f32x4*)(red + ((wave * 2 + rt) * 64 + lane) * 4) = acc[rt];
             __syncthreads();
@@ -345,10 +379,13 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
         }
         coop_barrier(c);
         // ---- I: norm3 -> the next layer's tgt; decoder.norm of it -> hs[l] (workgroup 0 saves both) ----
-        ln_rows<DROP>(W.f2, Xs, W.g3, W.e3, Xs, R, j == 0, W.y3, E, W.xh3, W.rs3, seed0 + W.salt_n3, th, ik, false);
+        uint4 win[8];
+        const bool more = l + 1 < a.nl;
+        if (more && wave < 3) wload<8>(a.L[l + 1].w_in, E, (wave * G + j) * 16, 0, li, g, win);      // the next in-projection's weights under the LayerNorms
+        ln_rows<DROP>(W.f2, Xs, W.g3, W.e3, Xs, R, j, W.y3, E, W.xh3, W.rs3, seed0 + W.salt_n3, th, ik, false);
         __syncthreads();
-        if (j == 0) ln_rows<false>(Xs, nullptr, a.gN, a.eN, XPs, R, true, a.hs + (long)l * R * E, E, W.xhN, W.rsN, 0, 0, 1.f, true);   // (XPs: scratch, rebuilt below)
-        __syncthreads();
+        // decoder.norm of rows j and j + 16 only (hs, xhat, rstd go to global; no workgroup needs the result)
+        ln_rows<false>(Xs, nullptr, a.gN, a.eN, nullptr, R, j, a.hs + (long)l * R * E, E, W.xhN, W.rsN, 0, 0, 1.f, true, true);
         for (int i = tid; i < MR * (E / 8); i += NT) {
             const int r = i / (E / 8), q8 = (i % (E / 8)) * 8;
             const bf16x8 x = as_bf16x8(*(const uint4*)(Xs + r * PX + q8)), p = as_bf16x8(*(const uint4*)(QPs + r * PX + q8));
@@ -358,6 +395,10 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
             *(uint4*)(XPs + r * PX + q8) = as_uint4(y);
         }
         __syncthreads();
+        if (more && wave < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) win_next[kk] = win[kk];
+        }
     }
     // ---- leave the synchronisation words zero for the next launch: a workgroup may still be re-reading the arrival counter of the last
     // barrier when the first ones are through, so departures are counted and the LAST workgroup out resets the words ----
