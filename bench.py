@@ -552,6 +552,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
+    model.engine()[0].check_coop()            # a timed-out barrier of the cooperative decoder launch would have invalidated the steps
     ms = 1e3 * dt / args.steps
     total_clips = args.batch * world * args.steps
     headline = args.config == "TubeR_CSN152_AVA21.yaml" and hw == (256, 340)

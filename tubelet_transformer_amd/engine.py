@@ -285,6 +285,16 @@ class ParamStore:
         if train:
             self.seed.add_(1)
 
+    def check_coop(self):
+        """host-side check (one 16-byte device read: call it where the loop synchronises anyway) of the cooperative decoder launch's
+        error word: a barrier of tuber_decoder_coop_fwd that could not complete within its spin bound leaves it set -- the step's results
+        are invalid then.  Raises, after clearing the words so that a retry with TUBER_AB=no_decoder_coop starts clean."""
+        w = self.coop_sync.cpu().tolist()
+        if w[2]:
+            self.coop_sync.zero_()
+            raise RuntimeError("tuber_decoder_coop_fwd: a workgroup barrier timed out (sync words %s); results of the affected steps are invalid -- "
+                               "set TUBER_AB=no_decoder_coop to run the decoder as separate launches" % w)
+
     def manual_seed(self, seed):
         self.seed.fill_(int(seed))
 

@@ -459,6 +459,7 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
         nonfinite = torch.where((nonfinite[:1] == 0) & bad, torch.tensor([1.0, idx + 1.0], device=bad.device), nonfinite)
         if idx % print_freq == 0:
             _raise_if_nonfinite(nonfinite, loss_dict, epoch, idx, rank, world, _dist)
+            model.engine()[0].check_coop()
         if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
             avg = meters.averages()
             lr = optimizer.param_groups[-1]["lr"]
@@ -478,6 +479,7 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
         end = time.time()
     if nonfinite is not None:
         _raise_if_nonfinite(nonfinite, loss_dict, epoch, n_iter - 1, rank, world, _dist)
+        model.engine()[0].check_coop()
     return loss
 
 
