@@ -565,12 +565,19 @@ def test_every_ab_switch_reproduces_the_default_path(dev, name):
     assert math.isfinite(l1) and abs(l1 - l0) <= (6e-2 if fwd else 1e-4) * max(abs(l0), 1.0), (l0, l1)
     assert set(g0) == set(g1)
     rels = []
+    gmax = max(float(v.norm()) for v in g0.values())
     for n in g0:
         den = float(g0[n].norm())
         if den < 1e-12:
             continue
-        rels.append((float((g1[n] - g0[n]).norm()) / den, n))
-        assert 0.5 < float(g1[n].norm()) / den < 2.0, n
+        # a gradient that is numerically zero (norm below 1e-4 of the largest tensor's: layer 0's self-attention in-projection -- tgt = 0, so
+        # its true gradient vanishes -- is bf16 rounding noise of the attention backward) is held to that floor, not to itself
+        floor = 1e-4 * gmax
+        rels.append((float((g1[n] - g0[n]).norm()) / max(den, floor), n))
+        if den > floor:
+            assert 0.5 < float(g1[n].norm()) / den < 2.0, n
+        else:
+            assert float(g1[n].norm()) <= 2.0 * floor, (n, float(g1[n].norm()), floor)
     rels.sort(reverse=True)
     med = rels[len(rels) // 2][0]
     if fwd:
@@ -655,10 +662,11 @@ def test_cooperative_decoder_launch_equals_the_launch_chain(dev, dropout):
         den = float(g0[n].norm())
         if den < 1e-12:
             continue
-        rels.append((float((g1[n] - g0[n]).norm()) / den, n))
+        rels.append((float((g1[n] - g0[n]).norm()) / max(den, 1e-4 * gmax), n))       # (numerically-zero gradients: see test_every_ab_switch_...)
         if den > 1e-3 * gmax:
             assert 0.9 < float(g1[n].norm()) / den < 1.1, (n, float(g1[n].norm()) / den)
     rels.sort(reverse=True)
     med = rels[len(rels) // 2][0]
-    print("   gradients: median relative difference %.3e, worst %.3e (%s) over %d tensors" % (med, rels[0][0], rels[0][1], len(rels)))
+    print("   gradients: median relative difference %.3e, worst %.3e (%s) over %d tensors; |grad| of layer 0's self-attention in-projection %.3e of the largest tensor's" % (
+        med, rels[0][0], rels[0][1], len(rels), float(g0["transformer.decoder.layers.0.self_attn.in_proj_weight"].norm()) / gmax))
     assert med <= 6e-2 and rels[0][0] <= 0.6, (med, rels[:3])

@@ -52,195 +52,9 @@ __device__ __forceinline__ float dot32(const float (&a)[32], const float (&b)[32
     return (s0 + s1) + (s2 + s3);
 }
 
-// Thread layout of the three main kernels: 256 threads = 16 rows x 16 "split" lanes; the 16 lanes of a row are an aligned
-// 16-lane group of one wave, so partial results are combined with xor-shuffles 1,2,4,8.  Splitting the key (or query)
-// loop over 16 lanes gives the small-batch calls of this model (B*H = 16, Lq = 15 tubelet queries) 16x more parallelism
-// than one-row-per-thread.  The other operand is staged through LDS in tiles of 64 rows (80-byte padded rows: the 16
-// lanes of a row read 16 different LDS rows conflict-free with ds_read_b128).
-#define KT 64
-#define KPAD 40
-__device__ __forceinline__ void stage_rows(bf16 (*dst)[KPAD], const bf16* base, const TokMap& m, int b, int h, int r0, int L) {
-    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;          // 64 rows x 4 chunks of 16 B = 256 threads
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < L) v = *(const uint4*)(base + tok_row(m, r0 + r, b) * m.ld + h * 32 + c * 8);
-    *(uint4*)&dst[r][c * 8] = v;
-}
-__device__ __forceinline__ void lds_row32(const bf16 (*src)[KPAD], int r, float (&v)[32]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16x8 t = as_bf16x8(*(const uint4*)&src[r][i * 8]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i * 8 + e] = bf2f(t[e]);
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[KT][KPAD];
-    __shared__ __attribute__((aligned(16))) bf16 vs[KT][KPAD];
-    __shared__ uint8_t msk[KT];
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), kl = threadIdx.x & 15;
-    const bool active = qi < a.Lq;
-    const int qc = active ? qi : a.Lq - 1;
-    float q[32], o[32];
-    load_row32(a.Q + tok_row(a.mq, qc, b) * a.mq.ld + h * 32, q);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] *= a.scale; o[d] = 0.f; }
-    float mx = -INFINITY, l = 0.f;
-    const float inv_keep = dropout_inv_keep(a.pdrop);
-    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
-    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
-    for (int k0 = 0; k0 < a.Lk; k0 += KT) {
-        __syncthreads();
-        stage_rows(ks, a.K, a.mk, b, h, k0, a.Lk);
-        stage_rows(vs, a.V, a.mv, b, h, k0, a.Lk);
-        if (threadIdx.x < KT) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < KT / 16; ++j) {
-            const int kk = kl + 16 * j;
-            if (msk[kk]) continue;
-            float kv[32];
-            lds_row32(ks, kk, kv);
-            const float sc = dot32(q, kv);
-            if (sc > mx) {
-                const float alpha = __expf(mx - sc);
-                l *= alpha;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) o[d] *= alpha;
-                mx = sc;
-            }
-            const float p = __expf(sc - mx);
-            l += p;
-            float pv = p;
-            if (a.pdrop > 0.f) pv = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? p * inv_keep : 0.f;
-            lds_row32(vs, kk, kv);
-#pragma unroll
-            for (int d = 0; d < 32; ++d) o[d] = fmaf(pv, kv[d], o[d]);
-        }
-    }
-    // combine the 16 partial softmaxes of this query row
-    float M = mx;
-    M = quad16_max(M);
-    const float f = mx == -INFINITY ? 0.f : __expf(mx - M);
-    l = quad16_sum(l * f);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] = quad16_sum(o[d] * f);
-    if (active && kl == 0) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) o[d] *= inv;
-        store_row32(a.O + tok_row(a.mo, qi, b) * a.mo.ld + h * 32, o);
-        if (a.lse) a.lse[((long)b * a.H + h) * a.Lq + qi] = M + __logf(l);
-    }
-}
-
-// dQ (and delta = dO . O for the dK/dV kernel): rows = queries, split = keys
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 ks[KT][KPAD];
-    __shared__ __attribute__((aligned(16))) bf16 vs[KT][KPAD];
-    __shared__ uint8_t msk[KT];
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), kl = threadIdx.x & 15;
-    const bool active = qi < a.Lq;
-    const int qc = active ? qi : a.Lq - 1;
-    float q[32], dov[32], dq[32];
-    load_row32(a.Q + tok_row(a.mq, qc, b) * a.mq.ld + h * 32, q);
-    load_row32(a.dO + tok_row(a.mdo, qc, b) * a.mdo.ld + h * 32, dov);
-    float delta;
-    {
-        float ov[32];
-        load_row32(a.O + tok_row(a.mo, qc, b) * a.mo.ld + h * 32, ov);
-        delta = dot32(dov, ov);
-    }
-    const float lse = a.lse[((long)b * a.H + h) * a.Lq + qc];
-    if (active && kl == 0) a.delta[((long)b * a.H + h) * a.Lq + qi] = delta;
-#pragma unroll
-    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
-    const float inv_keep = dropout_inv_keep(a.pdrop);
-    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
-    const uint64_t rbase = ((uint64_t)(b * a.H + h) * a.Lq + qc) * (uint64_t)a.Lk;
-    for (int k0 = 0; k0 < a.Lk; k0 += KT) {
-        __syncthreads();
-        stage_rows(ks, a.K, a.mk, b, h, k0, a.Lk);
-        stage_rows(vs, a.V, a.mv, b, h, k0, a.Lk);
-        if (threadIdx.x < KT) msk[threadIdx.x] = (k0 + threadIdx.x >= a.Lk) || (a.kpm && a.kpm[(long)b * a.Lk + k0 + threadIdx.x]);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < KT / 16; ++j) {
-            const int kk = kl + 16 * j;
-            if (msk[kk]) continue;
-            float kv[32], vv[32];
-            lds_row32(ks, kk, kv);
-            lds_row32(vs, kk, vv);
-            const float p = __expf(dot32(q, kv) * a.scale - lse);
-            float dp = dot32(dov, vv);
-            if (a.pdrop > 0.f) dp = dropout_keep(seed, rbase + k0 + kk, a.thresh) ? dp * inv_keep : 0.f;
-            const float ds = p * (dp - delta) * a.scale;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) dq[d] = fmaf(ds, kv[d], dq[d]);
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 32; ++d) dq[d] = quad16_sum(dq[d]);
-    if (active && kl == 0) store_row32(a.dQ + tok_row(a.mdq, qi, b) * a.mdq.ld + h * 32, dq);
-}
-
-// dK, dV: rows = keys, split = queries (Q / dO / lse / delta tiles staged in LDS)
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 qs[KT][KPAD];
-    __shared__ __attribute__((aligned(16))) bf16 dos[KT][KPAD];
-    __shared__ float lses[KT], dels[KT];
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int ki = blockIdx.x * 16 + (threadIdx.x >> 4), ql = threadIdx.x & 15;
-    const bool active = ki < a.Lk;
-    const int kc = active ? ki : a.Lk - 1;
-    const bool masked = a.kpm && a.kpm[(long)b * a.Lk + kc];
-    float k[32], v[32], dk[32], dv[32];
-    load_row32(a.K + tok_row(a.mk, kc, b) * a.mk.ld + h * 32, k);
-    load_row32(a.V + tok_row(a.mv, kc, b) * a.mv.ld + h * 32, v);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    const float inv_keep = dropout_inv_keep(a.pdrop);
-    const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
-    for (int q0 = 0; q0 < a.Lq; q0 += KT) {
-        __syncthreads();
-        stage_rows(qs, a.Q, a.mq, b, h, q0, a.Lq);
-        stage_rows(dos, a.dO, a.mdo, b, h, q0, a.Lq);
-        if (threadIdx.x < KT) {
-            const bool ok = q0 + threadIdx.x < a.Lq;
-            lses[threadIdx.x] = ok ? a.lse[((long)b * a.H + h) * a.Lq + q0 + threadIdx.x] : INFINITY;   // exp(-inf) = 0 beyond Lq
-            dels[threadIdx.x] = ok ? a.delta[((long)b * a.H + h) * a.Lq + q0 + threadIdx.x] : 0.f;
-        }
-        __syncthreads();
-        if (masked) continue;
-#pragma unroll
-        for (int j = 0; j < KT / 16; ++j) {
-            const int qq = ql + 16 * j;
-            if (q0 + qq >= a.Lq) continue;
-            float qv[32], dov[32];
-            lds_row32(qs, qq, qv);
-            lds_row32(dos, qq, dov);
-            const float p = __expf(dot32(qv, k) * a.scale - lses[qq]);
-            float dp = dot32(dov, v), pd = p;
-            if (a.pdrop > 0.f) {
-                const uint64_t idx = ((uint64_t)(b * a.H + h) * a.Lq + (q0 + qq)) * (uint64_t)a.Lk + kc;
-                const bool keep = dropout_keep(seed, idx, a.thresh);
-                pd = keep ? p * inv_keep : 0.f;
-                dp = keep ? dp * inv_keep : 0.f;
-            }
-            const float ds = p * (dp - dels[qq]) * a.scale;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) { dv[d] = fmaf(pd, dov[d], dv[d]); dk[d] = fmaf(ds, qv[d], dk[d]); }
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { dk[d] = quad16_sum(dk[d]); dv[d] = quad16_sum(dv[d]); }
-    if (active && ql == 0) {
-        store_row32(a.dK + tok_row(a.mdk, ki, b) * a.mdk.ld + h * 32, dk);
-        store_row32(a.dV + tok_row(a.mdv, ki, b) * a.mdv.ld + h * 32, dv);
-    }
-}
+// (round 5: the scalar flash kernels attn_fwd / attn_bwd_dq / attn_bwd_dkv of round 1 -- 16 rows x 16 split lanes -- are gone: their last caller,
+// the DETR decoder's self-attention over 15 tubelet queries, runs on the wave-split MFMA kernels of attention_mfma.hip like every other
+// attention above SMALL_L)
 
 // ---- tiny sequences (Lq, Lk <= 8: the class branch's attention over the 4 temporal slots, batch = layers x clips x h*w) ----
 // one thread per (batch, head, row); every row is a handful of 64-byte loads that the 4 sibling threads share in L1.
@@ -452,9 +266,6 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(const bf16* __restrict__
 
 // everything but short-query x short-key calls takes the MFMA kernels (attention_mfma.hip); measured on MI355X the tubelet-query
 // cross attentions (Lq = 15 against 352 / 1408 keys) are faster there too even with one active wave per 64-query block
-#define MFMA_MIN_LQ 32
-#define MFMA_MIN_LK 128
-static bool attn_force_scalar() { return false; }
 
 extern "C" {
 
@@ -472,10 +283,8 @@ int tuber_attn_fwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.thresh = (uint32_t)((double)pdrop * 4294967296.0); a.seed_ptr = (const uint64_t*)seed_ptr; a.salt = salt;
     if (Lq <= SMALL_L && Lk <= SMALL_L)
         hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(ceil_div((long)B * H * Lq, 256)), dim3(256), 0, stream, a);
-    else if ((Lq >= MFMA_MIN_LQ || Lk >= MFMA_MIN_LK) && !attn_force_scalar())
-        tuber_attn_mfma_fwd_launch(&a, stream);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
+        tuber_attn_mfma_fwd_launch(&a, stream);
     TUBER_RETURN_LAUNCH();
 }
 
@@ -493,11 +302,8 @@ int tuber_attn_bwd(const void* Q, const long* mq, const void* K, const long* mk,
     a.dV = (bf16*)dV; a.mdv = mk_map(mdv); a.delta = delta;
     if (Lq <= SMALL_L && Lk <= SMALL_L) {
         hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(ceil_div((long)B * H * (Lq > Lk ? Lq : Lk), 256)), dim3(256), 0, stream, a);
-    } else if ((Lq >= MFMA_MIN_LQ || Lk >= MFMA_MIN_LK) && !attn_force_scalar()) {
-        tuber_attn_mfma_bwd_launch(&a, stream);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 16), H, B), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(Lk, 16), H, B), dim3(256), 0, stream, a);
+        tuber_attn_mfma_bwd_launch(&a, stream);     // dQ and dK / dV bodies of one launch (two for the class branch's 2 x 2304 workgroups)
     }
     TUBER_RETURN_LAUNCH();
 }
