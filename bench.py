@@ -602,8 +602,9 @@ def main():
             pass
         line["roofline"] = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                            "traffic_source": "committed PMC passes of this command (profiles/*pmc_traffic.json), not collected in this run",
                             "traffic_over_alg": round(traffic / (s["bytes"] / s["launches"]), 3) if traffic else None,
-                            "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
+                            "launches_per_step": s["launches"] // max(timed_steps, 1), "launches_timed": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
                             "alg_bytes_per_launch": int(s["bytes"] / s["launches"]),
                             "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
                             "share_of_step": round(s["ms"] / timed_steps / ms, 4),
