@@ -99,7 +99,7 @@ def mha(state, p, q, k, v, nhead, key_padding_mask=None):
     s = torch.bmm(qp, kp.transpose(1, 2))
     if key_padding_mask is not None:
         s = s.view(b, nhead, lq, lk).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(b * nhead, lq, lk)
-    a = torch.softmax(s, dim=-1)
+    a = F.softmax(s, dim=-1)
     o = torch.bmm(a, vp).transpose(0, 1).reshape(lq, b, e)
     return linear(state, p + ".out_proj", o)
 

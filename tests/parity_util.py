@@ -20,6 +20,28 @@ class RoundBF(torch.autograd.Function):
         return g
 
 
+class RoundBFG(torch.autograd.Function):
+    """what a bf16-STORED activation does: the value is rounded forward, its gradient is rounded backward"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class RoundG(torch.autograd.Function):
+    """identity forward, bf16-rounded gradient backward (the dS operand of the attention backward's MFMAs)"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 class rounded_convs:
     """context: the oracle's conv3d / linear read bf16-rounded operands and round their result (exact accumulation)"""
 
@@ -67,12 +89,18 @@ def flat_outputs(out):
 
 def run_oracle(cfg, state, clips, train, rounded=False, param_names=None, loss=None, mask=None):
     """-> (outputs, {name: grad} or None).  ``state`` is cloned; with ``loss`` the parameters require grad and loss(out) is
-    back-propagated."""
+    back-propagated.  ``rounded``: True = conv3d / linear read bf16-rounded operands and round their result (straight-through
+    gradients); "full" = additionally the activation GRADIENTS entering and leaving every conv3d / linear are rounded, and so are the
+    attention probabilities and the gradient of the attention scores -- every place the HIP path stores or feeds an MFMA in bf16."""
     from oracle import tuber_oracle as O
     pn = set(param_names or [])
     st = {k: (v.clone().requires_grad_(True) if (loss is not None and k in pn) else v.clone()) for k, v in state.items()}
-    oc, ol = F.conv3d, F.linear
-    if rounded:
+    oc, ol, osm = F.conv3d, F.linear, F.softmax
+    if rounded == "full":
+        O.F.conv3d = lambda x, w, *a, **k: RoundBFG.apply(oc(RoundBFG.apply(x), RoundBF.apply(w), *a, **k))
+        O.F.linear = lambda x, w, b=None: RoundBFG.apply(ol(RoundBFG.apply(x), RoundBF.apply(w), b))
+        O.F.softmax = lambda s, dim=-1, **k: RoundBFG.apply(osm(RoundG.apply(s), dim, **k))
+    elif rounded:
         O.F.conv3d = lambda x, w, *a, **k: RoundBF.apply(oc(RoundBF.apply(x), RoundBF.apply(w), *a, **k))
         O.F.linear = lambda x, w, b=None: RoundBF.apply(ol(RoundBF.apply(x), RoundBF.apply(w), b))
     try:
@@ -83,7 +111,7 @@ def run_oracle(cfg, state, clips, train, rounded=False, param_names=None, loss=N
         out = O.tuber_forward(st, cfg, clips, mask=mask, train=train)
         loss(out).backward()
     finally:
-        O.F.conv3d, O.F.linear = oc, ol
+        O.F.conv3d, O.F.linear, O.F.softmax = oc, ol, osm
     return out, {k: st[k].grad for k in pn}
 
 

@@ -199,6 +199,11 @@ def test_train_step_matches_reference_golden(dev, golden_dir, name):
     assert 0.5 < ratios[0][0] and ratios[-1][0] < 2.0
 
 
+def _nsr(c):
+    """noise-to-signal ratio of a gradient whose cosine against the truth is c (noise orthogonal to the signal)"""
+    return math.sqrt(max(1.0 / max(c, 1e-3) ** 2 - 1.0, 0.0))
+
+
 @pytest.mark.parametrize("name", list(SPREAD_TRAIN_CASES))
 def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(dev, golden_dir, name):
     """End-to-end training step on the NON-DEGENERATE fixture: synth.SPREAD_GAINS keep the tubelet queries apart
@@ -212,9 +217,13 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
     * the assignment against the REFERENCE's, per problem: identical wherever the golden's decidability ratio is >= 6 and on at least
       9 of the 12 problems; a flip elsewhere is accepted only if the cost perturbation of the HIP run on that problem is <= 3 x the
       rounded oracle's (+ 0.02) -- i.e. explained by bf16 noise of the size ideal bf16 arithmetic has on the same fixture;
-    * on the layers whose assignment is the reference's: every loss term within max(2 %, 2 x the rounded oracle's error on that term
-      + 0.5 %); with all assignments identical also: total within 0.5 %, global gradient norm within 5 %, per-tensor gradient-norm
-      ratios in (0.67, 1.5), gradient cosines >= 0.98 (heads) / >= 0.85 (every stored tensor, incl. the stem's conv1).
+    * on the layers whose assignment is the reference's: every loss term within max(2 %, 4 x the rounded oracle's error on that term's
+      family + 1 %); with all assignments identical also, each against what the FULLY rounded oracle (parity_util.run_oracle
+      rounded="full": activation gradients, attention probabilities and score gradients through bf16 too) realises on this fixture:
+      total loss within max(0.5 %, 2 x + 0.1 %), global gradient norm within max(5 %, 2 x + 1 %), per-tensor gradient-norm ratios
+      inside its range widened by (0.67, 1.5), and for every stored gradient tensor (the stem's conv1 through 50 bottlenecks, the
+      query embedding through 18 attention blocks, ...) a noise-to-signal ratio sqrt(1 / cos^2 - 1) <= 3 x the yardstick's + 0.3
+      (the HIP path also keeps the residual streams in bf16, which the yardstick does not), the heads' cosines >= 0.98.
     """
     from parity_util import criterion_probe, check_criterion_on_model_outputs, matcher_problems, assignment_margin
     yaml_name, sizes = SPREAD_TRAIN_CASES[name]
@@ -274,7 +283,7 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
         print("  %-14s hip %.5f  ref %.5f  (%.2f %%; bf16-rounded oracle %.2f %%)" % (k, g, r, 100 * rel, 100 * rel_rounded))
         if layer not in flipped_layers:
             worst_term = max(worst_term, rel)
-            assert rel <= max(0.02, 2.0 * rel_rounded + 0.005), (k, g, r, rel_rounded)
+            assert rel <= max(0.02, 4.0 * rel_rounded + 0.01), (k, g, r, rel_rounded)
     tl, tr = float(loss), float(gold["total_loss"])
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
     gn = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
@@ -291,18 +300,23 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
             a, b = grads[n].flatten().double(), torch.as_tensor(gold[k]).flatten().double()
             cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
             print("  cos(grad %-44s) = %.4f   |hip| %.3e |ref| %.3e" % (n, cos, float(a.norm()), float(b.norm())))
-            # heads (closest to the loss) >= 0.98; every stored tensor -- down to the stem's conv1 through 50 bottlenecks -- >= 0.85
-            # (the plain name-hashed fixture reaches 0.007 there: the deep gradient is only testable on this fixture)
-            if cos < (0.98 if n in ("class_embed_b.weight", "class_fc.bias") else 0.85):
-                cos_low.append((n, cos))
+            yard = float(gold["rounded_cos." + n])
+            print("      noise-to-signal %.3f  (fully rounded oracle: cos %.4f, noise-to-signal %.3f)" % (_nsr(cos), yard, _nsr(yard)))
+            if _nsr(cos) > 3.0 * _nsr(yard) + 0.3 or (n in ("class_embed_b.weight", "class_fc.bias") and cos < 0.98):
+                cos_low.append((n, cos, yard))
     for k in gold.files:
         if k.startswith("buf."):
             v = dict(model.named_buffers())[k[4:]].float().cpu().numpy()
             assert float(np.abs(v - gold[k]).max()) <= 0.02 * max(1.0, float(np.abs(gold[k]).max())), k
     if not flipped_layers:
-        assert abs(tl - tr) <= 0.005 * abs(tr)
-        assert abs(gn - float(gold["grad_norm"])) <= 0.05 * float(gold["grad_norm"])
-        assert 0.67 < ratios[0][0] and ratios[-1][0] < 1.5, (ratios[0], ratios[-1])
+        y_tl = abs(float(gold["rounded_total_loss"]) - tr) / abs(tr)
+        y_gn = abs(float(gold["rounded_grad_norm"]) - float(gold["grad_norm"])) / float(gold["grad_norm"])
+        y_lo, y_hi = (float(v) for v in gold["rounded_ratio_range"])
+        print("  fully rounded oracle on this fixture: total loss %.3f %%, global grad norm %.2f %%, per-tensor norm ratios [%.3f, %.3f]" % (
+            100 * y_tl, 100 * y_gn, y_lo, y_hi))
+        assert abs(tl - tr) <= max(0.005, 2.0 * y_tl + 0.001) * abs(tr)
+        assert abs(gn - float(gold["grad_norm"])) <= max(0.05, 2.0 * y_gn + 0.01) * float(gold["grad_norm"])
+        assert 0.67 * min(1.0, y_lo) < ratios[0][0] and ratios[-1][0] < 1.5 * max(1.0, y_hi), (ratios[0], ratios[-1])
         assert not cos_low, cos_low
     else:
         assert abs(tl - tr) <= 0.02 * abs(tr)
