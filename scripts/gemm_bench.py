@@ -198,9 +198,14 @@ def bench_bn_fa():
         s0, s1 = torch.randn(R, C, device=dev), torch.randn(R, C, device=dev)
         gamma, mean, invstd = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-        t = time_it(lambda: lib.call("tuber_bn_bwd_fa", s0, s1, R, C, float(M), gamma, mean, invstd, dg, db, dz, x, dx, M))
         mb = 3 * 2 * M * C / 1e6
-        print("bn_bwd_fa M%d C%d R%d: %.1f us  (3-pass alg %.1f MB -> %.2f TB/s)" % (M, C, R, t, mb, mb / t), flush=True)
+        row = "bn_bwd_fa M%d C%d R%d:" % (M, C, R)
+        for kr in (0, 4, 8, 11):           # rows per thread forced (0 = the launcher's heuristic)
+            lib.query("tuber_bn_bwd_fa_rows_set", kr)
+            t = time_it(lambda: lib.call("tuber_bn_bwd_fa", s0, s1, R, C, float(M), gamma, mean, invstd, dg, db, dz, x, dx, M))
+            row += "  %s %.1f us" % ("heuristic (%d rows)" % lib.query("tuber_bn_bwd_fa_rows", M, C) if kr == 0 else "%d rows" % (16 * kr), t)
+        lib.query("tuber_bn_bwd_fa_rows_set", 0)
+        print(row + "  (3-pass alg %.1f MB)" % mb, flush=True)
 
 
 def bench_dw():

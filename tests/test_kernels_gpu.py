@@ -1009,7 +1009,7 @@ def test_class_error_kernel(dev, ava):
     assert abs(float(out) - want) < 1e-4 and int(ok.sum()) == 3, (float(out), want)
 
 
-@pytest.mark.parametrize("M,C,R", [(5632, 1024, 88), (5632, 256, 88), (2816, 2048, 44), (1000, 128, 7), (2816, 512, 128)])
+@pytest.mark.parametrize("M,C,R", [(5632, 1024, 88), (5632, 256, 88), (2816, 2048, 44), (1408, 2048, 22), (1000, 128, 7), (2816, 512, 128)])
 def test_bn_bwd_one_launch_matches_finalize_plus_apply(dev, M, C, R):
     """tuber_bn_bwd_fa (finalize + apply in one launch, short partial lists) against tuber_bn_bwd_finalize + tuber_bn_bwd_apply:
     same fp64 arithmetic in another fixed summation order -> dx equal up to one bf16 ulp on rare elements, dgamma / dbeta to 1e-6 rel"""
@@ -1027,19 +1027,25 @@ def test_bn_bwd_one_launch_matches_finalize_plus_apply(dev, M, C, R):
     lib.call("tuber_bn_bwd_finalize", b0, b1, R, C, float(M), gamma, mean, invstd, cA, cB, cC, dg0, db0, 1)
     dx0 = torch.empty(M, C, device=dev, dtype=BF)
     lib.call("tuber_bn_bwd_apply", dz, x, cA, cB, cC, dx0, M, C)
-    dg1, db1 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
-    dx1 = torch.full((M, C), float("nan"), device=dev, dtype=BF)
-    lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, dg1, db1, dz, x, dx1, M)
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(dx1.float()).all())
-    diff = (dx0.float() - dx1.float()).abs()
-    assert float((diff > 0).float().mean()) < 1e-3 and float(diff.max()) <= 2 ** -7 * float(dx0.float().abs().max())
-    close("fa dgamma", dg1, dg0, rel=1e-5)
-    close("fa dbeta", db1, db0, rel=1e-5)
-    # frozen BatchNorm: no dgamma / dbeta
-    dx2 = torch.empty(M, C, device=dev, dtype=BF)
-    lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, None, None, dz, x, dx2, M)
-    assert torch.equal(dx2, dx1)
+    try:
+        for kr in (0, 4, 8, 11):         # rows per workgroup = 16 * kr: the launcher's own choice (0), then each form forced
+            lib.query("tuber_bn_bwd_fa_rows_set", kr)
+            dg1, db1 = torch.full((C,), 0.5, device=dev), torch.full((C,), 0.25, device=dev)
+            dx1 = torch.full((M, C), float("nan"), device=dev, dtype=BF)
+            lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, dg1, db1, dz, x, dx1, M)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(dx1.float()).all())
+            diff = (dx0.float() - dx1.float()).abs()
+            assert float((diff > 0).float().mean()) < 1e-3 and float(diff.max()) <= 2 ** -7 * float(dx0.float().abs().max())
+            close("fa dgamma", dg1, dg0, rel=1e-5)
+            close("fa dbeta", db1, db0, rel=1e-5)
+            # frozen BatchNorm: no dgamma / dbeta
+            dx2 = torch.empty(M, C, device=dev, dtype=BF)
+            lib.call("tuber_bn_bwd_fa", b0, b1, R, C, float(M), gamma, mean, invstd, None, None, dz, x, dx2, M)
+            assert torch.equal(dx2, dx1)
+    finally:
+        lib.query("tuber_bn_bwd_fa_rows_set", 0)
+    assert lib.query("tuber_bn_bwd_fa_rows", M, C) in (64, 128, 176)
 
 
 @pytest.mark.parametrize("M,N,K,add_cols", [(704, 768, 256, 512), (30, 768, 256, 512), (30, 256, 256, 256), (704, 512, 256, 256), (2816, 768, 256, 512)])

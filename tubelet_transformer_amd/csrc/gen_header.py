@@ -19,6 +19,8 @@ DOC = {
                        "derives the coefficients of its 128-channel strip from the R partial rows (fp64) and applies dx = cA*dz + cB*x + cC to its rows; "
                        "dgamma / dbeta accumulated by the first row chunk (NULL: frozen BatchNorm). autograd of nn.BatchNorm3d (ir_CSN_152.py:46,56,64,154).",
     "tuber_bn_bwd_fa_max_rows": "largest R tuber_bn_bwd_fa accepts.",
+    "tuber_bn_bwd_fa_rows": "rows per workgroup tuber_bn_bwd_fa takes for (M, C): 64, 128 or 176 -- the grid that sits at or just under a multiple of the 256 CUs.",
+    "tuber_bn_bwd_fa_rows_set": "test hook: rows per THREAD of tuber_bn_bwd_fa forced to 4, 8 or 11 (0 = the heuristic), so that tests cover every instantiation at every shape.",
     "tuber_class_error": "class_error of the matched queries of one decoder layer, on the device: 100 - exact-set accuracy (AVA, utils/misc.py:497-518 "
                          "via models/criterion.py:76-78) or top-1 accuracy (JHMDB, utils/misc.py:521-539 via criterion.py:258-260).",
     "tuber_targets_pack": "the padded [B, Tmax] target layout of one batch in ONE launch: boxes (column 0 = key-frame index dropped, models/detr/matcher.py:64, "

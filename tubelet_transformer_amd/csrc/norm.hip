@@ -298,13 +298,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // the partial rows is fixed (deterministic) but differs from bn_bwd_finalize's, so results agree with the two-launch path to fp64
 // rounding, not bit for bit.  (Round 1's one-launch variant used 32-channel strips = 64-byte segments and 1024-thread workgroups and
 // lost 0.5 ms/step.)
+// Rows per workgroup = 16 * KR, chosen per launch (fa_rows_per_thread) so that the grid sits at or just under a multiple of the 256 CUs:
+// layer3's bn4 (M = 5632, C = 1024) is 44 x 8 = 352 workgroups at 128 rows -- the launch runs at the pace of the CUs that carry two --
+// and 32 x 8 = 256 at 176 rows.
 #define FA_CS 128          // channels per strip
-#define FA_ROWS 128        // rows per workgroup
+template <int KR>
 __global__ __launch_bounds__(256) void bn_bwd_fa_kernel(
     const float* __restrict__ st0, const float* __restrict__ st1, int R, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta,
     const bf16* __restrict__ dz, const bf16* __restrict__ x, bf16* __restrict__ dx, long M) {
+    constexpr int FA_ROWS = 16 * KR;
     __shared__ double red[2][8][FA_CS];
     __shared__ float coef[3][FA_CS];
     const int c0 = blockIdx.y * FA_CS;
@@ -764,12 +768,34 @@ int tuber_relu_bn_bwd_reduce(const void* g, const void* x, const float* sc, cons
 // dx = cA*dz + cB*x + cC with the coefficients derived per workgroup from the partial rows; dgamma / dbeta are ACCUMULATED (+=) unless
 // NULL (frozen BatchNorm).  Same arithmetic as tuber_bn_bwd_finalize + tuber_bn_bwd_apply (fp64 sums, another fixed order).
 int tuber_bn_bwd_fa_max_rows(void) { return 128; }
+// rows per thread (x 16 = rows per workgroup) of tuber_bn_bwd_fa: the candidate with the least (rounds of 256 workgroups) x (rows per
+// thread + 6, the derive prologue every workgroup pays, in row units)
+static int fa_rows_per_thread(long M, int C) {
+    if (ceil_div(M, 128L) * (C / FA_CS) >= 1024) return 8;      // many rounds either way (layer1 / layer2): 128 rows measured best
+    const int cand[3] = {4, 8, 11};
+    int best = 8;
+    long best_cost = -1;
+    for (int i = 0; i < 3; ++i) {
+        const long wgs = ceil_div(M, 16L * cand[i]) * (C / FA_CS);
+        const long cost = ceil_div(wgs, 256L) * (cand[i] + 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[i]; }
+    }
+    return best;
+}
+int tuber_bn_bwd_fa_rows(long M, int C) { return 16 * fa_rows_per_thread(M, C); }
+static int g_fa_rows_forced = 0;     // test hook: rows per thread forced (0 = heuristic), so the kernel test covers every instantiation at every shape
+int tuber_bn_bwd_fa_rows_set(int kr) { g_fa_rows_forced = kr; return 0; }
 int tuber_bn_bwd_fa(const float* st0, const float* st1, int R, int C, float count, const float* gamma, const float* mean,
                     const float* invstd, float* dgamma, float* dbeta, const void* dz, const void* x, void* dx, long M,
                     hipStream_t stream) {
     if (R <= 0 || R > 128 || C <= 0 || (C % FA_CS) || M <= 0) return TUBER_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_fa_kernel, dim3(ceil_div(M, FA_ROWS), C / FA_CS), dim3(256), 0, stream, st0, st1, R, C, count, gamma, mean,
-                       invstd, dgamma, dbeta, (const bf16*)dz, (const bf16*)x, (bf16*)dx, M);
+    const int kr = g_fa_rows_forced ? g_fa_rows_forced : fa_rows_per_thread(M, C);
+#define FA_LAUNCH(KR) hipLaunchKernelGGL(bn_bwd_fa_kernel<KR>, dim3(ceil_div(M, 16L * KR), C / FA_CS), dim3(256), 0, stream, st0, st1, R, C, \
+                                         count, gamma, mean, invstd, dgamma, dbeta, (const bf16*)dz, (const bf16*)x, (bf16*)dx, M)
+    if (kr == 4) FA_LAUNCH(4);
+    else if (kr == 11) FA_LAUNCH(11);
+    else FA_LAUNCH(8);
+#undef FA_LAUNCH
     TUBER_RETURN_LAUNCH();
 }
 
