@@ -59,7 +59,7 @@ def load():
         fn.argtypes = [_ctype(t) for t, _ in args]
         sigs[name] = args
     _lib, _sigs = lib, sigs
-    if os.environ.get("TUBER_NT_WSK96"):             # EXPERIMENT (round 5): "0" = 64-row wave-split-K tiles everywhere
+    if os.environ.get("TUBER_NT_WSK96"):             # measurement hook (DESIGN.md "Switches"): "0" = 64-row wave-split-K tiles everywhere
         lib.tuber_gemm_nt_wsk96_set(int(os.environ["TUBER_NT_WSK96"]))
     return lib
 
