@@ -182,6 +182,14 @@ def test_library_exports_every_symbol_the_header_declares():
     L = lib.load()                      # binds every prototype; AttributeError = header/library drift
     for _, name, _ in protos:
         assert hasattr(L, name), name
+    # ... and the header declares every extern "C" entry point of the sources (a stale header = a KeyError at the first lib.call of the new one)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_header", os.path.join(ROOT, "tubelet_transformer_amd", "csrc", "gen_header.py"))
+    gh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gh)
+    declared = {name for _, name, _ in protos}
+    defined = {name for _, _, name, _ in gh.prototypes()}
+    assert defined == declared, "include/tuber_hip.h is stale: run python tubelet_transformer_amd/csrc/gen_header.py (%s)" % sorted(defined ^ declared)
     # pure host helpers may be called without a GPU
     cfg = lib.query("tuber_gemm_nt_cfg", 348160, 64, 256)
     assert cfg == 13                                     # 64x64 tiles, two-tile prefetch

@@ -501,6 +501,62 @@ def test_layernorm_dropout_and_window(dev, M, E):
     close("layernorm(dropout) bwd d x", dxd, xin.grad, rel=2 ** -6)
 
 
+@pytest.mark.parametrize("M,Kin,epi,p,two", [(30, 256, "plain", 0.0, False), (30, 256, "res", 0.1, False), (30, 2048, "mask", 0.1, True),
+                                              (2816, 256, "res", 0.1, False), (2816, 2048, "mask", 0.1, False), (2816, 256, "plain", 0.0, True),
+                                              (77, 2048, "mask", 0.0, False), (100, 1024, "res", 0.1, True)])
+def test_layernorm_backward_fused_into_the_linear_data_gradient(dev, M, Kin, epi, p, two):
+    """tuber_ln_bwd_dx == [tuber_axpby] + tuber_layernorm_bwd + tuber_gemm_nt (the chain tape.py launches for norm(x + dropout(linear(.))) in
+    the backward pass): dx / dxd identical up to one bf16 ulp on rare elements (same arithmetic, another compilation unit), the dgamma / dbeta
+    partial rows summed over their blocks to 1e-5, the product to MFMA summation order; every epilogue of linear.bwd's data-gradient GEMM."""
+    E, salt = 256, 13
+    seed = torch.tensor([4321], dtype=torch.int64, device=dev)
+    dy = rnd(M, E, dev=dev, seed=1).to(BF)
+    dy2 = rnd(M, E, dev=dev, seed=2).to(BF) if two else None
+    xh = rnd(M, E, dev=dev, seed=3).to(BF)
+    rstd = 0.5 + torch.rand(M, device=dev)
+    gam = 1 + 0.1 * rnd(E, dev=dev, seed=4)
+    wt = (rnd(Kin, E, dev=dev, seed=5) / 16).to(BF)           # W^T rows: [Kin][E]
+    res = rnd(M, Kin, dev=dev, seed=6).to(BF) if epi == "res" else None
+    cm = rnd(M, Kin, dev=dev, seed=7).to(BF) if epi == "mask" else None
+    alpha = 1.25 if epi == "mask" else 1.0
+    # the launch chain
+    g = dy
+    if two:
+        g = torch.empty_like(dy)
+        lib.call("tuber_axpby", dy, dy2, g, dy.numel(), 1.0, 1.0)
+    nb0 = lib.query("tuber_layernorm_bwd_blocks", M)
+    part0 = torch.zeros(nb0, 2 * E, device=dev)
+    dx0, dxd0 = torch.empty(M, E, device=dev, dtype=BF), torch.empty(M, E, device=dev, dtype=BF)
+    lib.call("tuber_layernorm_bwd", g, E, xh, rstd, gam, dx0, dxd0 if p > 0 else None, part0, None, None, 2, M, E, p, seed, salt)
+    a0 = dxd0 if p > 0 else dx0
+    out0 = torch.empty(M, Kin, device=dev, dtype=BF)
+    if epi == "mask":
+        lib.call("tuber_gemm_nt", a0, E, wt, E, out0, Kin, M, Kin, E, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 2, None, None, 0, 0, 0, None, None, cm, Kin, None, None, alpha, 0.0, None, 0, None, 0, None)
+    else:
+        lib.call("tuber_gemm_nt", a0, E, wt, E, out0, Kin, M, Kin, E, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 0, None, res, Kin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+    # one launch
+    nb1 = lib.query("tuber_ln_bwd_dx_blocks", M)
+    part1 = torch.zeros(nb1, 2 * E, device=dev)
+    dx1 = torch.full((M, E), float("nan"), device=dev, dtype=BF)
+    dxd1 = torch.full((M, E), float("nan"), device=dev, dtype=BF)
+    out1 = torch.full((M, Kin), float("nan"), device=dev, dtype=BF)
+    assert lib.query("tuber_ln_bwd_dx_supported", E, Kin) == 1
+    lib.call("tuber_ln_bwd_dx", dy, E, dy2, E if two else 0, xh, rstd, gam, dx1, dxd1 if p > 0 else None, part1, M, E, p, seed, salt,
+             wt, E, Kin, out1, res, cm, alpha)
+    torch.cuda.synchronize()
+    for name, a, b in (("dx", dx1, dx0),) + ((("dxd", dxd1, dxd0),) if p > 0 else ()):
+        d = (a.float() - b.float()).abs()
+        assert bool(torch.isfinite(a.float()).all()), name
+        assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2 ** -7 * float(b.float().abs().max()), (name, float((d > 0).float().mean()), float(d.max()))
+    close("ln_bwd_dx partial sums", part1.sum(0), part0.sum(0), rel=1e-5)
+    assert bool(torch.isfinite(out1.float()).all())
+    close("ln_bwd_dx product", out1, out0, rel=2 ** -6)
+    if epi == "mask":
+        assert bool(((out1.float() == 0) | (cm.float() > 0)).all())
+
+
 def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
     """FFN pieces: h = Dropout(ReLU(x W1^T + b)) as one GEMM; the backward mask alpha*g*[h>0] as the epilogue of the next dgrad."""
     M, K, N, p, salt = 300, 256, 512, 0.1, 11

@@ -19,6 +19,14 @@ DOC = {
                        "derives the coefficients of its 128-channel strip from the R partial rows (fp64) and applies dx = cA*dz + cB*x + cC to its rows; "
                        "dgamma / dbeta accumulated by the first row chunk (NULL: frozen BatchNorm). autograd of nn.BatchNorm3d (ir_CSN_152.py:46,56,64,154).",
     "tuber_bn_bwd_fa_max_rows": "largest R tuber_bn_bwd_fa accepts.",
+    "tuber_ln_bwd_dx": "tuber_layernorm_bwd (partial rows only) + the data-gradient tuber_gemm_nt of the linear layer in front of the LayerNorm in ONE launch: "
+                       "autograd of tgt = norm(tgt + dropout(sublayer)) where the sublayer ends in out_proj / linear2 (models/transformer/transformer.py:160-167,229-247). "
+                       "Every workgroup runs the LayerNorm backward of its 32 rows itself and multiplies the bf16 result from LDS with W on MFMA; the column-0 workgroups "
+                       "store dx / dxd / the dgamma, dbeta partial rows ([tuber_ln_bwd_dx_blocks(M)][2E]) as the two-launch path does. dy2: a second gradient contribution (replaces "
+                       "a tuber_axpby launch) or NULL; res: an existing gradient of the linear's input to add; cm / alpha: the ReLU / Dropout mask of that input.",
+    "tuber_ln_bwd_dx_blocks": "partial rows tuber_ln_bwd_dx writes for M rows (32 rows per block).",
+    "tuber_ln_bwd_dx_pays": "1 where tape.py uses tuber_ln_bwd_dx instead of the two launches: M <= 64 rows at any width, or Kin <= 256 (measured; the encoder's linear2 loses).",
+    "tuber_ln_bwd_dx_supported": "1 when tuber_ln_bwd_dx handles a LayerNorm of width E in front of a linear with Kin inputs (E = 256, Kin % 64 = 0).",
     "tuber_bn_bwd_fa_rows": "rows per workgroup tuber_bn_bwd_fa takes for (M, C): 64, 128 or 176 -- the grid that sits at or just under a multiple of the 256 CUs.",
     "tuber_bn_bwd_fa_rows_set": "test hook: rows per THREAD of tuber_bn_bwd_fa forced to 4, 8 or 11 (0 = the heuristic), so that tests cover every instantiation at every shape.",
     "tuber_class_error": "class_error of the matched queries of one decoder layer, on the device: 100 - exact-set accuracy (AVA, utils/misc.py:497-518 "

@@ -21,7 +21,7 @@ models/tuber_ava.py:97-157.
 import numpy as np
 import torch
 
-from . import lib
+from . import ab, lib
 from .engine import TnArgs
 
 BF = torch.bfloat16
@@ -55,6 +55,8 @@ class Tape:
         self.stack = {}        # id(tensor) -> list of gradient tensors summed lazily by the producer's backward
         self.dry = False       # dry run: the ops allocate their outputs, draw their dropout salts and record their backward closures, but do
         self.dry_log = []      # not launch the forward kernel -- (kind, dict) per op, for a fused launch that fills those outputs (tuber.py)
+        self.pending = {}      # id(gradient tensor) -> _PendingLN: a LayerNorm backward not launched yet (it may fuse into its consumer)
+        self.lin_out = set()   # id(y) of linear() outputs a LayerNorm backward may fuse into (plain linear with 256 outputs, no ReLU / Dropout)
         self.req = set()       # ids of tensors whose gradient is needed (they depend on a trainable parameter): the backward pass
         #                        skips weight gradients of frozen parameters and data gradients nobody consumes, like autograd does
 
@@ -74,11 +76,19 @@ class Tape:
     def mark(self, t):
         self.req.add(id(t))
 
-    def take(self, t):
-        return self.g.pop(id(self.target(t)), None)
+    def force(self, g):
+        """launch the LayerNorm backward that produces ``g`` if it is still pending (someone is about to read or re-deposit g)"""
+        rec = self.pending.get(id(g)) if g is not None else None
+        if rec is not None:
+            rec.force()
+        return g
+
+    def take(self, t, force=True):
+        g = self.g.pop(id(self.target(t)), None)
+        return self.force(g) if force else g
 
     def peek(self, t):
-        return self.g.get(id(self.target(t)))
+        return self.force(self.g.get(id(self.target(t))))
 
     def set(self, t, g):
         self.g[id(self.target(t))] = g
@@ -87,14 +97,14 @@ class Tape:
         """deposit g for t; adds to an existing gradient (one axpby launch) when a GEMM could not fuse the accumulation."""
         t = self.target(t)
         if id(t) in self.stack:
-            self.stack[id(t)].append(g)
+            self.stack[id(t)].append(self.force(g))
             return
         cur = self.g.get(id(t))
         if cur is None:
             self.g[id(t)] = g
         else:
-            out = torch.empty_like(cur)
-            lib.call("tuber_axpby", cur, g, out, cur.numel(), 1.0, 1.0)
+            out = torch.empty_like(self.force(cur))
+            lib.call("tuber_axpby", cur, self.force(g), out, cur.numel(), 1.0, 1.0)
             self.g[id(t)] = out
 
     def backward(self, seeds):
@@ -103,16 +113,53 @@ class Tape:
                 self.put(t, g)
         for fn in reversed(self.ops):
             fn()
+        for rec in list(self.pending.values()):         # (nothing consumed them: cannot happen for a gradient somebody asked for; be safe)
+            rec.force()
         self.store.wq.flush()
         self.clear()
 
     def clear(self):
         self.ops.clear(); self.g.clear(); self.alias.clear(); self.mask.clear(); self.premasked.clear(); self.stack.clear()
-        self.req.clear()
+        self.req.clear(); self.pending.clear(); self.lin_out.clear()
 
     def salt(self):
         self.store.step_seed += 1
         return self.store.step_seed
+
+
+class _PendingLN:
+    """A LayerNorm backward that layer_norm.bwd did not launch: its consumer -- the backward of the linear whose output the LayerNorm
+    normalised (attention out_proj, the FFN's linear2) -- runs next and launches LayerNorm backward + its own data-gradient GEMM as ONE
+    kernel (tuber_ln_bwd_dx).  Anyone else who touches the two gradient tensors first (Tape.force) gets the stand-alone launch."""
+
+    def __init__(self, tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register):
+        self.tp, self.g, self.gptr, self.ldg, self.xhat, self.rstd, self.gamma = tp, g, gptr, ldg, xhat, rstd, gamma
+        self.dx, self.dxd, self.p, self.salt, self.M, self.E, self.register = dx, dxd, p, salt, M, E, register
+        self.keys = [id(t) for t in (dx, dxd) if t is not None]
+        for k in self.keys:
+            tp.pending[k] = self
+
+    def _done(self):
+        for k in self.keys:
+            self.tp.pending.pop(k, None)
+
+    def force(self):
+        st = self.tp.store
+        self._done()
+        nb = lib.query("tuber_layernorm_bwd_blocks", self.M)
+        part, dgamma, dbeta, acc = self.register(nb)
+        lib.call("tuber_layernorm_bwd", self.gptr, self.ldg, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, dgamma, dbeta, acc,
+                 self.M, self.E, self.p, st.seed, self.salt)
+
+    def fuse(self, wt, ldt, Kin, out, res, cm, alpha):
+        """LayerNorm backward + out = (gradient of the linear's output) . W [+ res | masked by cm > 0, x alpha] in one launch"""
+        st = self.tp.store
+        self._done()
+        nb = lib.query("tuber_ln_bwd_dx_blocks", self.M)
+        part, _, _, acc = self.register(nb)
+        assert acc == 2
+        lib.call("tuber_ln_bwd_dx", self.gptr, self.ldg, None, 0, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, self.M, self.E,
+                 self.p, st.seed, self.salt, wt, ldt, Kin, out, res, cm, alpha)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -149,11 +196,42 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
     inv_keep = 65536.0 / (65536 - t16) if t16 else 1.0
     if relu:
         tp.mask[id(y)] = inv_keep
+    toff, _, _, ldt = st.tinfo[wname]
+    if not relu and not out_f32 and p == 0.0 and N == 256 and r0 == 0 and xreq and ldt >= N and lib.query("tuber_ln_bwd_dx_pays", M, N, K) == 1:
+        tp.lin_out.add(id(y))                            # a LayerNorm over y may leave its backward to this linear's (layer_norm.bwd)
+
+    def fused_dgrad(rec, g):
+        """the data gradient of x together with the pending LayerNorm backward that produces g (one launch); mirrors the epilogue choice of
+        the stand-alone GEMM below.  -> True when launched."""
+        tx = tp.target(x)
+        if id(tx) in tp.stack:
+            return False
+        wt = st.tshadow.data_ptr() + 2 * (toff + r0)
+        r = tp.g.pop(id(tx), None)
+        if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous() or tp.pending.get(id(r)) is rec):
+            tp.g[id(tx)] = r
+            return False
+        tp.force(r)
+        dx = torch.empty(M, K, dtype=BF, device=dev)
+        if id(tx) in tp.mask and r is None and tx is x:
+            rec.fuse(wt, ldt, K, dx, None, x, tp.mask[id(tx)])
+            tp.premasked.add(id(tx))
+        else:
+            rec.fuse(wt, ldt, K, dx, r, None, 1.0)
+        tp.put(tx, dx)
+        return True
 
     def bwd():
-        g = tp.take(y)
+        g = tp.take(y, force=False)
         if g is None:
             return
+        rec = tp.pending.get(id(g))
+        dgrad_done = False
+        if rec is not None:
+            if id(y) in tp.lin_out and g is (rec.dxd if rec.p > 0.0 else rec.dx) and g.dtype == BF and tuple(g.shape) == (M, N):
+                dgrad_done = fused_dgrad(rec, g)         # (before the weight gradient below: a full queue launches at once and reads g)
+            if not dgrad_done:
+                rec.force()
         Np = _ceil(N, 64)
         if g.dtype != BF:
             gb = torch.empty(M, Np, dtype=BF, device=dev)
@@ -207,10 +285,9 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             lib.call("tuber_colsum", gb, part, gbias, acc, M, N, ldg)
             if acc == 2:
                 st.defer.add(part, gbias, N, N, nbc, 1)
-        if not xreq:
+        if not xreq or dgrad_done:
             return
         # data gradient; accumulation with an existing gradient of x and the ReLU/Dropout mask of x are GEMM epilogues
-        toff, _, _, ldt = st.tinfo[wname]
         wt = st.tshadow.data_ptr() + 2 * (toff + r0)           # W^T[:, r0:r1]: column offset, ld = ldt
         Kred = Np if (r0 == 0 and Np <= ldt) else N             # padded columns of both operands are zero
         assert Kred % 64 == 0, "row slices must be multiples of 64"
@@ -221,7 +298,7 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
                      0, None, None, 0, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
             tp.put(tx, dx)
             return
-        r = tp.g.pop(id(tx), None)
+        r = tp.force(tp.g.pop(id(tx), None))
         if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous()):
             tp.g[id(tx)] = r
             r = None
@@ -320,7 +397,7 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
             dx = torch.empty(M, K, dtype=BF, device=dev)
             r = None
             if id(tx) not in tp.stack:
-                r = tp.g.pop(id(tx), None)
+                r = tp.force(tp.g.pop(id(tx), None))
                 if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous()):
                     tp.g[id(tx)] = r
                     r = None
@@ -382,23 +459,31 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
                 return
             assert g.dtype == BF and g.is_contiguous() and g.shape[1] == ldy
             gptr, ldg = g.data_ptr() + 2 * (row0 * ldy + col0), ldy
-        dgamma = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".weight"]
-        dbeta = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".bias"]
-        nb = lib.query("tuber_layernorm_bwd_blocks", M)
         need_res = res is not None or p == 0.0
         dx = torch.empty(M, E, dtype=BF, device=dev) if need_res else None
         dxd = torch.empty(M, E, dtype=BF, device=dev) if p > 0.0 else None
-        part, acc = st.partial("ln", 2 * nb * E, lambda k, n: workspace(dev, k, n))
-        if not preq and acc != 2:          # frozen LayerNorm, immediate reductions: gamma/beta gradients go to scratch
-            dgamma = workspace(dev, "ln_frozen", 2 * E).data_ptr()
-            dbeta = dgamma + 4 * E
-        lib.call("tuber_layernorm_bwd", gptr, ldg, xhat, rstd, gamma, dx, dxd, part, dgamma, dbeta, acc, M, E, p, st.seed, salt)
-        if acc == 2 and preq:
-            if dbeta == dgamma + 4 * E:
-                st.defer.add(part, dgamma, 2 * E, 2 * E, nb, 1)
-            else:
-                st.defer.add(part, dgamma, E, 2 * E, nb, 1)
-                st.defer.add(part + 4 * E, dbeta, E, 2 * E, nb, 1)
+
+        def register(nb):
+            """partial rows [nb][2E] for the kernel about to be launched + where their sums go -> (partial, dgamma, dbeta, accumulate flag)"""
+            dgamma = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".weight"]
+            dbeta = st.gflat.data_ptr() + 4 * st.offsets[prefix + ".bias"]
+            part, acc = st.partial("ln", 2 * nb * E, lambda k, n: workspace(dev, k, n))
+            if not preq and acc != 2:          # frozen LayerNorm, immediate reductions: gamma/beta gradients go to scratch
+                dgamma = workspace(dev, "ln_frozen", 2 * E).data_ptr()
+                dbeta = dgamma + 4 * E
+            if acc == 2 and preq:
+                if dbeta == dgamma + 4 * E:
+                    st.defer.add(part, dgamma, 2 * E, 2 * E, nb, 1)
+                else:
+                    st.defer.add(part, dgamma, E, 2 * E, nb, 1)
+                    st.defer.add(part + 4 * E, dbeta, E, 2 * E, nb, 1)
+            return part, dgamma, dbeta, acc
+
+        rec = _PendingLN(tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register)
+        # the backward of the linear that produced x runs next and can take the LayerNorm backward into its data-gradient launch
+        # (tuber_ln_bwd_dx); everything else gets the stand-alone kernel right here
+        if not (xreq and out is None and st.defer.enabled and not ab.on("no_ln_bwd_fusion") and id(tp.target(x)) in tp.lin_out):
+            rec.force()
         if xreq:
             tp.put(x, dxd if p > 0.0 else dx)
         if rreq:
