@@ -557,6 +557,32 @@ def test_layernorm_backward_fused_into_the_linear_data_gradient(dev, M, Kin, epi
         assert bool(((out1.float() == 0) | (cm.float() > 0)).all())
 
 
+@pytest.mark.parametrize("M,N,Nq,Kin,with_res", [(30, 768, 512, 256, True), (30, 256, 256, 256, True), (30, 768, 512, 256, False), (7, 512, 256, 128, True),
+                                                 (77, 768, 512, 256, True)])
+def test_in_projection_data_gradients_in_one_launch(dev, M, N, Nq, Kin, with_res):
+    """tuber_rows_dx2 == the two tuber_gemm_nt launches of tape.py: in_proj.bwd: dx = g.W (+ res) over all N columns, dpos = g[:, :Nq].W[:Nq]"""
+    g = rnd(M, N, dev=dev, seed=1).to(BF)
+    wt = (rnd(Kin, N, dev=dev, seed=2) / 16).to(BF)            # W^T rows [Kin][N]
+    res = rnd(M, Kin, dev=dev, seed=3).to(BF) if with_res else None
+    dx0, da0 = torch.empty(M, Kin, device=dev, dtype=BF), torch.empty(M, Kin, device=dev, dtype=BF)
+    for ncols, r, out in ((N, res, dx0), (Nq, None, da0)):
+        lib.call("tuber_gemm_nt", g, N, wt, N, out, Kin, M, Kin, ncols, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                 0, None, r, Kin, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
+    dx1 = torch.full((M, Kin), float("nan"), device=dev, dtype=BF)
+    da1 = torch.full((M, Kin), float("nan"), device=dev, dtype=BF)
+    lib.call("tuber_rows_dx2", g, N, M, N, Nq, wt, N, Kin, dx1, res, da1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx1.float()).all()) and bool(torch.isfinite(da1.float()).all())
+    close("rows_dx2 dx", dx1, dx0, rel=2 ** -6)
+    close("rows_dx2 dpos", da1, da0, rel=2 ** -6)
+    ref = g.float() @ wt.float().t() + (res.float() if with_res else 0)
+    close("rows_dx2 dx vs fp32", dx1, ref, rel=2 ** -6)
+    close("rows_dx2 dpos vs fp32", da1, g.float()[:, :Nq] @ wt.float()[:, :Nq].t(), rel=2 ** -6)
+    dx2 = torch.empty(M, Kin, device=dev, dtype=BF)
+    lib.call("tuber_rows_dx2", g, N, M, N, Nq, wt, N, Kin, dx2, res, None)                # the prefix result not wanted
+    assert torch.equal(dx2, dx1)
+
+
 def test_gemm_epilogue_dropout_and_masked_dgrad(dev):
     """FFN pieces: h = Dropout(ReLU(x W1^T + b)) as one GEMM; the backward mask alpha*g*[h>0] as the epilogue of the next dgrad."""
     M, K, N, p, salt = 300, 256, 512, 0.1, 11

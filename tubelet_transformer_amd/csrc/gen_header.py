@@ -24,6 +24,9 @@ DOC = {
                        "Every workgroup runs the LayerNorm backward of its 32 rows itself and multiplies the bf16 result from LDS with W on MFMA; the column-0 workgroups "
                        "store dx / dxd / the dgamma, dbeta partial rows ([tuber_ln_bwd_dx_blocks(M)][2E]) as the two-launch path does. dy2: a second gradient contribution (replaces "
                        "a tuber_axpby launch) or NULL; res: an existing gradient of the linear's input to add; cm / alpha: the ReLU / Dropout mask of that input.",
+    "tuber_rows_dx2": "both data gradients of a packed attention in-projection with the positional embedding folded in (tuber_gemm_nt_addproj; "
+                      "models/transformer/transformer.py:150-159,215-240) in ONE launch for few rows: dx = g.W over all N columns (+ res), dpos = g[:, :Nq].W[:Nq] "
+                      "stored as a prefix of the same reduction. Replaces two tuber_gemm_nt launches per decoder in-projection.",
     "tuber_ln_bwd_dx_blocks": "partial rows tuber_ln_bwd_dx writes for M rows (32 rows per block).",
     "tuber_ln_bwd_dx_pays": "1 where tape.py uses tuber_ln_bwd_dx instead of the two launches: M <= 64 rows at any width, or Kin <= 256 (measured; the encoder's linear2 loses).",
     "tuber_ln_bwd_dx_supported": "1 when tuber_ln_bwd_dx handles a LayerNorm of width E in front of a linear with Kin inputs (E = 256, Kin % 64 = 0).",

@@ -56,6 +56,7 @@ class Tape:
         self.dry = False       # dry run: the ops allocate their outputs, draw their dropout salts and record their backward closures, but do
         self.dry_log = []      # not launch the forward kernel -- (kind, dict) per op, for a fused launch that fills those outputs (tuber.py)
         self.pending = {}      # id(gradient tensor) -> _PendingLN: a LayerNorm backward not launched yet (it may fuse into its consumer)
+        self.pair_ok = set()   # id(y) of LayerNorm outputs whose backward can take two unsummed gradient contributions (fusable ones)
         self.lin_out = set()   # id(y) of linear() outputs a LayerNorm backward may fuse into (plain linear with 256 outputs, no ReLU / Dropout)
         self.req = set()       # ids of tensors whose gradient is needed (they depend on a trainable parameter): the backward pass
         #                        skips weight gradients of frozen parameters and data gradients nobody consumes, like autograd does
@@ -77,14 +78,27 @@ class Tape:
         self.req.add(id(t))
 
     def force(self, g):
-        """launch the LayerNorm backward that produces ``g`` if it is still pending (someone is about to read or re-deposit g)"""
+        """make ``g`` a materialised tensor: launch the LayerNorm backward that produces it if that is still pending, form the sum of an
+        unsummed pair (someone is about to read or re-deposit g)"""
+        if isinstance(g, _Pair):
+            a, b = self.force(g.a), self.force(g.b)
+            out = torch.empty_like(a)
+            lib.call("tuber_axpby", a, b, out, a.numel(), 1.0, 1.0)
+            return out
         rec = self.pending.get(id(g)) if g is not None else None
         if rec is not None:
             rec.force()
         return g
 
-    def take(self, t, force=True):
+    def take(self, t, force=True, pair=False):
+        """the gradient of t (removed).  force=False: a pending LayerNorm backward stays pending; pair=True: an unsummed _Pair is returned
+        as it is (its two members materialised)"""
         g = self.g.pop(id(self.target(t)), None)
+        if isinstance(g, _Pair):
+            if not pair:
+                return self.force(g)
+            g.a, g.b = self.force(g.a), self.force(g.b)
+            return g
         return self.force(g) if force else g
 
     def peek(self, t):
@@ -102,8 +116,12 @@ class Tape:
         cur = self.g.get(id(t))
         if cur is None:
             self.g[id(t)] = g
+        elif (id(t) in self.pair_ok and not isinstance(cur, _Pair) and cur.dtype == BF and g.dtype == BF and cur.shape == g.shape
+              and cur.is_contiguous() and g.is_contiguous()):
+            self.g[id(t)] = _Pair(cur, g)                # its consumer (a fusable LayerNorm backward) adds on load
         else:
-            out = torch.empty_like(self.force(cur))
+            cur = self.force(cur)
+            out = torch.empty_like(cur)
             lib.call("tuber_axpby", cur, self.force(g), out, cur.numel(), 1.0, 1.0)
             self.g[id(t)] = out
 
@@ -120,11 +138,19 @@ class Tape:
 
     def clear(self):
         self.ops.clear(); self.g.clear(); self.alias.clear(); self.mask.clear(); self.premasked.clear(); self.stack.clear()
-        self.req.clear(); self.pending.clear(); self.lin_out.clear()
+        self.req.clear(); self.pending.clear(); self.lin_out.clear(); self.pair_ok.clear()
 
     def salt(self):
         self.store.step_seed += 1
         return self.store.step_seed
+
+
+class _Pair:
+    """two gradient contributions of one tensor whose sum has not been formed: a consumer that can add on load takes them as they are
+    (layer_norm.bwd -> tuber_ln_bwd_dx's dy / dy2), anyone else gets the tuber_axpby launch (Tape.force)"""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
 
 
 class _PendingLN:
@@ -132,8 +158,9 @@ class _PendingLN:
     normalised (attention out_proj, the FFN's linear2) -- runs next and launches LayerNorm backward + its own data-gradient GEMM as ONE
     kernel (tuber_ln_bwd_dx).  Anyone else who touches the two gradient tensors first (Tape.force) gets the stand-alone launch."""
 
-    def __init__(self, tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register):
+    def __init__(self, tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register, g2=None):
         self.tp, self.g, self.gptr, self.ldg, self.xhat, self.rstd, self.gamma = tp, g, gptr, ldg, xhat, rstd, gamma
+        self.g2 = g2                                     # a second, unsummed contribution to the LayerNorm output's gradient (or None)
         self.dx, self.dxd, self.p, self.salt, self.M, self.E, self.register = dx, dxd, p, salt, M, E, register
         self.keys = [id(t) for t in (dx, dxd) if t is not None]
         for k in self.keys:
@@ -146,6 +173,9 @@ class _PendingLN:
     def force(self):
         st = self.tp.store
         self._done()
+        if self.g2 is not None:                          # the stand-alone kernel takes one gradient tensor
+            self.g = self.tp.force(_Pair(self.g, self.g2))
+            self.gptr, self.ldg, self.g2 = self.g.data_ptr(), self.E, None
         nb = lib.query("tuber_layernorm_bwd_blocks", self.M)
         part, dgamma, dbeta, acc = self.register(nb)
         lib.call("tuber_layernorm_bwd", self.gptr, self.ldg, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, dgamma, dbeta, acc,
@@ -158,7 +188,7 @@ class _PendingLN:
         nb = lib.query("tuber_ln_bwd_dx_blocks", self.M)
         part, _, _, acc = self.register(nb)
         assert acc == 2
-        lib.call("tuber_ln_bwd_dx", self.gptr, self.ldg, None, 0, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, self.M, self.E,
+        lib.call("tuber_ln_bwd_dx", self.gptr, self.ldg, self.g2, self.E if self.g2 is not None else 0, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, self.M, self.E,
                  self.p, st.seed, self.salt, wt, ldt, Kin, out, res, cm, alpha)
 
 
@@ -392,6 +422,24 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
         plain = lambda ncols, res, out: lib.call("tuber_gemm_nt", g, N, wt, ldt, out, K, M, K, ncols, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                                  0, None, res, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
         shared = False
+        if xreq and areq and M <= 64 and K % 64 == 0 and not ab.on("no_in_proj_dx2"):
+            # few rows (the decoder's queries): both data gradients from ONE pass over g and W -- the addend's is a prefix of x's reduction
+            tx = tp.target(x)
+            r = None
+            if id(tx) not in tp.stack:
+                r = tp.force(tp.g.pop(id(tx), None))
+                if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous()):
+                    tp.g[id(tx)] = r
+                    r = None
+            if r is not None or add_cols < N:            # (else the two gradients are the same tensor: the one plain GEMM below)
+                dx = torch.empty(M, K, dtype=BF, device=dev)
+                da = torch.empty(M, K, dtype=BF, device=dev)
+                lib.call("tuber_rows_dx2", g, N, M, N, add_cols, wt, ldt, K, dx, r, da)
+                tp.put(tx, dx)
+                tp.put(addend, da)
+                return
+            if r is not None:
+                tp.g[id(tx)] = r
         if xreq:
             tx = tp.target(x)
             dx = torch.empty(M, K, dtype=BF, device=dev)
@@ -446,12 +494,17 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
     if not (preq or xreq or rreq):
         return y
     tp.mark(y)
+    if xreq and out is None and id(tp.target(x)) in tp.lin_out and not ab.on("no_ln_bwd_fusion"):
+        tp.pair_ok.add(id(y))                            # two contributions to y's gradient stay unsummed: tuber_ln_bwd_dx adds them on load
 
     def bwd():
+        g2 = None
         if out is None:
-            g = tp.take(y)
+            g = tp.take(y, pair=True)
             if g is None:
                 return
+            if isinstance(g, _Pair):
+                g, g2 = g.a, g.b
             gptr, ldg = g.data_ptr(), E
         else:
             g = tp.peek(base)               # shared with the other writers of base; dropped when the tape is cleared
@@ -479,7 +532,7 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
                     st.defer.add(part + 4 * E, dbeta, E, 2 * E, nb, 1)
             return part, dgamma, dbeta, acc
 
-        rec = _PendingLN(tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register)
+        rec = _PendingLN(tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register, g2)
         # the backward of the linear that produced x runs next and can take the LayerNorm backward into its data-gradient launch
         # (tuber_ln_bwd_dx); everything else gets the stand-alone kernel right here
         if not (xreq and out is None and st.defer.enabled and not ab.on("no_ln_bwd_fusion") and id(tp.target(x)) in tp.lin_out):
