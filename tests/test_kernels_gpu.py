@@ -558,7 +558,7 @@ def test_layernorm_backward_fused_into_the_linear_data_gradient(dev, M, Kin, epi
 
 
 @pytest.mark.parametrize("M,N,Nq,Kin,with_res", [(30, 768, 512, 256, True), (30, 256, 256, 256, True), (30, 768, 512, 256, False), (7, 512, 256, 128, True),
-                                                 (77, 768, 512, 256, True)])
+                                                 (77, 768, 512, 256, True), (30, 2048, 2048, 256, True), (30, 2048, 1024, 256, False), (30, 1280, 512, 64, True)])
 def test_in_projection_data_gradients_in_one_launch(dev, M, N, Nq, Kin, with_res):
     """tuber_rows_dx2 == the two tuber_gemm_nt launches of tape.py: in_proj.bwd: dx = g.W (+ res) over all N columns, dpos = g[:, :Nq].W[:Nq]"""
     g = rnd(M, N, dev=dev, seed=1).to(BF)

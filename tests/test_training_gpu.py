@@ -547,6 +547,9 @@ def _ab_names():
 # is bit-stable; these three measure median 4-7 % / p99 20-50 % on the gradients), so they are held tightly on the eval-mode outputs
 # and to the chaos level on the training gradients; every other switch only regroups launches and measures <= 8 % on single tensors.
 _AB_FORWARD = {"dw_register_tiled", "no_blockout_conv1", "no_entry_conv", "no_decoder_coop"}
+# backward-only switches that change the fp32 SUMMATION ORDER of a data-gradient GEMM (other split of the reduction over waves): the bf16
+# rounding of that gradient flips on a few elements and everything below it moves by a bf16 ulp -- linear, no chaos: median <= 1e-2
+_AB_SUMORDER = {"no_in_proj_dx2"}
 
 
 @pytest.mark.parametrize("name", _ab_names())
@@ -583,7 +586,7 @@ def test_every_ab_switch_reproduces_the_default_path(dev, name):
     if fwd:
         assert med <= 0.15 and rels[0][0] <= 1.0, (med, rels[:3])
     else:
-        assert rels[0][0] <= 0.15 and med <= 1e-3, (med, rels[:3])      # (a wrong kernel is O(1) on everything below it)
+        assert rels[0][0] <= 0.15 and med <= (1e-2 if name in _AB_SUMORDER else 1e-3), (med, rels[:3])      # (a wrong kernel is O(1) on everything below it)
     for n in b0:
         assert torch.allclose(b0[n], b1[n], rtol=2e-2 if fwd else 1e-5, atol=2e-3 if fwd else 1e-6), n
     print("TUBER_AB=%s: loss %.6f vs %.6f, median / worst gradient relerr %.2e / %.2e (%s)" % (name, l1, l0, med, rels[0][0], rels[0][1]))

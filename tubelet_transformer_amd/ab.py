@@ -27,7 +27,7 @@ KNOWN = {
     "no_stem_bn_in_wgrad": "stand-alone bn_bwd_apply for the stem instead of forming it inside the stem weight-gradient kernel",
     "dw_register_tiled": "the register-tiled depthwise kernels (used for the strided blocks) for every block",
     "no_ln_bwd_fusion": "LayerNorm backward and the data-gradient GEMM of the linear in front of it as two launches (no tuber_ln_bwd_dx)",
-    "no_in_proj_dx2": "the two data gradients of a decoder in-projection (x and query_pos) as two GEMM launches instead of tuber_rows_dx2",
+    "no_in_proj_dx2": "the few-row data gradients of the decoder (in-projection: x and query_pos; linear1) as tuber_gemm_nt launches instead of tuber_rows_dx2",
     "no_decoder_coop": "the DETR decoder stack as its ~80 separate launches instead of the one cooperative launch (csrc/decoder_coop.hip)",
     "eager_step": "train_tuber_detection without the captured hipGraph step",
 }

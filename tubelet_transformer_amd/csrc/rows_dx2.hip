@@ -4,8 +4,7 @@
 //     dx   = g . W            over all N columns of g   (+ the gradient x already holds)
 //     dpos = g[:, :Nq] . W[:Nq]   over the q / k columns only
 // tape.py: in_proj.bwd launched them as two tuber_gemm_nt calls of 4 workgroups each (30 decoder rows: ~5 + ~8 us, launch-bound).
-// dpos is a PREFIX of dx's reduction: each wave walks its 16 output columns through the reduction in order, stores the accumulator as
-// dpos when it has passed Nq and goes on to N -- one pass over g and W, two results.
+// dpos is a PREFIX of dx's reduction: one pass over g and W, two results.
 #include "common.h"
 
 namespace {
@@ -39,37 +38,52 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[2], bf16* out, con
     }
 }
 
-// grid (row blocks of 32, Kin / 64); wave = 16 output columns; weights = MFMA A operand (one 16-byte load per lane and k-step straight from
-// the row-major W^T), activations = B operand from global rows (30 x 768 bf16: L2-resident, read by the 4 waves of 4 workgroups)
+// grid (row blocks of 32, Kin / 16): a workgroup owns 16 output columns; its four waves take consecutive spans of the reduction (256 elements
+// each up to N = 1024, 512 up to 2048, ...), so the 30 x 768 in-projection runs on 16 workgroups x 3 waves instead of 4 x 1 (12.5 -> ~6 us) and
+// linear1's data gradient (N = 2048) on 16 x 4.  Weights = MFMA A operand (one 16-byte load per lane and k-step straight from the row-major
+// W^T), activations = B operand from global rows (L2-resident); partial accumulators meet in LDS, wave 0 adds them in wave order: the waves
+// whose span lies below Nq give dpos, all of them dx.  Nq is a multiple of the span (host check).
 __global__ __launch_bounds__(256) void rows_dx2_kernel(Dx2Args a) {
+    __shared__ f32x4 red[4][2][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int r0 = blockIdx.x * RB, rows = min(RB, a.M - r0);
-    const int col0 = blockIdx.y * 64 + w * 16;
+    const int col0 = blockIdx.y * 16;
+    const int span = 256 * ((a.N + 1023) / 1024);
+    const int kb = w * span, ke = min(a.N, kb + span);
     const bf16* wp = a.wt + (long)(col0 + li) * a.ldt + g * 8;
     const bf16* xp[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) xp[rt] = a.g + (long)(r0 + min(rt * 16 + li, rows - 1)) * a.ldg + g * 8;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     // chunks of 256 reduction elements: 8 weight + 16 activation fragments in flight per lane
-    for (int k0 = 0; k0 < a.N; k0 += 256) {
+    for (int k0 = kb; k0 < ke; k0 += 256) {
         uint4 wf[8], xf[2][8];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            const bool ok = k0 + kk * 32 < a.N;
+            const bool ok = k0 + kk * 32 < ke;
             wf[kk] = ok ? *(const uint4*)(wp + k0 + kk * 32) : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) xf[rt][kk] = ok ? *(const uint4*)(xp[rt] + k0 + kk * 32) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (k0 + kk * 32 == a.Nq && a.dpos && a.Nq < a.N) store_tile(acc, a.dpos, nullptr, a.Kin, r0, rows, col0, li, g);
+        for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) acc[rt] = mma(as_bf16x8(wf[kk]), as_bf16x8(xf[rt][kk]), acc[rt]);
-        }
     }
-    if (a.dpos && a.Nq >= a.N) store_tile(acc, a.dpos, nullptr, a.Kin, r0, rows, col0, li, g);
-    store_tile(acc, a.dx, a.res, a.Kin, r0, rows, col0, li, g);
+    red[w][0][lane] = acc[0]; red[w][1][lane] = acc[1];
+    __syncthreads();
+    if (w) return;
+    f32x4 tot[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, pre[2] = {tot[0], tot[1]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i * span >= a.N) break;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) tot[rt] += red[i][rt][lane];
+        if ((i + 1) * span == a.Nq || ((i + 1) * span > a.N && a.Nq == a.N)) { pre[0] = tot[0]; pre[1] = tot[1]; }
+    }
+    if (a.dpos) store_tile(pre, a.dpos, nullptr, a.Kin, r0, rows, col0, li, g);
+    store_tile(tot, a.dx, a.res, a.Kin, r0, rows, col0, li, g);
 }
 
 }  // namespace
@@ -77,16 +91,19 @@ __global__ __launch_bounds__(256) void rows_dx2_kernel(Dx2Args a) {
 extern "C" {
 
 // dx[M][Kin] = g[M][:N] . W (+ res);  dpos[M][Kin] = g[M][:Nq] . W[:Nq]  (bare; NULL: not wanted) -- W^T given as rows wt[Kin][ldt].
-// N, Nq multiples of 32, Nq <= N, Kin a multiple of 64.  Meant for the few-row case (the DETR decoder's 30 query rows).
+// N a multiple of 32, Nq = N or a multiple of the per-wave span (256 up to N = 1024, 512 up to 2048), Kin a multiple of 16.  Meant for the few-row case
+// (the DETR decoder's 30 query rows); with dpos = NULL it is a plain few-row data-gradient GEMM (linear1's, N = 2048).
 int tuber_rows_dx2(const void* g, long ldg, int M, int N, int Nq, const void* wt, long ldt, int Kin, void* dx, const void* res, void* dpos,
                    hipStream_t stream) {
-    if (M <= 0 || N <= 0 || (N & 31) || Nq <= 0 || (Nq & 31) || Nq > N || Kin <= 0 || (Kin & 63) || ldg < N || (ldg & 7) || ldt < N || (ldt & 7) || !dx)
+    const int span = 256 * ((N + 1023) / 1024);
+    if (M <= 0 || N <= 0 || (N & 31) || N > 4 * span || Nq <= 0 || Nq > N || (Nq != N && (Nq % span)) || Kin <= 0 || (Kin & 15) || ldg < N || (ldg & 7) ||
+        ldt < N || (ldt & 7) || !dx)
         return TUBER_EINVAL;
     Dx2Args a;
     a.g = (const bf16*)g; a.ldg = ldg; a.M = M; a.N = N; a.Nq = Nq;
     a.wt = (const bf16*)wt; a.ldt = ldt; a.Kin = Kin;
     a.dx = (bf16*)dx; a.res = (const bf16*)res; a.dpos = (bf16*)dpos;
-    hipLaunchKernelGGL(rows_dx2_kernel, dim3(ceil_div(M, RB), Kin / 64), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rows_dx2_kernel, dim3(ceil_div(M, RB), Kin / 16), dim3(256), 0, stream, a);
     TUBER_RETURN_LAUNCH();
 }
 

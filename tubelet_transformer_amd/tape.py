@@ -336,6 +336,9 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                      2, None, None, 0, 0, 0, None, None, x, K, None, None, tp.mask[id(tx)], 0.0, None, 0, None, 0, None)
             tp.premasked.add(id(tx))
+        elif M <= 64 and Kred >= 1024 and K % 16 == 0 and ldg % 8 == 0 and not ab.on("no_in_proj_dx2"):
+            # few rows, long reduction (the decoder's linear1): 16 workgroups x 4 waves over the reduction instead of 4 wave-split tiles
+            lib.call("tuber_rows_dx2", gb, ldg, M, Kred, Kred, wt, ldt, K, dx, r, None)
         else:
             lib.call("tuber_gemm_nt", gb, ldg, wt, ldt, dx, K, M, K, Kred, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                      0, None, r, K, 0, 0, None, None, None, 0, None, None, 1.0, 0.0, None, 0, None, 0, None)
