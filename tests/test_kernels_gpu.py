@@ -544,7 +544,7 @@ def test_layernorm_backward_fused_into_the_linear_data_gradient(dev, M, Kin, epi
     out1 = torch.full((M, Kin), float("nan"), device=dev, dtype=BF)
     assert lib.query("tuber_ln_bwd_dx_supported", E, Kin) == 1
     lib.call("tuber_ln_bwd_dx", dy, E, dy2, E if two else 0, xh, rstd, gam, dx1, dxd1 if p > 0 else None, part1, M, E, p, seed, salt,
-             wt, E, Kin, out1, res, cm, alpha)
+             wt, E, Kin, out1, res, cm, alpha, None, 0, None, None, None, None)
     torch.cuda.synchronize()
     for name, a, b in (("dx", dx1, dx0),) + ((("dxd", dxd1, dxd0),) if p > 0 else ()):
         d = (a.float() - b.float()).abs()
@@ -555,6 +555,34 @@ def test_layernorm_backward_fused_into_the_linear_data_gradient(dev, M, Kin, epi
     close("ln_bwd_dx product", out1, out0, rel=2 ** -6)
     if epi == "mask":
         assert bool(((out1.float() == 0) | (cm.float() > 0)).all())
+    if two:
+        # the second contribution formed ON LOAD as the backward of another LayerNorm (no Dropout / residual) from its output gradient ga:
+        # same results as handing over that backward's stored output, plus that LayerNorm's partial rows
+        ga = rnd(M, 2 * E, dev=dev, seed=8).to(BF)[:, E:]                     # a column window (ld = 2E), as the decoder's hs gradient is
+        xha = rnd(M, E, dev=dev, seed=9).to(BF)
+        rstda = 0.5 + torch.rand(M, device=dev)
+        gama = 1 + 0.1 * rnd(E, dev=dev, seed=10)
+        parta0 = torch.zeros(nb0, 2 * E, device=dev)
+        dxa = torch.empty(M, E, device=dev, dtype=BF)
+        lib.call("tuber_layernorm_bwd", ga, 2 * E, xha, rstda, gama, dxa, None, parta0, None, None, 2, M, E, 0.0, None, 0)
+        outs = []
+        for chained in (False, True):
+            pa, pb = torch.zeros(nb1, 2 * E, device=dev), torch.zeros(nb1, 2 * E, device=dev)
+            dxx, dxdx, oo = (torch.full((M, n), float("nan"), device=dev, dtype=BF) for n in (E, E, Kin))
+            extra = (ga, 2 * E, xha, rstda, gama, pb) if chained else (None, 0, None, None, None, None)
+            lib.call("tuber_ln_bwd_dx", dy, E, None if chained else dxa, 0 if chained else E, xh, rstd, gam, dxx, dxdx if p > 0 else None, pa, M, E, p, seed, salt,
+                     wt, E, Kin, oo, res, cm, alpha, *extra)
+            outs.append((dxx, dxdx, oo, pa, pb))
+        torch.cuda.synchronize()
+        for i in range(3 if p > 0 else 1):
+            a, b = outs[1][i].float(), outs[0][i].float()
+            if i == 1 and p == 0:
+                continue
+            d = (a - b).abs()
+            assert bool(torch.isfinite(a).all()) and float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2 ** -6 * float(b.abs().max()), i
+        close("chained: product", outs[1][2], outs[0][2], rel=2 ** -6)
+        close("chained: partial rows", outs[1][3].sum(0), outs[0][3].sum(0), rel=1e-4)
+        close("chained: the other LayerNorm's partial rows", outs[1][4].sum(0), parta0.sum(0), rel=1e-4)
 
 
 @pytest.mark.parametrize("M,N,Nq,Kin,with_res", [(30, 768, 512, 256, True), (30, 256, 256, 256, True), (30, 768, 512, 256, False), (7, 512, 256, 128, True),

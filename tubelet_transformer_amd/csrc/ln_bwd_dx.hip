@@ -21,6 +21,9 @@ constexpr int PX = 264;                    // bf16 pitch of the [32][256] operan
 
 struct LnDxArgs {
     const bf16* dy; long lddy; const bf16* dy2; long lddy2;      // gradient of the LayerNorm output (dy2: a second contribution, or NULL)
+    // ... or that second contribution is itself the backward of ANOTHER LayerNorm over the same rows (the decoder's shared decoder.norm on each
+    // layer's output, no Dropout, no residual): its output gradient ga, saved xhat / rstd, gamma and partial rows (ga != NULL excludes dy2)
+    const bf16* ga; long ldga; const bf16* xhat_a; const float* rstd_a; const float* gamma_a; float* part_a;
     const bf16* xhat; const float* rstd; const float* gamma;
     bf16* dx; bf16* dxd; float* part;                             // what layernorm_bwd stores ([blocks][2E] partials)
     int M; uint32_t thresh; float inv_keep; const uint64_t* seed_ptr; uint64_t salt;
@@ -57,8 +60,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(LnDxArgs a) {
     }
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     // all eight rows of the wave are fetched together (the rows are independent; one row per trip waited for its own round trip)
-    uint2 rd[RB / 4], rh[RB / 4], rd2[RB / 4];
-    float rrs[RB / 4];
+    uint2 rd[RB / 4], rh[RB / 4], rd2[RB / 4], rha[RB / 4];
+    float rrs[RB / 4], rrsa[RB / 4];
+    float gma[4] = {0.f, 0.f, 0.f, 0.f}, aga[4] = {0.f, 0.f, 0.f, 0.f}, aba[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.ga) {
+        const float4 gv = *(const float4*)(a.gamma_a + lane * 4);
+        gma[0] = gv.x; gma[1] = gv.y; gma[2] = gv.z; gma[3] = gv.w;
+    }
 #pragma unroll
     for (int k = 0; k < RB / 4; ++k) {
         const int row = r0 + min(w + 4 * k, rows - 1);
@@ -66,6 +74,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(LnDxArgs a) {
         rh[k] = *(const uint2*)(a.xhat + (long)row * E + lane * 4);
         if (a.dy2) rd2[k] = *(const uint2*)(a.dy2 + (long)row * a.lddy2 + lane * 4);
         rrs[k] = a.rstd[row];
+        if (a.ga) {
+            rd2[k] = *(const uint2*)(a.ga + (long)row * a.ldga + lane * 4);
+            rha[k] = *(const uint2*)(a.xhat_a + (long)row * E + lane * 4);
+            rrsa[k] = a.rstd_a[row];
+        }
     }
 #pragma unroll
     for (int k = 0; k < RB / 4; ++k) {
@@ -81,6 +94,20 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(LnDxArgs a) {
                 const bf16x4 db = as_bf16x4(rd2[k]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = bf2f(f2bf(d[e] + bf2f(db[e])));
+            } else if (a.ga) {                          // the other LayerNorm's backward first (layernorm_bwd_kernel's arithmetic, bf16 result), then the sum
+                const bf16x4 da2 = as_bf16x4(rd2[k]), ha = as_bf16x4(rha[k]);
+                float d2[4], h2[4], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d2[e] = bf2f(da2[e]); h2[e] = bf2f(ha[e]);
+                    aga[e] += d2[e] * h2[e]; aba[e] += d2[e];
+                    const float gd = d2[e] * gma[e];
+                    t1 += gd; t2 += gd * h2[e];
+                }
+                t1 = wave_sum(t1) * (1.f / E);
+                t2 = wave_sum(t2) * (1.f / E);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = bf2f(f2bf(d[e] + bf2f(f2bf(rrsa[k] * (d2[e] * gma[e] - t1 - h2[e] * t2)))));
             }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -116,6 +143,14 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(LnDxArgs a) {
         const int col = tid;                            // 256 threads = E columns
         a.part[(long)blockIdx.x * 2 * E + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
         a.part[(long)blockIdx.x * 2 * E + E + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        if (a.ga) {                                     // (uniform branch: a.ga is a kernel argument)
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[0][w][lane * 4 + e] = aga[e]; red[1][w][lane * 4 + e] = aba[e]; }
+            __syncthreads();
+            a.part_a[(long)blockIdx.x * 2 * E + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+            a.part_a[(long)blockIdx.x * 2 * E + E + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        }
     }
 
     // ---- out[r0 + .][colbase + ..] = img . W^T: weights = MFMA A operand, so lane (li, g) ends with acc[rt][r] = out[rt*16 + li][col + g*4 + r] ----
@@ -184,14 +219,19 @@ int tuber_ln_bwd_dx_pays(int M, int E_, int Kin) { return tuber_ln_bwd_dx_suppor
 // LayerNorm backward (tuber_layernorm_bwd with accumulate = 2: partial rows only) + the data-gradient product of the linear in front of it:
 //   dxn = LN'(dy [+ dy2]);  dx = dxn (if given);  dxd = Dropout-masked dxn (if given; required when p > 0);
 //   out[M][Kin] = (p > 0 ? dxd : dxn) . W   with W^T given as rows wt[Kin][ldt]  [+ res | masked by cm > 0 and scaled by alpha]
+// ga .. partial_a (or NULLs): the second contribution is the backward of another LayerNorm over the same rows (no Dropout / residual), formed
+// on load from ITS output gradient and saved xhat / rstd; its dgamma / dbeta partial rows go to partial_a (same block count)
 int tuber_ln_bwd_dx(const void* dy, long lddy, const void* dy2, long lddy2, const void* xhat, const float* rstd, const float* gamma,
                     void* dx, void* dxd, float* partial, int M, int E_, float p, const void* seed_ptr, unsigned long long salt,
-                    const void* wt, long ldt, int Kin, void* out, const void* res, const void* cm, float alpha, hipStream_t stream) {
+                    const void* wt, long ldt, int Kin, void* out, const void* res, const void* cm, float alpha,
+                    const void* ga, long ldga, const void* xhat_a, const float* rstd_a, const float* gamma_a, float* partial_a, hipStream_t stream) {
+    if (ga && (dy2 || ldga < E || (ldga & 3) || !xhat_a || !rstd_a || !gamma_a || !partial_a)) return TUBER_EINVAL;
     if (!tuber_ln_bwd_dx_supported(E_, Kin) || M <= 0 || lddy < E || (lddy & 3) || (dy2 && (lddy2 < E || (lddy2 & 3))) || ldt < E || (ldt & 7) ||
         p < 0.f || p >= 1.f || (p > 0.f && !dxd) || !partial || !out || (res && cm))
         return TUBER_EINVAL;
     LnDxArgs a;
     a.dy = (const bf16*)dy; a.lddy = lddy; a.dy2 = (const bf16*)dy2; a.lddy2 = lddy2;
+    a.ga = (const bf16*)ga; a.ldga = ldga; a.xhat_a = (const bf16*)xhat_a; a.rstd_a = rstd_a; a.gamma_a = gamma_a; a.part_a = partial_a;
     a.xhat = (const bf16*)xhat; a.rstd = rstd; a.gamma = gamma;
     a.dx = (bf16*)dx; a.dxd = (bf16*)dxd; a.part = partial;
     a.M = M; a.thresh = (uint32_t)((double)p * 4294967296.0); a.inv_keep = dropout_inv_keep(p);

@@ -97,7 +97,7 @@ class Tape:
         if isinstance(g, _Pair):
             if not pair:
                 return self.force(g)
-            g.a, g.b = self.force(g.a), self.force(g.b)
+            g.a = self.force(g.a)                        # (b may stay a pending LayerNorm backward: _PendingLN.fuse forms it on load)
             return g
         return self.force(g) if force else g
 
@@ -188,8 +188,21 @@ class _PendingLN:
         nb = lib.query("tuber_ln_bwd_dx_blocks", self.M)
         part, _, _, acc = self.register(nb)
         assert acc == 2
-        lib.call("tuber_ln_bwd_dx", self.gptr, self.ldg, self.g2, self.E if self.g2 is not None else 0, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, self.M, self.E,
-                 self.p, st.seed, self.salt, wt, ldt, Kin, out, res, cm, alpha)
+        # the second contribution: a tensor (added on load), or the still-pending backward of ANOTHER LayerNorm over the same rows without
+        # Dropout / residual (decoder.norm on this layer's output) -- formed on load from its own saved tensors, never materialised
+        ra = self.tp.pending.get(id(self.g2)) if self.g2 is not None else None
+        if ra is not None and not (ra.p == 0.0 and ra.dxd is None and ra.g2 is None and ra.M == self.M and ra.E == self.E and ra.dx is self.g2):
+            ra = None
+        if ra is not None:
+            ra._done()
+            part_a, _, _, acc_a = ra.register(nb)
+            assert acc_a == 2
+            g2, other = None, (ra.gptr, ra.ldg, ra.xhat, ra.rstd, ra.gamma, part_a)
+            self.keep = (ra.g, ra.dx)
+        else:
+            g2, other = self.tp.force(self.g2), (None, 0, None, None, None, None)
+        lib.call("tuber_ln_bwd_dx", self.gptr, self.ldg, g2, self.E if g2 is not None else 0, self.xhat, self.rstd, self.gamma, self.dx, self.dxd, part, self.M, self.E,
+                 self.p, st.seed, self.salt, wt, ldt, Kin, out, res, cm, alpha, *other)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -507,7 +520,7 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
             if g is None:
                 return
             if isinstance(g, _Pair):
-                g, g2 = g.a, g.b
+                g, g2 = g.a, g.b                         # (g2 may be a pending LayerNorm backward, see _PendingLN.fuse)
             gptr, ldg = g.data_ptr(), E
         else:
             g = tp.peek(base)               # shared with the other writers of base; dropped when the tape is cleared
@@ -538,7 +551,12 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
         rec = _PendingLN(tp, g, gptr, ldg, xhat, rstd, gamma, dx, dxd, p, salt, M, E, register, g2)
         # the backward of the linear that produced x runs next and can take the LayerNorm backward into its data-gradient launch
         # (tuber_ln_bwd_dx); everything else gets the stand-alone kernel right here
-        if not (xreq and out is None and st.defer.enabled and not ab.on("no_ln_bwd_fusion") and id(tp.target(x)) in tp.lin_out):
+        fusable = xreq and out is None and st.defer.enabled and not ab.on("no_ln_bwd_fusion") and id(tp.target(x)) in tp.lin_out
+        # ... and a LayerNorm without Dropout / residual over the OUTPUT of such a LayerNorm (the shared decoder.norm on every decoder layer's
+        # output) whose input already holds a gradient: the pair stays unsummed and that LayerNorm's fused backward forms this one on load
+        chained = (xreq and out is not None and p == 0.0 and res is None and E == 256 and st.defer.enabled and not ab.on("no_ln_bwd_fusion")
+                   and id(tp.target(x)) in tp.pair_ok and isinstance(tp.g.get(id(tp.target(x))), torch.Tensor))
+        if not (fusable or chained):
             rec.force()
         if xreq:
             tp.put(x, dxd if p > 0.0 else dx)
