@@ -180,11 +180,32 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g_l, g_b, g_x, g_g = ctx.saved_tensors
-        g = g.float()
-        gl = g[:, 0].view(-1, 1, 1, 1) * g_l
-        gb = g[:, 1].view(-1, 1, 1, 1) * g_b if ctx.ava else None
-        gx = g[:, 2].view(-1, 1, 1, 1) * g_x + g[:, 3].view(-1, 1, 1, 1) * g_g
+        g = g.float().contiguous()
+        L = g_l.shape[0]
+        gl, gx = torch.empty_like(g_l), torch.empty_like(g_x)
+        gb = torch.empty_like(g_b) if ctx.ava else None
+        lib.call("tuber_criterion_scale", g, g_l, g_b if ctx.ava else None, g_x, g_g, L, g_l.numel() // L, g_b.numel() // L, g_x.numel() // L, gl, gb, gx)
         return gl, gb, gx, None, None, None, None, None
+
+
+class _WeightedSum(torch.autograd.Function):
+    """sum(lv * W) of the [L,4] loss table and the [L,4] weight table in one launch each way (tuber_weighted_sum)"""
+
+    @staticmethod
+    def forward(ctx, lv, W):
+        lv = lv.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=lv.device)
+        lib.call("tuber_weighted_sum", lv, W, lv.numel(), out, None, None)
+        ctx.save_for_backward(W)
+        ctx.shape = lv.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (W,) = ctx.saved_tensors
+        gl = torch.empty(ctx.shape, dtype=torch.float32, device=W.device)
+        lib.call("tuber_weighted_sum", None, W, W.numel(), None, g.float().contiguous(), gl)
+        return gl, None
 
 
 class _SetCriterionBase(nn.Module):
@@ -276,7 +297,7 @@ class _SetCriterionBase(nn.Module):
         vals = tuple(float(wd.get(n + ("" if l == L - 1 else "_%d" % l), 0.0)) for l in range(L) for n in names)
         W, wb = self.sync_weights(lv.device, vals)
         if ce_b is None:
-            return (lv * W).sum()
+            return _WeightedSum.apply(lv, W)
         Wm = W.clone()
         Wm[:, 1] = 0
         total = (lv * Wm).sum() + (ce_b * wb).sum()

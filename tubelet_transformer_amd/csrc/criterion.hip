@@ -383,6 +383,38 @@ __global__ void targets_pack_kernel(TargetPack a) {
     }
 }
 
+__global__ __launch_bounds__(256) void criterion_scale_kernel(const float* __restrict__ g, const float* __restrict__ g_l, const float* __restrict__ g_b,
+                                                              const float* __restrict__ g_x, const float* __restrict__ g_g, long nl, long nb, long nx,
+                                                              float* __restrict__ gl, float* __restrict__ gb, float* __restrict__ gx) {
+    const int l = blockIdx.y;
+    const float c0 = g[l * 4 + 0], c1 = g[l * 4 + 1], c2 = g[l * 4 + 2], c3 = g[l * 4 + 3];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nl) { gl[l * nl + i] = c0 * g_l[l * nl + i]; return; }
+    i -= nl;
+    if (i < nb) { gb[l * nb + i] = c1 * g_b[l * nb + i]; return; }
+    i -= nb;
+    if (i < nx) gx[l * nx + i] = __fadd_rn(__fmul_rn(c2, g_x[l * nx + i]), __fmul_rn(c3, g_g[l * nx + i]));      // (two rounded products, as the ATen ops formed it)
+}
+
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w, int n, float* __restrict__ out,
+                                                           const float* __restrict__ gout, float* __restrict__ out_g) {
+    if (gout) {
+        const float c = gout[0];
+        for (int i = threadIdx.x; i < n; i += 256) out_g[i] = c * w[i];
+        return;
+    }
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += a[i] * w[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 extern "C" {
 
 int tuber_criterion_cost(const float* logits, const float* logits_b, const float* boxes, const float* tboxes, const float* tlabels,
@@ -406,6 +438,26 @@ int tuber_criterion_loss(const float* logits, const float* logits_b, const float
     a.match = match; a.L = L; a.B = B; a.Q = Q; a.C = C; a.Tmax = Tmax; a.ava = ava; a.eos = eos; a.pos_weight = pos_weight;
     a.losses = losses; a.g_logits = g_logits; a.g_logits_b = g_logits_b; a.g_bbox = g_bbox; a.g_giou = g_giou;
     hipLaunchKernelGGL(criterion_loss_kernel, dim3(L), dim3(256), (size_t)B * Q * sizeof(int), stream, a);
+    TUBER_RETURN_LAUNCH();
+}
+
+// backward of tuber_criterion_loss's [L][4] loss table in ONE launch: the stored per-layer gradients scaled by the incoming gradient g[L][4]
+//   gl = g[:,0] * g_logits;  gb = g[:,1] * g_logits_b (ava);  gx = g[:,2] * g_bbox + g[:,3] * g_giou
+// (five elementwise ATen launches before).  nl / nb / nx = elements per layer of the three tensors.
+int tuber_criterion_scale(const float* g, const float* g_logits, const float* g_logits_b, const float* g_bbox, const float* g_giou, int L, long nl,
+                          long nb, long nx, float* gl, float* gb, float* gx, hipStream_t stream) {
+    if (L <= 0 || nl <= 0 || nx <= 0 || !g || !gl || !gx || (gb && !g_logits_b)) return TUBER_EINVAL;
+    const long per = nl + (gb ? nb : 0) + nx;
+    hipLaunchKernelGGL(criterion_scale_kernel, dim3((unsigned)ceil_div(per, 256), L), dim3(256), 0, stream, g, g_logits, g_logits_b, g_bbox, g_giou,
+                       nl, gb ? nb : 0, nx, gl, gb, gx);
+    TUBER_RETURN_LAUNCH();
+}
+
+// out[0] = sum_i a[i] * w[i] (n <= 4096, fixed summation order) and, for the backward, out_g[i] = gout[0] * w[i] when gout is given instead of a
+// (`(losses * W).sum()` and its autograd: two + one ATen launches before)
+int tuber_weighted_sum(const float* a, const float* w, int n, float* out, const float* gout, float* out_g, hipStream_t stream) {
+    if (n <= 0 || n > 4096 || !w || (!a && !gout) || (a && !out) || (gout && !out_g)) return TUBER_EINVAL;
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, stream, a, w, n, out, gout, out_g);
     TUBER_RETURN_LAUNCH();
 }
 

@@ -27,6 +27,10 @@ DOC = {
     "tuber_rows_dx2": "both data gradients of a packed attention in-projection with the positional embedding folded in (tuber_gemm_nt_addproj; "
                       "models/transformer/transformer.py:150-159,215-240) in ONE launch for few rows: dx = g.W over all N columns (+ res), dpos = g[:, :Nq].W[:Nq] "
                       "stored as a prefix of the same reduction. Replaces two tuber_gemm_nt launches per decoder in-projection.",
+    "tuber_criterion_scale": "backward of tuber_criterion_loss's loss table in one launch: the stored per-layer gradients scaled by the incoming gradient of the [L][4] "
+                             "losses (autograd of the weighted sum of loss terms, models/criterion.py:169-206 + train_tuber_ava.py loss weighting).",
+    "tuber_weighted_sum": "sum_i a[i] w[i] on the device in a fixed order, or its backward gout * w: the weighted total of the loss terms "
+                          "(pipelines/video_action_recognition.py:147) without ATen launches.",
     "tuber_ln_bwd_dx_blocks": "partial rows tuber_ln_bwd_dx writes for M rows (32 rows per block).",
     "tuber_ln_bwd_dx_pays": "1 where tape.py uses tuber_ln_bwd_dx instead of the two launches: M <= 64 rows at any width, or Kin <= 256 (measured; the encoder's linear2 loses).",
     "tuber_ln_bwd_dx_supported": "1 when tuber_ln_bwd_dx handles a LayerNorm of width E in front of a linear with Kin inputs (E = 256, Kin % 64 = 0).",
