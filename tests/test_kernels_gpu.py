@@ -1127,7 +1127,7 @@ def test_bn_bwd_one_launch_matches_finalize_plus_apply(dev, M, C, R):
     dz = rnd(M, C, dev=dev, seed=1).to(BF)
     x = rnd(M, C, dev=dev, seed=2).to(BF)
     gamma = 1 + 0.1 * rnd(C, dev=dev, seed=3)
-    mean, invstd = 0.1 * rnd(C, dev=dev, seed=4), 1 + 0.2 * torch.rand(C, device=dev)
+    mean, invstd = 0.1 * rnd(C, dev=dev, seed=4), (1 + 0.2 * torch.rand(C, generator=torch.Generator().manual_seed(5))).to(dev)
     # partial rows: R row blocks of the true sums
     dch, xch = dz.float().chunk(R, 0), x.float().chunk(R, 0)
     b0 = torch.stack([c.sum(0) for c in dch]).contiguous()
@@ -1212,7 +1212,7 @@ def test_dwconv_tile_backward_with_bn_backward_folded_in(dev, N, T, H, W, C, R):
     mean, invstd = 0.3 + 0.1 * rnd(C, dev=dev, seed=8), 1.0 / (1.5 + 0.1 * rnd(C, dev=dev, seed=9).abs())
     # partial rows whose column sums are the true statistics (split unevenly over R rows)
     s_dz, s_dzx = dz3.float().sum(0), (dz3.float() * c3.float()).sum(0)
-    wts = torch.rand(R, 1, device=dev) + 0.1
+    wts = (torch.rand(R, 1, generator=torch.Generator().manual_seed(6)) + 0.1).to(dev)
     wts = wts / wts.sum()
     st0, st1 = (wts * s_dz).contiguous(), (wts * s_dzx).contiguous()
     # fp32 reference of the composite
