@@ -299,7 +299,16 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
         ws = lambda k, n: workspace(dev, k, n)
         gbias = st.gflat.data_ptr() + 4 * (st.offsets[bname] + r0) if breq else None
         fuse_b = 0
-        if wreq:
+        N8 = _ceil(N, 8)
+        if (wreq and N8 != N and st.wq.enabled and st.defer.enabled and ldg >= N8 and st.wq.eligible(M, N8, K, ldg, K)
+                and lib.query("tuber_gemm_tn_slabs", M, N8, K) == 1):
+            # a head with 3 or 4 outputs (class_embed_b, the last box layer): the transpose-read kernel wants multiples of 8, so the product runs
+            # over the zero-padded columns of gb into arena scratch [N8][K] and the deferred reduction adds its first N rows to the gradient --
+            # queued with its neighbours instead of a tuber_gemm_tn launch of its own (8 - 12 us each on the critical path)
+            scratch = st.defer.alloc(N8 * K)
+            st.wq.add(TnArgs(gb.data_ptr(), ldg, x.data_ptr(), K, None, scratch, 0, M, N8, K, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None, None),
+                      (gb, x), [(scratch, gw, N * K, N8 * K, 1, 0)])
+        elif wreq:
             S = lib.query("tuber_gemm_tn_slabs", M, N, K)
             # bias gradient inside the GEMM: 1 = accumulated directly (single slab), 2 = one partial row per slab
             fuse_b = lib.query("tuber_gemm_tn_fuses_bias", M, N, K, ldg, K) if breq else 0
