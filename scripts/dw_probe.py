@@ -15,6 +15,17 @@ CSRC = os.path.join(ROOT, "tubelet_transformer_amd", "csrc")
 src = open(os.path.join(CSRC, "dwconv_tile.hip")).read()
 k0 = src.index("__global__ __launch_bounds__(512) void dwconv_tile_bwd_both_kernel")
 head, body = src[:k0], src[k0:]
+HALF = "--half-lds" in sys.argv
+if HALF:
+    # TIMING-ONLY upper bound for a bf16-parked ring (results are WRONG): every tap-loop operand read and every parking
+    # store moves HALF the LDS bytes in half the instructions, the FMAs stay -- what a bf16 ring could return at most, before it pays for
+    # unpacking bf16 pairs into the fp32 operands v_pk_fma_f32 needs (2 VALU per position) or for the conversion on the way in
+    a0 = "                for (int i = 0; i < 10; ++i) { const float2 v = *(const float2*)(rp + i * 64); in[i] = f32x2{v.x, v.y}; }\n"
+    assert body.count(a0) == 1
+    body = body.replace(a0, "                for (int i = 0; i < 5; ++i) { const float2 v = *(const float2*)(rp + i * 64); in[2 * i] = f32x2{v.x, v.y}; in[2 * i + 1] = f32x2{v.y, v.x}; }\n")
+    a1 = "            *(float4*)(dst + 4 * (tid + 512 * i)) = o;              // (position * 64 + quad * 4 == 4 * slot index)\n"
+    assert body.count(a1) == 1
+    body = body.replace(a1, "            *(float2*)(dst + 4 * (tid + 512 * i)) = make_float2(o.x + o.z, o.y + o.w);\n")
 STAMPS = [  # (anchor inside the kernel, stamp id, before/after)
     ("    const TileGeom g = a.g;\n", 0, "after"),
     ("    fetch(t0 - 1, regs_a, regx_a);\n", 1, "before"),            # small loads issued

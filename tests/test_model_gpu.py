@@ -267,7 +267,7 @@ def test_train_step_on_the_spread_fixture_reproduces_the_reference_assignment(de
                 assert noise_hip <= 3.0 * noise_ref + 2e-2, "flip at (layer %d, clip %d) needs a cost perturbation of %.3f; the rounded oracle's is %.3f" % (li, b, noise_hip, noise_ref)
     print("%s matcher assignments identical to the reference: %d / %d   [%s]" % (name, same, total, "; ".join(lines)))
     print("%s query spread of the reference: boxes %s%s" % (name, gold["box_spread"][0].round(3), ", p_b in [%.3f, %.3f]" % tuple(gold["p_b_range"]) if ava else ""))
-    assert same >= (3 * total) // 4, (same, total)
+    assert same >= total - 1, (same, total)          # at most ONE flip of 12 (rounds 5-6: 12 / 11 / 11-12 of 12 over every build), and only under the conditions above
     worst_term = 0.0
     for k in sorted(ld):
         if k == "class_error":

@@ -673,3 +673,106 @@ def test_cooperative_decoder_launch_equals_the_launch_chain(dev, dropout):
     print("   gradients: median relative difference %.3e, worst %.3e (%s) over %d tensors; |grad| of layer 0's self-attention in-projection %.3e of the largest tensor's" % (
         med, rels[0][0], rels[0][1], len(rels), float(g0["transformer.decoder.layers.0.self_attn.in_proj_weight"].norm()) / gmax))
     assert med <= 6e-2 and rels[0][0] <= 0.6, (med, rels[:3])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 6: the cooperative decoder launch fails SAFE (VERDICT r05 item 7 / ADVICE r05 medium)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _xcd_blocker():
+    """tests/helpers/xcd_blocker.hip compiled with hipcc at test time (the same toolchain the library is built with) -> ctypes handle"""
+    import ctypes
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tests", "helpers", "xcd_blocker.hip")
+    out = os.path.join(tempfile.gettempdir(), "tuber_xcd_blocker_%d.so" % os.getpid())
+    if not os.path.exists(out):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", out, src],
+                       check=True, cwd=tempfile.gettempdir())
+    lib = ctypes.CDLL(out)
+    lib.xcd_blocker_launch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    lib.xcd_blocker_launch.restype = ctypes.c_int
+    return lib
+
+
+def test_cooperative_decoder_fails_safe_when_starved(dev):
+    """tuber_decoder_coop_fwd needs its 16 workgroups co-resident on ONE XCD and does not ask the runtime for that (a plain launch inside a
+    captured graph).  Here a helper kernel on a second stream holds 28 of the 32 CUs of every XCD (120 KB of LDS each) for 0.5 s, so at most 8 of the 16
+    workgroups become resident (two fit the LDS of a free CU): their barrier times out.  What must happen then:
+      * the launch ends (bounded spins), raises its error word and overwrites its output with NaN -- every output of the model is NaN;
+      * a training step on such a forward is SKIPPED on the device: loss NaN, gradient norm NaN, clip coefficient -1, parameters, both
+        AdamW moments and the step count bit-unchanged (the reference stops before optimizer.step() on a non-finite loss);
+      * ``ParamStore.coop_failed()`` reports it once, clears the words and switches the engine to the launch chain: the next forward is
+        bit-identical to ``TUBER_AB=no_decoder_coop`` and the next training step moves the parameters;
+      * the validation loops' ``_forward_checked`` repeats the batch by itself."""
+    from tubelet_transformer_amd import ab
+    from tubelet_transformer_amd.evaluation import _forward_checked
+    blk = _xcd_blocker()
+    side = torch.cuda.Stream()
+    started = torch.zeros(2, dtype=torch.int32, device=dev)
+    KEYS = ("pred_logits", "pred_boxes", "pred_logits_b")
+
+    def starve(ms=500.0, keep=28):
+        started.zero_()
+        torch.cuda.synchronize()
+        assert blk.xcd_blocker_launch(keep, ms, started.data_ptr(), side.cuda_stream) == 0
+        import time
+        t0 = time.time()
+        while int(started[0].item()) < 8 * keep:               # every blocker workgroup is resident before the model's launches are issued
+            assert time.time() - t0 < 5.0, "the blocker kernel did not start"
+        return
+
+    cfg, model, crit = _model("TubeR_CSN152_AVA21.yaml", dev, dropout=False)
+    store, _ = model.engine()
+    clips = synth.synthetic_clips(2, 32, 64, 96, seed=21, device=dev)
+    targets = synth.synthetic_targets(2, "ava", 80, seed=5, device=dev, hw=(64, 96))
+    model.eval()
+    with torch.no_grad():
+        good = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}
+        with ab.override("no_decoder_coop"):
+            chain = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}
+    assert store.coop_sync.cpu().tolist() == [0, 0, 0, 0] and not store.coop_off
+    assert all(bool(torch.isfinite(v).all()) for v in good.values())
+
+    # ---- a starved TRAINING step: skipped on the device ----
+    model.train()
+    opt = build_optimizer(model, cfg)
+    train_step(model, crit, opt, clips, targets, 0.1)          # one clean step first: non-zero moments, step count 1
+    torch.cuda.synchronize()
+    flat0, m0, v0, t0 = store.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t
+    assert t0 == 1
+    starve()
+    loss, _ = train_step(model, crit, opt, clips, targets, 0.1)
+    torch.cuda.synchronize()
+    words = store.coop_sync.cpu().tolist()
+    print("starved cooperative decoder: sync words %s, loss %s, norm_out %s" % (words, float(loss), opt.norm_out.tolist()))
+    assert words[2] == 1, words
+    assert not bool(torch.isfinite(loss)), float(loss)
+    assert float(opt.norm_out[1]) == -1.0 and not math.isfinite(float(opt.norm_out[0]))
+    assert torch.equal(store.flat, flat0) and torch.equal(opt.exp_avg, m0) and torch.equal(opt.exp_avg_sq, v0) and opt.t == 1
+    # ---- the host notices once, the engine switches to the launch chain, training goes on ----
+    assert store.coop_failed() is True and store.coop_off and store.coop_sync.cpu().tolist() == [0, 0, 0, 0]
+    assert store.coop_failed() is False
+    loss, _ = train_step(model, crit, opt, clips, targets, 0.1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss)) and opt.t == 2 and not torch.equal(store.flat, flat0)
+
+    # ---- a starved EVAL forward: NaN outputs; the validation loops' wrapper repeats the batch on the launch chain ----
+    with torch.no_grad():
+        store.flat.copy_(flat0)
+    model.eval()                                               # (the training steps moved the BatchNorm buffers: fresh chain reference below)
+    store.coop_off = False
+    with torch.no_grad():
+        with ab.override("no_decoder_coop"):
+            chain2 = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}
+        starve()
+        bad = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}
+        torch.cuda.synchronize()
+        assert all(bool(torch.isnan(v).all()) for v in bad.values()), {k: int(torch.isnan(v).sum()) for k, v in bad.items()}
+        assert store.coop_sync.cpu().tolist()[2] == 1
+        store.coop_sync.zero_()
+        starve()
+        out = {k: v.detach().float().clone() for k, v in _forward_checked(model, clips).items() if k in KEYS}
+    assert store.coop_off
+    for k in KEYS:
+        assert torch.equal(out[k], chain2[k]), k
+    torch.cuda.synchronize()

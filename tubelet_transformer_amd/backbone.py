@@ -684,17 +684,22 @@ class CSNRunner:
                     dy = dx
             # layer1 / layer2 weight gradients are long GEMMs: launched per bottleneck (their operands are 45-180 MB each);
             # layer3 / layer4 ones are short: up to 8 (four bottlenecks) share a launch
-            if d["stage"] <= 2 or red is not None or (d["first"] and d["stage"] == 3):
+            # stage boundaries at which the gradient windows above them are made FINAL (queued weight-gradient groups launched, deferred
+            # second-stage sums landed): always where layer3 ends; the graph-mode DDP step (training.GraphedTrainStep) adds the end of
+            # layer4 -- set BEFORE its eager warm-up, so warm-up and capture build the same launch groups and reduce tables
+            at_cut = d["first"] and d["stage"] in getattr(self, "cut_stages", (3,))
+            if d["stage"] <= 2 or red is not None or at_cut:
                 self.flush_wgrads()
             if red is not None:
                 self.store.defer.flush()         # the slice handed to RCCL must include the deferred second-stage reductions
                 red.notify(d["off0"])
             hook = getattr(self, "split_hook", None)
-            if d["first"] and d["stage"] == 3:
-                self.store.defer.flush()         # always here, so eager warm-up and a split capture build the same reduce tables
-            if hook is not None and d["first"] and d["stage"] == 3 and need_dx:
-                # every parameter at flat offsets >= off0 (layer3, layer4, everything behind the body) is final here: the
-                # graph-mode DDP step cuts its hipGraph at this point and all-reduces that slice under layer2 / layer1 / stem
+            if at_cut:
+                self.store.defer.flush()
+            if hook is not None and at_cut and need_dx:
+                # every parameter at flat offsets >= off0 (this stage, the stages above it, everything behind the body) and everything
+                # laid out in front of the body (transformer, heads) is final here: the graph-mode DDP step cuts its hipGraph at this
+                # point and all-reduces those windows under the backward of the stages below
                 hook(d["off0"])
         return dy
 

@@ -105,6 +105,11 @@ __device__ __forceinline__ void coop_barrier(Ctx& c) {
         }
     }
     __syncthreads();
+    // acquire side of the XCD-local path: the exchanged tensors are written once and first read after the barrier that
+    // follows their producer, so this CU's vector L1 should not hold any line of them -- but four workgroups' 32-byte slices share a
+    // 128-byte line and neighbouring buffers share lines at their ends, so the L1 is invalidated instead of relying on that (one
+    // buffer_inv per wave and barrier; the data comes from the shared L2 either way)
+    if (c.same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
     ++c.phase;
 }
 
@@ -403,6 +408,17 @@ __global__ __launch_bounds__(NT, 1) void decoder_coop_fwd_kernel(DecCoopArgs a) 
     // ---- leave the synchronisation words zero for the next launch: a workgroup may still be re-reading the arrival counter of the last
     // barrier when the first ones are through, so departures are counted and the LAST workgroup out resets the words ----
     coop_barrier(c);
+    // ---- fail safe: a barrier that timed out anywhere (a workgroup that was not co-resident: another kernel held its CU) leaves the error
+    // word set, every later barrier falls through and what the stack computed is garbage.  Every workgroup that sees the word at its exit
+    // overwrites the WHOLE output hs with NaN -- a workgroup cannot be past a barrier the others timed out at, and the laggard itself
+    // checks here last -- so the heads, the loss and the gradient norm become NaN and the optimizer's non-finite guard (optim.hip:
+    // clip coefficient -1) skips the update on the device; the host switches this engine to the launch chain when it next reads the
+    // word (engine.ParamStore.coop_failed).
+    if (__hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const uint4 nan4 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+        const long n8 = (long)a.nl * R * (E / 8);
+        for (long i = tid; i < n8; i += NT) ((uint4*)a.hs)[i] = nan4;
+    }
     if (tid == 0) {
         const unsigned left = __hip_atomic_fetch_add(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == G - 1) {                                     // the last workgroup out resets the words (error word stays)
@@ -429,7 +445,7 @@ int tuber_decoder_coop_supported(int d_model, int nhead, int dim_ff, int batch, 
 int tuber_decoder_coop_ptrs_per_layer(void) { return 40; }
 
 // The decoder stack forward (training or eval) as one cooperative launch.  sync: 4 zeroed 32-bit words in device memory (arrival counter,
-// XCC census, error word, departure counter); a clean run leaves them zero, sync[2] != 0 afterwards = a barrier timed out (results invalid).
+// XCC census, error word, departure counter); a clean run leaves them zero, sync[2] != 0 afterwards = a barrier timed out: hs is all NaN then.
 int tuber_decoder_coop_fwd(const void* const* layer_ptrs, const unsigned long long* layer_salts, int num_layers, const void* qpos,
                            const float* norm_weight, const float* norm_bias, void* hs, const void* kpm, int B, int Q, int Lm,
                            float pdrop, float pattn, const void* seed_ptr, void* sync, hipStream_t stream) {

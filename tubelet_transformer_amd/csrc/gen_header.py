@@ -49,7 +49,8 @@ DOC = {
                               "layer (6 bf16 weights: self in-proj, self out-proj, cross q rows, cross out-proj, linear1, linear2; their 6 fp32 biases; norm1 / norm2 / norm3 weight, "
                               "bias; the layer's packed memory projection [(memory + pos) W_k | memory W_v]; then the 21 tensors the launch chain saves for its backward: qkv, o1, lse1, "
                               "a1, y1, xhat1, rstd1, q, o2, lse2, a2, y2, xhat2, rstd2, h, f2, y3, xhat3, rstd3, xhatN, rstdN). layer_salts: HOST array, 6 dropout salts per layer. "
-                              "sync: 4 zeroed 32-bit device words, left zero by a clean run; sync[2] != 0 afterwards = a barrier timed out (results invalid).",
+                              "sync: 4 zeroed 32-bit device words, left zero by a clean run; sync[2] != 0 afterwards = a barrier timed out (a workgroup was not co-resident): the kernel has "
+                              "overwritten hs with NaN, so the step's loss / gradient norm are NaN and tuber_adamw_segment skips the update.",
     "tuber_decoder_coop_supported": "1 when tuber_decoder_coop_fwd takes this decoder (d_model 256, 8 heads, FFN 2048, batch * 8 == 16 attention units, batch * queries <= 32, <= 6 layers).",
     "tuber_decoder_coop_ptrs_per_layer": "device pointers per layer in tuber_decoder_coop_fwd's layer_ptrs (40).",
     "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "
@@ -220,7 +221,9 @@ DOC = {
     "tuber_lsap_device": "the same assignment (scipy.optimize.linear_sum_assignment semantics incl. tie-breaking; matcher.py:80, matcher_ucf.py:82) for all "
                          "(decoder layer, clip) problems at once ON THE DEVICE, one thread per problem: match[l][b][t] = query of target t.",
     "tuber_grad_norm_clip_coef": "global L2 norm of the flat gradient buffer and the clip coefficient min(1, max_norm/(norm+1e-6)), left on the device: "
-                                 "torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1) (utils/video_action_recognition.py:153).",
+                                 "torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1) (utils/video_action_recognition.py:153).  A non-finite norm "
+                                 "yields coefficient -1 = skip the update and leaves the step count alone: the reference stops BEFORE optimizer.step() on a "
+                                 "non-finite loss (video_action_recognition.py:195-198).",
     "tuber_adamw_segment": "AdamW update (torch.optim.AdamW semantics: decoupled decay, bias correction) of one contiguous flat segment with the "
                            "clip coefficient applied to the gradient on the fly (video_action_recognition.py:154; groups train_tuber_ava.py:41-58).",
     "tuber_scale_f32": "x *= coef: gradient averaging after the RCCL all-reduce (DistributedDataParallel's mean, utils/model_utils.py:47-49).",

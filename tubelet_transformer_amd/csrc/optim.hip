@@ -21,8 +21,12 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// norm_out[0] = sqrt(sum partial), norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0)
-__global__ void clip_coef_kernel(const float* __restrict__ partial, int np, float max_norm, float* __restrict__ norm_out) {
+// norm_out[0] = sqrt(sum partial), norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0).
+// A NON-FINITE norm (a NaN / Inf anywhere in the gradient buffer: a non-finite loss, a poisoned cooperative-decoder launch, a peer rank's
+// NaN arriving through the all-reduce) makes the coefficient -1 = "skip": adamw_kernel leaves parameters and moments untouched and the
+// step count *step_ptr does not advance, so no invalid update is ever applied -- the reference stops BEFORE optimizer.step() on a
+// non-finite loss (utils/video_action_recognition.py:195-198); here the host learns about it when it next reads the loss.
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int np, float max_norm, float* __restrict__ norm_out, int* __restrict__ step_ptr) {
     __shared__ double red[256];
     double a = 0.0;
     for (int i = threadIdx.x; i < np; i += 256) a += (double)partial[i];
@@ -37,7 +41,9 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int np, floa
         norm_out[0] = norm;
         float c = 1.f;
         if (max_norm > 0.f) { c = max_norm / (norm + 1e-6f); if (c > 1.f) c = 1.f; }
-        norm_out[1] = c;
+        const bool ok = norm == norm && norm <= 3.0e38f;
+        norm_out[1] = ok ? c : -1.f;
+        if (step_ptr && ok) *step_ptr += 1;
     }
 }
 
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     int write_clipped_grad, const float* __restrict__ hyper) {
     if (hyper) { lr = hyper[0]; wd = hyper[1]; }     // per-group lr / weight decay in DEVICE memory: schedulers act on replayed hipGraphs
     const float c = clip ? clip[1] : 1.f;
+    if (c < 0.f) return;                             // non-finite gradient norm: the step is skipped (clip_coef_kernel)
     const float tstep = (float)(*step_ptr);
     const float bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
     const float step_size = lr / bc1;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 }
 
 __global__ void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef_dev, float coef) {
-    const float c = coef_dev ? coef_dev[1] * coef : coef;
+    const float c = coef_dev ? fmaxf(coef_dev[1], 0.f) * coef : coef;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= c;
 }
 
@@ -90,16 +97,17 @@ extern "C" {
 
 #define NORM_BLOCKS 1024
 
-// total L2 norm of g[0..n) and the clip coefficient, both left ON THE DEVICE in norm_out[0..1] (no host sync).
-// partial must hold 1024 floats.
-int tuber_grad_norm_clip_coef(const float* g, long n, float max_norm, float* partial, float* norm_out, hipStream_t stream) {
+// total L2 norm of g[0..n) and the clip coefficient, both left ON THE DEVICE in norm_out[0..1] (no host sync); norm_out[1] = -1 when the
+// norm is not finite (tuber_adamw_segment then skips its update).  step_ptr (optional, device int): the AdamW step count, advanced by one
+// iff the norm is finite.  partial must hold 1024 floats.
+int tuber_grad_norm_clip_coef(const float* g, long n, float max_norm, float* partial, float* norm_out, int* step_ptr, hipStream_t stream) {
     if (n <= 0) return TUBER_EINVAL;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, g, n, partial);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partial, NORM_BLOCKS, max_norm, norm_out);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partial, NORM_BLOCKS, max_norm, norm_out, step_ptr);
     TUBER_RETURN_LAUNCH();
 }
 
-// one AdamW step on a contiguous segment; `clip` = norm_out of tuber_grad_norm_clip_coef (or NULL);
+// one AdamW step on a contiguous segment; `clip` = norm_out of tuber_grad_norm_clip_coef (or NULL); clip[1] < 0 = skip (non-finite norm);
 // the step count t (for the bias corrections 1 - beta^t) is read from DEVICE memory so a captured hipGraph
 // replays with the right value every step; so are lr / weight_decay when `hyper` (device float[2] = {lr, weight_decay}) is given
 // (lr_scheduler.step() between replays), else the by-value arguments are used.

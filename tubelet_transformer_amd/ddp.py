@@ -106,6 +106,42 @@ class RcclComm:
             self.comm = None
 
 
+class StreamEdge:
+    """One-directional ordering edge between two HIP streams of this device: what was enqueued on ``src`` so far happens before what is
+    enqueued on ``dst`` afterwards (hipEventRecord + hipStreamWaitEvent on a reusable event).
+
+    torch's ``dst.wait_stream(src)`` records a DEFAULT event, and a default HIP event performs a SYSTEM-scope release when it completes
+    (cache write-back + invalidate: /opt/rocm/include/hip/hip_runtime_api.h, hipEventDisableSystemFence).  Round 6 measured what that costs
+    the captured step (scripts/r06_ddp_probe.sh): the pair of edges around the gradient exchange -- with NO collective enqueued between
+    them -- slows the step by 0.7 - 0.8 ms, the same as with the one-rank ncclAllReduce (which is a no-op on the device: 5 us of stream
+    time).  ``mode``: 'torch' = wait_stream; 'device' = own event with hipEventReleaseToDevice (an agent-scope release is all another
+    stream of the SAME device needs); 'nofence' = hipEventDisableSystemFence."""
+    _hip = None
+    FLAGS = {"device": 0x2 | 0x40000000, "nofence": 0x2 | 0x20000000, "plain": 0x2}
+
+    def __init__(self, mode):
+        self.mode = mode
+        self.ev = None
+        if mode != "torch":
+            if StreamEdge._hip is None:
+                StreamEdge._hip = ctypes.CDLL("libamdhip64.so")
+            ev = ctypes.c_void_p()
+            rc = StreamEdge._hip.hipEventCreateWithFlags(ctypes.byref(ev), ctypes.c_uint(self.FLAGS[mode]))
+            if rc != 0:
+                raise RuntimeError("hipEventCreateWithFlags(%s) failed: %d" % (mode, rc))
+            self.ev = ev
+
+    def __call__(self, src, dst):
+        if self.ev is None:
+            dst.wait_stream(src)
+            return
+        h = StreamEdge._hip
+        rc = h.hipEventRecord(self.ev, ctypes.c_void_p(src.cuda_stream))
+        rc = rc or h.hipStreamWaitEvent(ctypes.c_void_p(dst.cuda_stream), self.ev, ctypes.c_uint(0))
+        if rc != 0:
+            raise RuntimeError("stream edge failed: %d" % rc)
+
+
 class RcclBootstrapTimeout(RuntimeError):
     """ncclCommInitRank did not complete before TUBER_RCCL_INIT_TIMEOUT_S: a rank is missing.  Not recoverable in-process."""
 
@@ -125,6 +161,7 @@ class FlatGradReducer:
         self.windows = 0                      # all-reduce calls since begin()
         self.measure = False                  # bench.py: time how long the optimizer's stream stalls on the transport (HIP events)
         self.exposed = []                     # [(event before the wait, event after it)] of the measured steps
+        self.win_events = []                  # measured steps: per step [(t0 on the backward stream at begin(), [(issue, start, end, bytes)])]
         self.done_from = store.total          # everything at offsets >= done_from has been handed to the transport
         self.late = []                        # [(begin, end)] windows that must wait for the end of backward
         for n in store.names:
@@ -133,6 +170,10 @@ class FlatGradReducer:
                 self.late.append((o, o + (store.module.get_parameter(n).numel() + 63) // 64 * 64))
         self.late.sort()
         self.ranges = trainable_ranges(store)
+        mode = os.environ.get("TUBER_DDP_EDGE", "torch")
+        self.edge_out = [StreamEdge(mode) for _ in range(8)]     # backward stream -> transport stream, one reusable event per issue point of a step
+        self.edge_back = StreamEdge(mode)                         # transport stream -> optimizer's stream
+        self.edge_k = 0
 
     # -- step protocol -----------------------------------------------------------------------------------------------------
     def begin(self):
@@ -140,8 +181,13 @@ class FlatGradReducer:
         self.issued = 0
         self.windows = 0
         self.done_from = self.store.total
+        self.edge_k = 0
         self.ranges = trainable_ranges(self.store)       # windows of frozen parameters hold no gradient: never sent
         self._joined = True
+        if self.measure and self.comm is not None and not torch.cuda.is_current_stream_capturing():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            self.win_events.append((e, []))
 
     def reduce(self, lo, hi):
         """all-reduce (and average) the trainable part of gflat[lo:hi); returns immediately."""
@@ -160,11 +206,22 @@ class FlatGradReducer:
             return
         from . import lib
         cs = self.comm.stream
-        cs.wait_stream(torch.cuda.current_stream())            # the windows are final on the backward stream up to here
+        timed = self.measure and bool(self.win_events) and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            issue = torch.cuda.Event(enable_timing=True)
+            issue.record(torch.cuda.current_stream())           # when the backward stream reaches this issue point
+        self.edge_out[self.edge_k % len(self.edge_out)](torch.cuda.current_stream(), cs)      # the windows are final on the backward stream up to here
+        self.edge_k += 1
         self._joined = False
         inv = 1.0 / self.world
         base = st.gflat.data_ptr()
+        skip_call = bool(os.environ.get("TUBER_DDP_SKIP_CALL"))      # diagnostic: everything but the ncclAllReduce call itself (stream edges only)
+        import time as _time
+        h0 = _time.perf_counter()
         with torch.cuda.stream(cs):
+            if timed:
+                w0 = torch.cuda.Event(enable_timing=True)
+                w0.record(cs)
             for a, b in wins:
                 n = b - a
                 if self.compress:
@@ -175,11 +232,16 @@ class FlatGradReducer:
                     self.comm.all_reduce(sp, n, bf16=True)
                     lib.call("tuber_cast_bf16_f32_scale", sp, base + 4 * a, n, inv)
                 else:
-                    self.comm.all_reduce(base + 4 * a, n)
+                    if not skip_call:
+                        self.comm.all_reduce(base + 4 * a, n)
                     if self.world > 1:
                         lib.call("tuber_scale_f32", base + 4 * a, n, None, inv)
                 self.issued += n
                 self.windows += 1
+            if timed:
+                w1 = torch.cuda.Event(enable_timing=True)
+                w1.record(cs)
+                self.win_events[-1][1].append((issue, w0, w1, sum(b - a for a, b in wins) * (2 if self.compress else 4), _time.perf_counter() - h0))
 
     def _reduce_excluding_late(self, lo, hi):
         cur = lo
@@ -213,7 +275,7 @@ class FlatGradReducer:
                 if timed:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(cur)
-                cur.wait_stream(self.comm.stream)
+                self.edge_back(self.comm.stream, cur)
                 if timed:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(cur)
@@ -243,11 +305,24 @@ class FlatGradReducer:
             ms = [a.elapsed_time(b) for a, b in self.exposed]
             exposed = sum(ms) / len(ms)
         bpe = 2 if self.compress else 4
+        per_issue = None
+        if self.win_events:
+            # per issue point (mean over the measured steps): when the backward stream reached it (ms after begin()), how long the
+            # transport's stream was busy with it, and how late after the issue it finished
+            torch.cuda.synchronize()
+            k = min(len(w) for _, w in self.win_events)
+            per_issue = []
+            for i in range(k):
+                rows = [(t0.elapsed_time(w[i][0]), w[i][1].elapsed_time(w[i][2]), w[i][0].elapsed_time(w[i][2]), w[i][3], 1e3 * w[i][4]) for t0, w in self.win_events]
+                m = [sum(r[j] for r in rows) / len(rows) for j in (0, 1, 2, 4)]
+                per_issue.append({"MB": round(rows[0][3] / 1e6, 1), "issued_at_ms": round(m[0], 3), "stream_busy_ms": round(m[1], 3), "done_after_issue_ms": round(m[2], 3),
+                                  "host_call_ms": round(m[3], 3)})
+            self.win_events = []
         return {"transport": "own RCCL communicator (csrc/collective.cpp)" if self.comm is not None else "torch.distributed process group (%s)" % (dist.get_backend() if dist.is_initialized() else "none"),
                 "world": self.world, "ranks_seen_by_rccl": getattr(self.comm, "ranks_seen", None) if self.comm is not None else None,
                 "rccl_version": getattr(self.comm, "version", None) if self.comm is not None else None,
                 "bf16_compressed": bool(self.compress), "windows_per_step": self.windows, "bytes_per_step": self.issued * bpe,
-                "exposed_ms": exposed}
+                "exposed_ms": exposed, "issue_points": per_issue}
 
 
 def broadcast_parameters(store, src=0):

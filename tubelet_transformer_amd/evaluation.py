@@ -180,6 +180,18 @@ def read_labelmap(path):
 # ---------------------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------------------
+def _forward_checked(model, samples):
+    """model(samples) of a validation iteration.  The cooperative decoder launch (csrc/decoder_coop.hip) fails safe -- a timed-out
+    barrier leaves NaN outputs and an error word -- and the loop copies the outputs to the host right after this anyway, so the word is
+    read here (16 bytes) every iteration: on a failure the engine switches to the launch chain and the batch is run again (ADVICE r05:
+    the evaluation path never looked at the word)."""
+    outputs = model(samples)
+    store = model.engine()[0]
+    if not store.coop_off and store.coop_failed():
+        outputs = model(samples)
+    return outputs
+
+
 @torch.no_grad()
 def validate_tuber_detection(cfg, model, criterion, postprocessors, data_loader, epoch, writer=None, excluded_timestamps=None,
                              verbose=True):
@@ -206,7 +218,7 @@ def validate_tuber_detection(cfg, model, criterion, postprocessors, data_loader,
         samples = samples.to(dev)            # reference :280 / :513; runs the HIP clip pre-pass when the loader yields ClipBatch
         batch_id = [t["image_id"] for t in targets]
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
-        outputs = model(samples)
+        outputs = _forward_checked(model, samples)
         loss_dict = criterion(outputs, targets)
         sizes = torch.stack([t["size"] for t in targets], dim=0)
         scores, boxes, output_b = postprocessors["bbox"](outputs, sizes)
@@ -341,7 +353,7 @@ def validate_tuber_ucf_detection(cfg, model, criterion, postprocessors, data_loa
         samples = samples.to(dev)
         batch_id = [t["image_id"] for t in targets]
         targets = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items() if k != "image_id"} for t in targets]
-        outputs = model(samples)
+        outputs = _forward_checked(model, samples)
         loss_dict = criterion(outputs, targets)
         sizes = torch.stack([t["size"] for t in targets], dim=0)
         scores, boxes, output_b = postprocessors["bbox"](outputs, sizes)

@@ -110,24 +110,26 @@ class FusedClipAdamW(torch.optim.Optimizer):
             stock._opt_called = True
 
     @torch.no_grad()
-    def grad_norm(self, max_norm=0.0):
-        """device-side total gradient norm (float tensor [2] = norm, clip coefficient); no host sync."""
-        lib.call("tuber_grad_norm_clip_coef", self.store.gflat, self.store.total, float(max_norm), self.partial, self.norm_out)
+    def grad_norm(self, max_norm=0.0, advance=False):
+        """device-side total gradient norm (float tensor [2] = norm, clip coefficient; coefficient -1 = non-finite norm, the AdamW launches
+        skip their update); no host sync.  ``advance``: the device step counter moves on by one iff the norm is finite."""
+        lib.call("tuber_grad_norm_clip_coef", self.store.gflat, self.store.total, float(max_norm), self.partial, self.norm_out,
+                 self.t_dev if advance else None)
         return self.norm_out
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=None):
-        """AdamW step; with ``max_norm`` the global-norm clipping is fused in (else call clip_grad_norm_ yourself).
+        """AdamW step; with ``max_norm`` the global-norm clipping is fused in (else call clip_grad_norm_ yourself).  A step whose
+        gradient buffer holds a NaN / Inf is SKIPPED on the device (parameters, moments and the step count stay as they were).
         The norm runs over the whole flat gradient buffer: windows of frozen parameters are never written and stay zero, so it equals
         ``clip_grad_norm_`` over the parameters that have a gradient (video_action_recognition.py:153)."""
         st = self.store
         self.mark_stepped()
-        clip = None
-        if max_norm is not None and max_norm > 0:
-            clip = self.grad_norm(max_norm)
+        # the norm pass runs with or without clipping: it is also the guard that keeps a non-finite gradient (NaN loss, a poisoned
+        # cooperative-decoder launch, a peer's NaN through the all-reduce) from ever being applied -- coefficient -1, step count unchanged
+        clip = self.grad_norm(max_norm if max_norm is not None and max_norm > 0 else 0.0, advance=True)
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
-        self.t_dev.add_(1)
         for o, end, gi in self.segments:
             g = self.param_groups[gi]
             b1, b2 = g["betas"]

@@ -116,9 +116,11 @@ class GraphedTrainStep:
     AdamW step count.  A new clip shape or a changed set of frozen parameters captures a new graph (the eager warm-up passes of
     a capture are rolled back, so they are not optimisation steps); at most ``max_graphs`` graphs are kept (LRU).
 
-    With > 1 rank (ddp.py) the step is graph A (refresh .. layer3's backward) -> RCCL all-reduce of the ~97 % of the gradient
-    buffer that is final at that point, on the reducer's own stream -> graph A2 (layer2 / layer1 / stem backward, running UNDER
-    the all-reduce) -> all-reduce of the remainder -> graph B2 (clip + AdamW) which waits for the side stream by event.  With
+    With > 1 rank (ddp.py) the step is graph A (refresh .. layer4's backward) -> RCCL all-reduce, on the reducer's own stream, of the
+    ~58 % of the gradient buffer that is final at that point (transformer, heads, class branch, layer4, pool decoder) -> graph A1
+    (layer3's backward, a latency-bound chain that leaves HBM and most CUs to the collective) -> all-reduce of layer3's 38 % ->
+    graph A2 (layer2 / layer1 / stem backward) -> all-reduce of the remainder -> graph B2 (clip + AdamW), which waits for the side
+    stream by event.  ``TUBER_DDP_CUTS=3`` restores the single cut of rounds 2-5 (97 % under layer2 / layer1 / stem); with
     ``TUBER_RCCL_IN_GRAPH=1`` the collectives are captured into ONE graph as a forked branch instead.
     """
 
@@ -186,6 +188,12 @@ class GraphedTrainStep:
         # the loss-weight / hyper-parameter device tables.  Rolled back afterwards -- a capture is not an optimisation step.
         snap = _Snapshot(model, store, opt)
         store.reducer = red if in_graph else None
+        split = ddp and not in_graph and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
+        split = split or bool(os.environ.get("TUBER_FORCE_SPLIT_GRAPH"))
+        _, runner = model.engine()
+        # where the backward makes its gradient windows final (backbone.CSNRunner._backward_blocks): fixed BEFORE the warm-up passes so
+        # that they and the capture issue the same weight-gradient groups and deferred-reduce tables
+        runner.cut_stages = tuple(int(x) for x in os.environ.get("TUBER_DDP_CUTS", "4,3").split(",") if x) if split else (3,)
         if in_graph:
             red.dry = True                           # hooks fire (same deferred-reduce flush points as the capture), nothing is sent
         try:
@@ -206,9 +214,8 @@ class GraphedTrainStep:
                 red.dry = False
         opt.sync_hyper()
         crit.sync_weights(dev)
-        g.A, g.A2, g.B1, g.B2, g.split = torch.cuda.CUDAGraph(), None, None, None, None
-        split = ddp and not in_graph and g.on_device and not os.environ.get("TUBER_NO_SPLIT_GRAPH")
-        split = split or bool(os.environ.get("TUBER_FORCE_SPLIT_GRAPH"))
+        g.A, g.A2, g.B1, g.B2, g.split, g.parts, g.cuts = torch.cuda.CUDAGraph(), None, None, None, None, [], []
+        split = split and g.on_device
         own_step = not ddp or in_graph               # clip + AdamW inside the main graph (else graph B2, behind the all-reduce)
         if in_graph:
             # ONE graph: the reducer's hooks fork its side stream off the capture stream inside the backward pass, so the RCCL
@@ -221,22 +228,26 @@ class GraphedTrainStep:
                 red.finish()
                 opt.step(max_norm=max_norm)
         elif split and g.on_device:
-            # DDP: graph A is cut where layer3's backward ends (~97 % of the gradient bytes are final there), so the RCCL
-            # all-reduce of that slice runs under the layer2 / layer1 / stem backward (graph A2) instead of after it.
-            _, runner = model.engine()
-            cut = {}
-            a2 = torch.cuda.CUDAGraph()
+            # DDP: the graph is CUT inside the backward pass where a gradient window becomes final, so that window's RCCL all-reduce runs
+            # on the reducer's stream under the backward of the stages below it.  Default cuts (TUBER_DDP_CUTS=4,3): (1) where layer4's
+            # backward ends -- transformer + heads + class branch + layer4 + pool decoder, ~58 % of the bytes, go under layer3's
+            # latency-bound chain, which leaves HBM and most CUs idle; (2) where layer3's backward ends -- layer3's 19 M parameters go
+            # under layer2 / layer1 / stem; the ~1.5 M tail after the last graph.  (Until round 5 the only cut was (2): the whole 97 % ran
+            # beside the bandwidth-bound layer2 / layer1 backward and cost a rank 0.77 ms of contention with nothing on the wire.)
+            cut = []
+            graphs = [g.A]
             torch.cuda.synchronize()
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                g.A.capture_begin(capture_error_mode="relaxed")      # the cut happens on autograd's worker thread
+                g.A.capture_begin(capture_error_mode="relaxed")      # the cuts happen on autograd's worker thread
 
                 def hook(off):
-                    if "off" not in cut:
-                        g.A.capture_end()
-                        cut["off"] = off
-                        a2.capture_begin(pool=g.A.pool(), capture_error_mode="relaxed")
+                    graphs[-1].capture_end()
+                    cut.append(int(off))
+                    nxt = torch.cuda.CUDAGraph()
+                    nxt.capture_begin(pool=g.A.pool(), capture_error_mode="relaxed")
+                    graphs.append(nxt)
                 runner.split_hook = hook
                 try:
                     head()
@@ -244,11 +255,10 @@ class GraphedTrainStep:
                     tail(own_step)
                 finally:
                     runner.split_hook = None
-                if "off" in cut:
-                    a2.capture_end()
-                    g.A2, g.split, g.body_begin = a2, int(cut["off"]), int(runner.body_begin)
-                else:
-                    g.A.capture_end()
+                graphs[-1].capture_end()
+                g.parts, g.cuts, g.body_begin = graphs[1:], cut, int(runner.body_begin)
+                g.A2 = graphs[-1] if cut else None
+                g.split = cut[-1] if cut else None
             torch.cuda.current_stream().wait_stream(cs)
         elif g.on_device:
             with torch.cuda.graph(g.A):
@@ -279,7 +289,7 @@ class GraphedTrainStep:
         place and passes them back to ``__call__`` saves the step its 67 MB device-to-device copy."""
         store, _ = self.model.engine()
         for k, g in self.graphs.items():
-            if k[:3] == (tuple(clips_shape), store.trainable_signature(), self.criterion.training):
+            if k[:3] == (tuple(clips_shape), store.trainable_signature(), self.criterion.training) and k[4] == store.coop_off:
                 return g.clips, g.mask
         return None
 
@@ -298,10 +308,11 @@ class GraphedTrainStep:
         need = max([int(t["boxes"].shape[0]) for t in targets] + [1])
         tmax = max(self.tmax, (need + 15) // 16 * 16)
         for k in self.graphs:                                     # a captured wider layout serves narrower batches too
-            if k[:3] == (tuple(clips.shape), store.trainable_signature(), self.criterion.training) and k[3] >= tmax:
+            if k[:3] == (tuple(clips.shape), store.trainable_signature(), self.criterion.training) and k[3] >= tmax and k[4] == store.coop_off:
                 tmax = k[3]
                 break
-        key = (tuple(clips.shape), store.trainable_signature(), self.criterion.training, tmax)
+        # (a captured step bakes the decoder's launch form in: after a timed-out cooperative launch -- engine.coop_failed -- a new one is captured)
+        key = (tuple(clips.shape), store.trainable_signature(), self.criterion.training, tmax, store.coop_off)
         g = self.graphs.get(key)
         if g is None:
             while len(self.graphs) >= self.max_graphs:            # LRU: a graph holds its own memory pool
@@ -324,6 +335,9 @@ class GraphedTrainStep:
         self.optimizer.mark_stepped()
         self.criterion.sync_weights(store.device)
         sizes = g.pt.sizes
+        red = g.red
+        if red is not None and not g.in_graph:
+            red.begin()
         g.A.replay()
         if g.on_device:
             self.criterion._indices, self.criterion._match_dev = None, (g.match, sizes)
@@ -336,18 +350,20 @@ class GraphedTrainStep:
             L = len(indices)
             self.criterion.last_indices = [indices[L - 1]] + indices[:L - 1]
             g.B1.replay()
-        red = g.red
-        if red is not None and not g.in_graph:
-            red.begin()
-        if g.A2 is not None:
-            # final at the cut: layer3, layer4 and everything laid out behind the body [split, total) and everything laid out
-            # before it (transformer, heads: [0, body_begin)); pending: stem, layer1, layer2 [body_begin, split)
+        if g.parts:
+            # final at cut i: the stage that just ended, the stages above it, everything laid out behind the body [cuts[i], previous cut)
+            # and -- at the first cut -- everything laid out before the body (transformer, heads: [0, body_begin)); pending after the
+            # last cut: [body_begin, cuts[-1]) (stem, layer1, layer2)
+            hi = store.total
+            for i, part in enumerate(g.parts):
+                if red is not None:
+                    red.reduce(g.cuts[i], hi)
+                    if i == 0:
+                        red.reduce(0, g.body_begin)
+                hi = g.cuts[i]
+                part.replay()                                 # the backward of the stages below, under the all-reduce
             if red is not None:
-                red.reduce(g.split, store.total)
-                red.reduce(0, g.body_begin)
-            g.A2.replay()                                     # layer2 / layer1 / stem backward, under the all-reduce
-            if red is not None:
-                red.reduce(g.body_begin, g.split)
+                red.reduce(g.body_begin, hi)
         elif red is not None and not g.in_graph:
             red.reduce(0, store.total)
         if red is not None and not g.in_graph:
@@ -420,7 +436,8 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
     meters = _DeviceMeters(dev)
     end = time.time()
     loss = None
-    nonfinite = None
+    store = model.engine()[0]
+    tracker = _StepTracker(dev)
     import torch.distributed as _dist
     world = _dist.get_world_size() if _dist.is_available() and _dist.is_initialized() else 1
     n_iter = len(data_loader)
@@ -445,21 +462,19 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
             lr_scheduler.step_update(epoch * n_iter + idx)
         if rank == 0:
             meters.update(loss, loss_dict, len(targets))
-        # non-finite loss (reference :195-198 checks the rank-reduced loss on every rank, every iteration): a device-side flag updated
-        # on EVERY rank every step, MAX-reduced over the ranks and read on every rank, so that all ranks stop together instead of
-        # rank 0 raising while the others wait in the next gradient all-reduce.  The collective is issued at
-        # iterations every rank reaches by construction (idx % print_freq == 0 -- the same idx on every rank as long as the
-        # loaders have one length, which the gradient all-reduce needs anyway) and once more after the loop; NOT at
-        # ``idx + 1 == n_iter``, which would pair with nothing on a rank whose loader is longer.  Up to print_freq
-        # optimizer steps with a non-finite loss may have been applied when this fires (the reference stops before the first):
-        # resume from the last checkpoint, not from the live weights.
-        bad = ~torch.isfinite(loss.detach()).reshape(1)
-        if nonfinite is None:
-            nonfinite = torch.zeros(2, dtype=torch.float32, device=bad.device)       # [flag, first offending iteration + 1]
-        nonfinite = torch.where((nonfinite[:1] == 0) & bad, torch.tensor([1.0, idx + 1.0], device=bad.device), nonfinite)
+        # non-finite loss (reference :195-198 checks the rank-reduced loss on every rank, every iteration, BEFORE optimizer.step()): here the
+        # optimizer's device-side guard skips the update of any step whose gradient norm is not finite (csrc/optim.hip), so nothing invalid is
+        # ever applied, and the host learns about it from a device-side tracker updated on EVERY rank every step (no host-to-device copy, no
+        # sync), MAX-reduced over the ranks and read on every rank, so that all ranks stop together instead of rank 0 raising while the
+        # others wait in the next gradient all-reduce.  The collective is issued at iterations every rank reaches by
+        # construction (idx % print_freq == 0 -- the same idx on every rank as long as the loaders have one length, which the gradient
+        # all-reduce needs anyway) and once more after the loop; NOT at ``idx + 1 == n_iter``, which would pair with nothing on a rank whose
+        # loader is longer.  The same tracker carries the cooperative decoder launch's error word: a timed-out
+        # launch poisons its step with NaN (skipped like any other non-finite step); when ANY rank reports one, EVERY rank switches to
+        # the launch chain at this same iteration and training continues.
+        tracker.update(loss, store.coop_sync)
         if idx % print_freq == 0:
-            _raise_if_nonfinite(nonfinite, loss_dict, epoch, idx, rank, world, _dist)
-            model.engine()[0].check_coop()
+            _check_tracker(tracker, store, loss_dict, epoch, idx, rank, world, _dist)      # (a captured step is keyed on store.coop_off: re-captured by itself)
         if rank == 0 and (idx % print_freq == 0 or idx + 1 == n_iter):
             avg = meters.averages()
             lr = optimizer.param_groups[-1]["lr"]
@@ -477,20 +492,50 @@ def train_tuber_detection(cfg, model, criterion, data_loader, optimizer, epoch, 
                 writer.add_scalar("train/loss_ce", avg["loss_ce"], it)
                 writer.add_scalar("train/loss_ce_b", avg["loss_ce_b"], it)
         end = time.time()
-    if nonfinite is not None:
-        _raise_if_nonfinite(nonfinite, loss_dict, epoch, n_iter - 1, rank, world, _dist)
-        model.engine()[0].check_coop()
+    if loss is not None:
+        _check_tracker(tracker, store, loss_dict, epoch, n_iter - 1, rank, world, _dist)
     return loss
 
 
-def _raise_if_nonfinite(state, loss_dict, epoch, idx, rank, world, _dist):
-    """MAX-reduce the [flag, iteration + 1] pair over the ranks and stop every rank together (the only host sync of the loop)."""
+class _StepTracker:
+    """Device-side record of what went wrong since the last check: [a non-finite loss was seen, -(first such iteration + 1), the cooperative
+    decoder launch's error word].  The iteration is stored NEGATED (initially -inf) so that the MAX all-reduce over the ranks yields the
+    FIRST offending iteration of any rank; the counter lives on the device (no per-step host-to-device copy)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.reset()
+
+    def reset(self):
+        self.state = torch.tensor([0.0, float("-inf"), 0.0], dtype=torch.float32, device=self.device)
+        self.it = torch.zeros((), dtype=torch.float32, device=self.device)
+
+    def update(self, loss, coop_sync):
+        bad = (~torch.isfinite(loss.detach())).reshape(()).to(torch.float32)
+        self.it = self.it + 1.0
+        first = torch.where((self.state[0] == 0) & (bad > 0), -self.it, self.state[1])
+        self.state = torch.stack([torch.maximum(self.state[0], bad), first, torch.maximum(self.state[2], coop_sync[2].to(torch.float32))])
+
+
+def _check_tracker(tracker, store, loss_dict, epoch, idx, rank, world, _dist):
+    """MAX-reduce the tracker over the ranks (the only host sync of the loop).  A timed-out cooperative decoder launch on any rank: every
+    rank clears its words, switches to the launch chain and goes on (returns True; the poisoned steps were skipped by the optimizer on
+    every rank -- the NaN gradients reached the others through the all-reduce).  Otherwise a non-finite loss stops every rank together."""
+    state = tracker.state
     if world > 1:
         _dist.all_reduce(state, op=_dist.ReduceOp.MAX)
-    flag, first = state.tolist()
+    flag, negfirst, coop = state.tolist()
+    if coop:
+        if not store.coop_failed():          # another rank's launch failed: same switch here, so that all ranks run the same launch sequence
+            store.coop_sync.zero_()
+            store.coop_off = True
+        tracker.reset()
+        return True
     if flag:
         losses = {k: float(v.detach()) if torch.is_tensor(v) else v for k, v in loss_dict.items()}
         print("Loss is non-finite on some rank, stopping training")
         print(losses)
         raise FloatingPointError("non-finite loss first seen at epoch %d, iteration %d (checked at iteration %d, rank %d of %d; this rank's "
-                                 "last loss terms: %s); the weights may already hold non-finite updates" % (epoch, int(first) - 1, idx, rank, world, losses))
+                                 "last loss terms: %s); steps with a non-finite gradient norm were skipped by the optimizer, the weights hold "
+                                 "the last finite update" % (epoch, int(-negfirst) - 1, idx, rank, world, losses))
+    return False
