@@ -540,11 +540,16 @@ def main():
         # the gradient exchange as it ran in the timed region + a few measured steps (HIP events around the optimizer stream's wait
         # for the transport = EXPOSED communication time), for the first multi-GPU run to be diagnosable from its one JSON line
         red.measure = True
+        if mode == "hipgraph":
+            graphed.part_marks = []
         for _ in range(min(args.steps, 5)):
             step()
         fence()
         comm_info = red.describe()
         red.measure = False
+        if mode == "hipgraph":
+            comm_info["graph_part_ms"] = graphed.part_ms()      # [graph A, A1, ..., (B2)]: HIP events between the replays
+        red.check()
         parts = 0
         if mode == "hipgraph":
             parts = max((len(g.parts) for g in graphed.graphs.values()), default=0)

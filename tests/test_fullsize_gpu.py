@@ -69,11 +69,16 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
     want, _ = run_oracle(cfg, state, clips, train=False)
     rnd, _ = run_oracle(cfg, state, clips, train=False, rounded=True)
     t1 = time.time()
+    from tubelet_transformer_amd import ab
     with torch.no_grad():
-        got = model(clips.to(dev))
+        got = model(clips.to(dev))                      # default: the eval precision mode (fp32 residual streams, round 6)
+        with ab.override("eval_bf16_stream"):
+            got_bf = model(clips.to(dev))               # the training path's rounding points (bf16-stored block / LayerNorm outputs)
     errs = output_errors(got, want, rnd)
+    errs_bf = output_errors(got_bf, want, rnd)
     print("%s (%s, %dx3x32x%dx%d) eval: max abs err vs fp32 oracle  hip / bf16-rounded oracle: %s   [oracle %.1f s]" % (
         case, yaml_name, B, hw[0], hw[1], {k: "%.2e / %.2e" % v for k, v in errs.items()}, t1 - t0))
+    print("   the same with bf16-stored residual streams (TUBER_AB=eval_bf16_stream, the training path's rounding points): %s" % {k: "%.2e" % v[0] for k, v in errs_bf.items()})
     scale = {}
     for k, v in flat_outputs(want).items():
         scale[k.split(".")[-1]] = max(scale.get(k.split(".")[-1], 0.0), float(np.abs(v).max()))
@@ -85,6 +90,7 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
         assert eh <= CAP[kind] * max(1.0, scale[kind] / 3.0) * gain, (kind, eh, scale[kind])
         assert eh <= K_ROUNDED * eb + SLACK[kind], "%s: hip %.3e vs %.1f x rounded-oracle %.3e + %.0e" % (kind, eh, K_ROUNDED, eb, SLACK[kind])
     _decision_flips(case, got, want, FULL[case][3], rnd=rnd)
+    _decision_flips(case + " [bf16 streams]", got_bf, want, FULL[case][3])
 
 
 def _decision_flips(case, got, want, dataset, rnd=None):

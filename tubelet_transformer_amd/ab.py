@@ -30,6 +30,8 @@ KNOWN = {
     "no_in_proj_dx2": "the few-row data gradients of the decoder (in-projection: x and query_pos; linear1) as tuber_gemm_nt launches instead of tuber_rows_dx2",
     "no_decoder_coop": "the DETR decoder stack as its ~80 separate launches instead of the one cooperative launch (csrc/decoder_coop.hip)",
     "eager_step": "train_tuber_detection without the captured hipGraph step",
+    "eval_bf16_stream": "eval forward with the residual streams (block outputs, LayerNorm outputs) stored in bf16 like the training path, instead of the fp32 "
+                        "streams of the eval precision mode (round 6; also TUBER_EVAL_PRECISION=bf16_stream)",
 }
 
 
@@ -53,6 +55,11 @@ def on(name):
 
 def active():
     return sorted(_active)
+
+
+def eval_fp32_stream():
+    """eval precision mode (default): under ``model.eval()`` the residual streams stay fp32 between the blocks / layers"""
+    return not on("eval_bf16_stream") and os.environ.get("TUBER_EVAL_PRECISION", "fp32_stream") != "bf16_stream"
 
 
 @contextlib.contextmanager

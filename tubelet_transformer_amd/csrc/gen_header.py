@@ -51,6 +51,18 @@ DOC = {
                               "a1, y1, xhat1, rstd1, q, o2, lse2, a2, y2, xhat2, rstd2, h, f2, y3, xhat3, rstd3, xhatN, rstdN). layer_salts: HOST array, 6 dropout salts per layer. "
                               "sync: 4 zeroed 32-bit device words, left zero by a clean run; sync[2] != 0 afterwards = a barrier timed out (a workgroup was not co-resident): the kernel has "
                               "overwritten hs with NaN, so the step's loss / gradient norm are NaN and tuber_adamw_segment skips the update.",
+    "tuber_block_out_fwd_f32": "tuber_block_out_fwd for the eval precision mode: y = relu(bn4(c4) + shortcut) (models/backbones/ir_CSN_152.py:84-90) with the residual "
+                               "stream kept in fp32 between the bottlenecks -- reads the previous block's fp32 output, writes the bf16 GEMM operand AND the fp32 stream.",
+    "tuber_layernorm_fwd_f32": "tuber_layernorm_fwd for the eval precision mode: LayerNorm(x + res) (models/transformer/transformer.py:160-167,229-247, post-norm) with the "
+                               "residual stream in fp32 from LayerNorm to LayerNorm; writes the bf16 GEMM operand and (optionally) the fp32 stream.",
+    "tuber_gemm_tn_glds_set": "measurement / test hook: 1 = the 128 x 128 weight-gradient tiles of tuber_gemm_tn / tuber_gemm_tn_group (Conv3d / Linear weight gradients, "
+                              "ir_CSN_152.py:41-64, transformer.py:153-168) park their operands by LDS-DMA (global_load_lds_dwordx4) instead of through VGPRs; returns the previous setting.",
+    "tuber_flag_signal": "software ordering edge between two HIP streams, producer side: *flag += 1 (release, agent scope) once everything enqueued on the stream "
+                         "before it has completed; capturable as the last node of a graph part. With tuber_flag_wait it replaces the hipEventRecord / "
+                         "hipStreamWaitEvent pair between the backward stream and the gradient exchange's stream (DistributedDataParallel's reducer, "
+                         "utils/model_utils.py:47-52): a pending cross-stream event wait slows every kernel of a launch-bound graph by ~1.3 us on this runtime.",
+    "tuber_flag_wait": "consumer side: a one-wave kernel that polls *flag until it reaches `expect` (wrap-around safe), in front of the collective on the "
+                       "exchange's stream; gives up after ~2 s, sets *err = 1 and lets the stream go on (the caller checks the word where it synchronises).",
     "tuber_decoder_coop_supported": "1 when tuber_decoder_coop_fwd takes this decoder (d_model 256, 8 heads, FFN 2048, batch * 8 == 16 attention units, batch * queries <= 32, <= 6 layers).",
     "tuber_decoder_coop_ptrs_per_layer": "device pointers per layer in tuber_decoder_coop_fwd's layer_ptrs (40).",
     "tuber_mask_resize": "F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0] (models/backbone_builder.py:85-86): nearest-neighbour resize of the "

@@ -183,6 +183,44 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(
     }
 }
 
+// the same join for the EVAL precision mode (round 6): the residual stream stays fp32 -- res32 = the previous block's fp32 output (identity
+// blocks) or the BatchNorm of the bf16 projection-shortcut conv output (res / rs / rh) -- and the block output is written twice: y32 (fp32,
+// the next block's residual input) and y (bf16, the operand of the next block's conv1 / projection GEMMs).  That is where the bf16-rounded
+// execution of the oracle (tests/parity_util.py) rounds: conv operands and results, never the stream between the blocks.
+__global__ __launch_bounds__(256) void block_out_fwd_f32_kernel(
+    const bf16* __restrict__ c4, const float* __restrict__ s4, const float* __restrict__ h4,
+    const bf16* __restrict__ res, const float* __restrict__ rs, const float* __restrict__ rh, const float* __restrict__ res32,
+    bf16* __restrict__ y, float* __restrict__ y32, long M, int C) {
+    const int tpr = C >> 3;
+    const int cg = threadIdx.x % tpr;
+    const long rpp = 256 / tpr;
+    float a4[8], b4[8], ar[8], br[8];
+    load8f(s4 + cg * 8, a4); load8f(h4 + cg * 8, b4);
+    if (rs) { load8f(rs + cg * 8, ar); load8f(rh + cg * 8, br); }
+    for (long row = (long)blockIdx.x * rpp + threadIdx.x / tpr; row < M; row += (long)gridDim.x * rpp) {
+        const long off = row * C + cg * 8;
+        const bf16x8 c = as_bf16x8(*(const uint4*)(c4 + off));
+        float rv[8];
+        if (res32) {
+            load8f(res32 + off, rv);
+        } else {
+            const bf16x8 r = as_bf16x8(*(const uint4*)(res + off));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = rs ? fmaf(bf2f(r[e]), ar[e], br[e]) : bf2f(r[e]);
+        }
+        bf16x8 o;
+        float of[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            of[e] = fmaxf(fmaf(bf2f(c[e]), a4[e], b4[e]) + rv[e], 0.f);
+            o[e] = f2bf(of[e]);
+        }
+        *(uint4*)(y + off) = as_uint4(o);
+        ((float4*)(y32 + off))[0] = make_float4(of[0], of[1], of[2], of[3]);
+        ((float4*)(y32 + off))[1] = make_float4(of[4], of[5], of[6], of[7]);
+    }
+}
+
 // dz = dy * [y > 0]  (bf16 out) ; partial stats per block: sum dz, sum dz*c4, (sum dz*cds)
 __global__ __launch_bounds__(256) void block_out_bwd_kernel(
     const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ c4, const bf16* __restrict__ cds,
@@ -440,6 +478,55 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
         if (xhat_out) *(uint2*)(xhat_out + base + col) = as_uint2(xh);
     }
     if (rstd_out && lane == 0) rstd_out[row] = rstd;
+}
+
+// eval precision mode (round 6): y = LayerNorm(x + res) with the residual STREAM in fp32 -- x32 / res32 (fp32 [M, E]) take precedence over
+// the bf16 x / res when given -- and the result written as bf16 (y, leading dimension ldy: the operand of the next GEMM) and, when y32 is
+// not NULL, as fp32 [M, E] (the next LayerNorm's residual input).  No dropout, nothing saved for a backward.
+template <int EPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_f32_kernel(
+    const bf16* __restrict__ x, const float* __restrict__ x32, const bf16* __restrict__ res, const float* __restrict__ res32,
+    const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ y, long ldy, float* __restrict__ y32, int M, float eps) {
+    constexpr int E = EPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[EPL];
+    const long base = (long)row * E;
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        float xv[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (x32) { const float4 t = *(const float4*)(x32 + base + col); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; }
+        else { const bf16x4 a = as_bf16x4(*(const uint2*)(x + base + col)); xv[0] = bf2f(a[0]); xv[1] = bf2f(a[1]); xv[2] = bf2f(a[2]); xv[3] = bf2f(a[3]); }
+        if (res32) { const float4 t = *(const float4*)(res32 + base + col); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+        else if (res) { const bf16x4 r = as_bf16x4(*(const uint2*)(res + base + col)); rv[0] = bf2f(r[0]); rv[1] = bf2f(r[1]); rv[2] = bf2f(r[2]); rv[3] = bf2f(r[3]); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i * 4 + e] = xv[e] + rv[e];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.f / E);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / E) + eps);
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const float4 g = *(const float4*)(gamma + col), b = *(const float4*)(beta + col);
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+        bf16x4 o;
+        float of[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            of[e] = fmaf((v[i * 4 + e] - mean) * rstd, gg[e], bb[e]);
+            o[e] = f2bf(of[e]);
+        }
+        *(uint2*)(y + (long)row * ldy + col) = as_uint2(o);
+        if (y32) *(float4*)(y32 + base + col) = make_float4(of[0], of[1], of[2], of[3]);
+    }
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); partial dgamma = sum dy*xhat, dbeta = sum dy
@@ -738,6 +825,16 @@ int tuber_block_out_fwd(const void* c4, const float* s4, const float* h4, const 
     TUBER_RETURN_LAUNCH();
 }
 
+// tuber_block_out_fwd with an fp32 residual stream (eval precision mode): res32 (fp32 [M, C], the previous block's y32) or, when NULL, the
+// bf16 shortcut `res` with its optional BatchNorm (rs / rh); writes y (bf16) AND y32 (fp32).
+int tuber_block_out_fwd_f32(const void* c4, const float* s4, const float* h4, const void* res, const float* rs, const float* rh,
+                            const float* res32, void* y, float* y32, long M, int C, hipStream_t stream) {
+    if (!chan_ok(C) || (!res && !res32) || !y || !y32) return TUBER_EINVAL;
+    hipLaunchKernelGGL(block_out_fwd_f32_kernel, dim3(ew_grid(M, C)), dim3(256), 0, stream, (const bf16*)c4, s4, h4, (const bf16*)res,
+                       rs, rh, res32, (bf16*)y, y32, M, C);
+    TUBER_RETURN_LAUNCH();
+}
+
 // rows of partial stats written by the row-blocked reduce kernels for an [M, C] tensor: ~16K elements per block
 // (8 passes of 256 threads x 8 channels), at most 1024 blocks
 int tuber_rowblock_count(long M, int C) {
@@ -817,6 +914,21 @@ int tuber_layernorm_fwd(const void* x, const void* res, const float* gamma, cons
     const float ik = dropout_inv_keep(p);
 #define LNF(EPL) hipLaunchKernelGGL(layernorm_fwd_kernel<EPL>, grid, block, 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta, \
                                     (bf16*)y, ldy, (bf16*)xhat, rstd, M, eps, th, ik, (const uint64_t*)seed_ptr, (uint64_t)salt)
+    if (E == 256) LNF(4);
+    else if (E == 2048) LNF(32);
+    else return TUBER_EINVAL;
+#undef LNF
+    TUBER_RETURN_LAUNCH();
+}
+
+// eval precision mode: LayerNorm(x + res) with fp32 stream operands (x32 / res32 override x / res when not NULL; res, res32 both NULL =
+// no residual) -> y (bf16, leading dimension ldy) and y32 (fp32 [M, E], may be NULL).
+int tuber_layernorm_fwd_f32(const void* x, const float* x32, const void* res, const float* res32, const float* gamma, const float* beta,
+                            void* y, long ldy, float* y32, int M, int E, float eps, hipStream_t stream) {
+    if (ldy < E || (ldy & 3) || (!x && !x32) || !y) return TUBER_EINVAL;
+    dim3 grid(ceil_div(M, 4)), block(256);
+#define LNF(EPL) hipLaunchKernelGGL(layernorm_fwd_f32_kernel<EPL>, grid, block, 0, stream, (const bf16*)x, x32, (const bf16*)res, res32, gamma, beta, \
+                                    (bf16*)y, ldy, y32, M, eps)
     if (E == 256) LNF(4);
     else if (E == 2048) LNF(32);
     else return TUBER_EINVAL;

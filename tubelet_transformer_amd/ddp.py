@@ -170,10 +170,17 @@ class FlatGradReducer:
                 self.late.append((o, o + (store.module.get_parameter(n).numel() + 63) // 64 * 64))
         self.late.sort()
         self.ranges = trainable_ranges(store)
-        mode = os.environ.get("TUBER_DDP_EDGE", "torch")
-        self.edge_out = [StreamEdge(mode) for _ in range(8)]     # backward stream -> transport stream, one reusable event per issue point of a step
-        self.edge_back = StreamEdge(mode)                         # transport stream -> optimizer's stream
+        # how the transport's stream learns that a window is final on the backward stream (see flag_points): 'flag' = a counter in device
+        # memory, bumped by a one-thread kernel that is the last node of a graph part and polled by a one-wave kernel in front of the
+        # collective (csrc/stream_flag.hip); 'event' = hipEventRecord + hipStreamWaitEvent as until round 5 ('device' / 'nofence' /
+        # 'plain': the same with other event flags -- measured identical); 'hybrid' (default) = counter at the first cut, events after.
+        self.edge_mode = os.environ.get("TUBER_DDP_EDGE", "hybrid")
+        ev_mode = "torch" if self.edge_mode in ("flag", "event", "hybrid") else self.edge_mode
+        self.edge_out = [StreamEdge(ev_mode) for _ in range(8)]  # backward stream -> transport stream, one reusable event per issue point of a step
+        self.edge_back = StreamEdge(ev_mode)                      # transport stream -> optimizer's stream (few kernels behind it: cheap)
         self.edge_k = 0
+        self.flags = torch.zeros(16, dtype=torch.int32, device=store.device) if comm is not None else None      # [0..7] counters, [15] error word
+        self.expect = [0] * 8
 
     # -- step protocol -----------------------------------------------------------------------------------------------------
     def begin(self):
@@ -189,8 +196,40 @@ class FlatGradReducer:
             e.record(torch.cuda.current_stream())
             self.win_events.append((e, []))
 
-    def reduce(self, lo, hi):
-        """all-reduce (and average) the trainable part of gflat[lo:hi); returns immediately."""
+    def flag_points(self):
+        """issue points of the captured step (0 = the first cut) that are ordered by a device-memory counter instead of an event.
+        Measured on the one-rank line, per graph part, against the same cut graphs with no edges (profiles/r06_ddp_edges.txt):
+          event edge   : the part in front of it + 0.35 ms when that part is the 520 small launches of forward + transformer backward
+                         (a pending hipStreamWaitEvent costs every dispatch of the other queue), + 0.09 / + 0.06 ms for the layer3 /
+                         layer2-1 backward parts (fewer, longer kernels);
+          counter edge : + 0.02 ms in front of the first cut, but + 0.41 / + 0.27 ms on the layer3 / layer2-1 backward parts: the polling
+                         wave holds a few VGPRs of one SIMD, and the one-workgroup-per-CU backward kernels (dwconv_tile_bwd_both, conv1_bwd,
+                         conv4_bwd: 8 waves x up to 256 VGPRs = a CU's whole register file) then find 255 free CUs and run a second round.
+        'hybrid' (default) takes the cheap one at each point: counter for the first cut, events behind it."""
+        if self.comm is None or self.edge_mode not in ("flag", "hybrid"):
+            return frozenset()
+        return frozenset(range(8)) if self.edge_mode == "flag" else frozenset([0])
+
+    def signal(self, i):
+        """on the CURRENT stream (the backward stream; capturable): counter i += 1 once everything enqueued before has completed"""
+        from . import lib
+        lib.call("tuber_flag_signal", self.flags.data_ptr() + 4 * i)
+
+    def wait_for(self, i):
+        """the transport's stream goes on once signal(i) of this step has executed (no runtime-level dependency between the queues)"""
+        from . import lib
+        self.expect[i] = (self.expect[i] + 1) & 0xFFFFFFFF
+        lib.call("tuber_flag_wait", self.flags.data_ptr() + 4 * i, self.expect[i], self.flags.data_ptr() + 4 * 15, self.comm.stream.cuda_stream)
+        self._joined = False
+
+    def check(self):
+        """host-side (syncs): a flag wait that gave up after 2 s means a signal was lost -- the step ordering is broken"""
+        if self.flags is not None and int(self.flags[15].item()):
+            raise RuntimeError("gradient exchange: a stream-flag wait timed out (counters %s, expected %s)" % (self.flags[:8].tolist(), self.expect))
+
+    def reduce(self, lo, hi, edge=True):
+        """all-reduce (and average) the trainable part of gflat[lo:hi); returns immediately.  ``edge``: order the transport's stream behind the
+        current stream with an event first (False: the caller has already ordered it -- wait_for(), or an earlier window of the same issue point)."""
         if hi <= lo or (self.world <= 1 and self.comm is None):
             return
         wins = [(max(a, lo), min(b, hi)) for a, b in self.ranges]
@@ -210,8 +249,9 @@ class FlatGradReducer:
         if timed:
             issue = torch.cuda.Event(enable_timing=True)
             issue.record(torch.cuda.current_stream())           # when the backward stream reaches this issue point
-        self.edge_out[self.edge_k % len(self.edge_out)](torch.cuda.current_stream(), cs)      # the windows are final on the backward stream up to here
-        self.edge_k += 1
+        if edge:
+            self.edge_out[self.edge_k % len(self.edge_out)](torch.cuda.current_stream(), cs)      # the windows are final on the backward stream up to here
+            self.edge_k += 1
         self._joined = False
         inv = 1.0 / self.world
         base = st.gflat.data_ptr()

@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "tuber_hip.h")
 LIBPATH = os.path.join(HERE, "lib", "libtuber_hip.so")
 
 _CT = {
-    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "unsigned": ctypes.c_uint,
     "unsigned long long": ctypes.c_ulonglong, "hipStream_t": ctypes.c_void_p, "const char*": ctypes.c_char_p,
 }
 _lib = None

@@ -58,6 +58,7 @@ class Tape:
         self.pending = {}      # id(gradient tensor) -> _PendingLN: a LayerNorm backward not launched yet (it may fuse into its consumer)
         self.pair_ok = set()   # id(y) of LayerNorm outputs whose backward can take two unsummed gradient contributions (fusable ones)
         self.lin_out = set()   # id(y) of linear() outputs a LayerNorm backward may fuse into (plain linear with 256 outputs, no ReLU / Dropout)
+        self.f32 = {}          # eval precision mode: id(bf16 LayerNorm output) -> (that tensor, its fp32 twin): the residual stream between LayerNorms
         self.req = set()       # ids of tensors whose gradient is needed (they depend on a trainable parameter): the backward pass
         #                        skips weight gradients of frozen parameters and data gradients nobody consumes, like autograd does
 
@@ -510,6 +511,15 @@ def layer_norm(tp, x, res, prefix, drop=0.0, out=None):
     rstd = torch.empty(M, dtype=torch.float32, device=dev) if tp.train else None
     if tp.dry:
         tp.dry_log.append(("layer_norm", dict(x=x, res=res, yptr=yptr, ldy=ldy, xhat=xhat, rstd=rstd, gamma=gamma, beta=beta, p=p, salt=salt)))
+    elif not tp.train and p == 0.0 and ab.eval_fp32_stream():
+        # eval precision mode: the post-norm residual stream stays fp32 from LayerNorm to LayerNorm (tp.f32: fp32 twin of a bf16 LayerNorm
+        # output); the bf16 result is only the operand of the GEMMs behind it.  The training path's bf16-stored stream costs ~1.3x on the actor
+        # logits of a fixture with identity-dominated layers (measured on the oracle)
+        x32, r32 = tp.f32.get(id(x)), (tp.f32.get(id(res)) if res is not None else None)
+        y32 = torch.empty(M, E, dtype=torch.float32, device=dev) if out is None else None
+        lib.call("tuber_layernorm_fwd_f32", x, x32[1] if x32 else None, res, r32[1] if r32 else None, gamma, beta, yptr, ldy, y32, M, E, 1e-5)
+        if y32 is not None:
+            tp.f32[id(y)] = (y, y32)             # (the bf16 tensor is held too: its id must not be recycled while the twin is listed)
     else:
         lib.call("tuber_layernorm_fwd", x, res, gamma, beta, yptr, ldy, xhat, rstd, M, E, 1e-5, p, st.seed, salt)
     if not tp.train:

@@ -131,6 +131,7 @@ class GraphedTrainStep:
         self.model, self.criterion, self.optimizer = model, criterion, fused
         self.max_norm, self.tmax, self.max_graphs = max_norm, tmax, max_graphs
         self.graphs = collections.OrderedDict()
+        self.part_marks = None
 
     # -- capture -------------------------------------------------------------------------------------------------------------
     def _capture(self, clips, mask, targets, tmax):
@@ -214,7 +215,7 @@ class GraphedTrainStep:
                 red.dry = False
         opt.sync_hyper()
         crit.sync_weights(dev)
-        g.A, g.A2, g.B1, g.B2, g.split, g.parts, g.cuts = torch.cuda.CUDAGraph(), None, None, None, None, [], []
+        g.A, g.A2, g.B1, g.B2, g.split, g.parts, g.cuts, g.flag_edges = torch.cuda.CUDAGraph(), None, None, None, None, [], [], frozenset()
         split = split and g.on_device
         own_step = not ddp or in_graph               # clip + AdamW inside the main graph (else graph B2, behind the all-reduce)
         if in_graph:
@@ -236,6 +237,8 @@ class GraphedTrainStep:
             # beside the bandwidth-bound layer2 / layer1 backward and cost a rank 0.77 ms of contention with nothing on the wire.)
             cut = []
             graphs = [g.A]
+            # issue points ordered by a device-memory counter instead of an event (ddp.FlatGradReducer.flag_points): by default the FIRST
+            flag_edges = g.flag_edges = red.flag_points() if red is not None else frozenset()
             torch.cuda.synchronize()
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
@@ -243,6 +246,8 @@ class GraphedTrainStep:
                 g.A.capture_begin(capture_error_mode="relaxed")      # the cuts happen on autograd's worker thread
 
                 def hook(off):
+                    if len(cut) in flag_edges:
+                        red.signal(len(cut))                         # last node of this part: the windows above are final
                     graphs[-1].capture_end()
                     cut.append(int(off))
                     nxt = torch.cuda.CUDAGraph()
@@ -255,6 +260,8 @@ class GraphedTrainStep:
                     tail(own_step)
                 finally:
                     runner.split_hook = None
+                if len(cut) in flag_edges and not own_step and cut:  # (no cut -- a frozen body: one event-ordered window after the graph)
+                    red.signal(len(cut))                             # end of backward: the remainder is final
                 graphs[-1].capture_end()
                 g.parts, g.cuts, g.body_begin = graphs[1:], cut, int(runner.body_begin)
                 g.A2 = graphs[-1] if cut else None
@@ -338,7 +345,13 @@ class GraphedTrainStep:
         red = g.red
         if red is not None and not g.in_graph:
             red.begin()
+        marks = self.part_marks                               # bench.py: HIP-event stamps between the graph parts of the measured steps
+        if marks is not None:
+            marks.append([])
+            self._mark()
         g.A.replay()
+        if marks is not None:
+            self._mark()
         if g.on_device:
             self.criterion._indices, self.criterion._match_dev = None, (g.match, sizes)
         else:
@@ -357,20 +370,45 @@ class GraphedTrainStep:
             hi = store.total
             for i, part in enumerate(g.parts):
                 if red is not None:
-                    red.reduce(g.cuts[i], hi)
+                    soft = i in g.flag_edges                  # ordered by the counter the graph part bumps, not by an event (csrc/stream_flag.hip)
+                    if soft:
+                        red.wait_for(i)
+                    red.reduce(g.cuts[i], hi, edge=not soft)
                     if i == 0:
-                        red.reduce(0, g.body_begin)
+                        red.reduce(0, g.body_begin, edge=False)
                 hi = g.cuts[i]
                 part.replay()                                 # the backward of the stages below, under the all-reduce
+                if marks is not None:
+                    self._mark()
             if red is not None:
-                red.reduce(g.body_begin, hi)
+                soft = len(g.parts) in g.flag_edges
+                if soft:
+                    red.wait_for(len(g.parts))
+                red.reduce(g.body_begin, hi, edge=not soft)
         elif red is not None and not g.in_graph:
             red.reduce(0, store.total)
         if red is not None and not g.in_graph:
             red.finish(rest=False)                            # the optimizer graph waits for the side stream (events only)
         if g.B2 is not None:
             g.B2.replay()
+            if marks is not None:
+                self._mark()
         return g.loss, g.loss_dict
+
+    def _mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.part_marks[-1].append(e)
+
+    def part_ms(self):
+        """mean duration (ms) of each graph part over the steps stamped since ``part_marks = []`` (syncs)"""
+        torch.cuda.synchronize()
+        rows = [[a.elapsed_time(b) for a, b in zip(m[:-1], m[1:])] for m in (self.part_marks or []) if len(m) > 1]
+        self.part_marks = None
+        if not rows:
+            return None
+        n = min(len(r) for r in rows)
+        return [round(sum(r[i] for r in rows) / len(rows), 3) for i in range(n)]
 
 
 class _DeviceMeters:

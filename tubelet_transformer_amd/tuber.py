@@ -334,7 +334,9 @@ class DETR(nn.Module):
         tgt = torch.zeros(B * Q, E, dtype=BF, device=dev)
         lay_n = self.transformer.decoder.num_layers
         hs = torch.empty(lay_n * B * Q, E, dtype=BF, device=dev)                    # rows (layer, b, q)
-        coop = (not ab.on("no_decoder_coop") and not st.coop_off and lib.query("tuber_decoder_coop_supported", E, H, self.transformer.decoder.layers[0].linear1.out_features, B, Q, lay_n) == 1)
+        # (the eval precision mode keeps the decoder's residual stream fp32 from LayerNorm to LayerNorm: the launch chain, whose LayerNorm
+        #  kernel has that form; the cooperative launch holds its state as bf16 LDS images)
+        coop = (not ab.on("no_decoder_coop") and not st.coop_off and (self.training or not ab.eval_fp32_stream()) and lib.query("tuber_decoder_coop_supported", E, H, self.transformer.decoder.layers[0].linear1.out_features, B, Q, lay_n) == 1)
         if coop:
             # the decoder stack as ONE cooperative launch (csrc/decoder_coop.hip): the memory-side projections first (they do not depend on
             # the decoder state), then a DRY run of the same op sequence -- it allocates every saved tensor, draws the dropout salts and
