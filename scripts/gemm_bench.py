@@ -141,22 +141,9 @@ def bench_tn_group():
             by += 2 * M * (N + K) + 4 * N * K
             fl += 2 * M * N * K
         arr = (TnArgs * len(ents))(*ents)
-        ref = None
-        for glds in (0, 1, 0, 1):          # round 6: operands parked through registers (0) / by LDS-DMA (1), interleaved, same data
-            lib.query("tuber_gemm_tn_glds_set", glds)
-            for k in keep:
-                k[4].zero_(); k[5].zero_()
-            lib.call("tuber_gemm_tn_group", arr, len(ents))          # one launch on zeroed outputs: what the two paths are compared on
-            torch.cuda.synchronize()
-            res = [(k[4] if k[4].numel() > k[5].numel() else k[5]).clone() for k in keep]
-            t = time_it(lambda: lib.call("tuber_gemm_tn_group", arr, len(ents)))
-            same = "" if ref is None else ("  bit-identical to the register path: %s" % all(torch.equal(a, b) for a, b in zip(ref, res)))
-            if ref is None:
-                ref = res
-            print("%-20s %2d GEMMs  slabs %s  %s %7.1f us   %.1f MB alg -> %.2f TB/s (%.3f of 8 TB/s), %.0f TF/s%s" % (
-                name, len(ents), [lib.query("tuber_gemm_tn_slabs", *q[:3]) for q in probs[:2]], "LDS-DMA  " if glds else "registers", t, by / 1e6, by / t / 1e6,
-                by / t / 1e6 / 8.0, fl / t / 1e6, same), flush=True)
-        lib.query("tuber_gemm_tn_glds_set", 0)
+        t = time_it(lambda: lib.call("tuber_gemm_tn_group", arr, len(ents)))
+        print("%-20s %2d GEMMs  slabs %s  %7.1f us   %.1f MB alg -> %.2f TB/s (%.3f of 8 TB/s), %.0f TF/s" % (
+            name, len(ents), [lib.query("tuber_gemm_tn_slabs", *q[:3]) for q in probs[:2]], t, by / 1e6, by / t / 1e6, by / t / 1e6 / 8.0, fl / t / 1e6), flush=True)
 
 
 def bench_misc():

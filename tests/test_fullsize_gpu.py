@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the build's stated bf16 tolerance (DESIGN.md section 4): yardstick factor + slack against the bf16-rounded oracle, and absolute caps
 CAP = {"pred_logits": 5e-2, "pred_logits_b": 5e-2, "pred_boxes": 1e-2}
 K_ROUNDED, SLACK = 2.0, {"pred_logits": 4e-3, "pred_logits_b": 4e-3, "pred_boxes": 1e-3}
+# the tolerance the survey stated before any bf16 execution existed (BASELINE.md section 4): met by the eval precision mode since round 6
+BASELINE_TOL = {"pred_logits": 2e-2, "pred_logits_b": 2e-2, "pred_boxes": 5e-3}
 
 FULL = {
     "cfg1_csn50_decode_224": ("TubeR_CSN50_AVA21.yaml", 1, (224, 224), "ava"),      # BASELINE config 1's geometry: 14 x 14 grid = 196 tokens (not a multiple of 16)
@@ -72,10 +74,13 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
     from tubelet_transformer_amd import ab
     with torch.no_grad():
         got = model(clips.to(dev))                      # default: the eval precision mode (fp32 residual streams, round 6)
+        with ab.override("eval_bf16_decoder"):
+            got_st = model(clips.to(dev))               # fp32 residual streams only: the decoder / heads on the bf16 launch chain
         with ab.override("eval_bf16_stream"):
             got_bf = model(clips.to(dev))               # the training path's rounding points (bf16-stored block / LayerNorm outputs)
     errs = output_errors(got, want, rnd)
     errs_bf = output_errors(got_bf, want, rnd)
+    print("   fp32 residual streams only (TUBER_AB=eval_bf16_decoder): %s" % {k: "%.2e" % v[0] for k, v in output_errors(got_st, want, rnd).items()})
     print("%s (%s, %dx3x32x%dx%d) eval: max abs err vs fp32 oracle  hip / bf16-rounded oracle: %s   [oracle %.1f s]" % (
         case, yaml_name, B, hw[0], hw[1], {k: "%.2e / %.2e" % v for k, v in errs.items()}, t1 - t0))
     print("   the same with bf16-stored residual streams (TUBER_AB=eval_bf16_stream, the training path's rounding points): %s" % {k: "%.2e" % v[0] for k, v in errs_bf.items()})
@@ -83,13 +88,23 @@ def test_full_size_eval_forward_vs_oracle_and_rounded_yardstick(dev, case):
     for k, v in flat_outputs(want).items():
         scale[k.split(".")[-1]] = max(scale.get(k.split(".")[-1], 0.0), float(np.abs(v).max()))
     print("   output scales (max |fp32 oracle|): %s" % {k: "%.2f" % v for k, v in scale.items()})
-    for kind, (eh, eb) in errs.items():
+    for kind in errs:
         # absolute caps were stated for O(1..3) logits; an output with a larger range (the JHMDB 2048->2 visibility head on
         # pooled features: |logit| ~ 10) gets the cap in proportion
         gain = synth.SPREAD_GAINS["class_embed_b"] if (spread and kind == "pred_logits_b") else 1.0     # the head's weight gain scales logits and error alike
-        assert eh <= CAP[kind] * max(1.0, scale[kind] / 3.0) * gain, (kind, eh, scale[kind])
+        rng = max(1.0, scale[kind] / 3.0) * gain
+        # (1) the default eval path -- the EVAL PRECISION MODE of round 6 (fp32 residual streams, fp32 decoder and box / actor heads) --
+        # meets the tolerance BASELINE.md section 4 / SURVEY section 8c wrote down: 2e-2 on logits, 5e-3 on boxes (x the output's range)
+        eh, eb = errs[kind]
+        assert eh <= BASELINE_TOL[kind] * rng, "%s: %.3e exceeds the stated tolerance %.0e x %.2f" % (kind, eh, BASELINE_TOL[kind], rng)
+        # (2) the training path's rounding points (bf16-stored streams, bf16 MFMA decoder): the round-3 statement -- within 2 x the bf16-rounded
+        # oracle + slack and under the caps
+        eh = errs_bf[kind][0]
+        assert eh <= CAP[kind] * rng, (kind, eh, scale[kind])
         assert eh <= K_ROUNDED * eb + SLACK[kind], "%s: hip %.3e vs %.1f x rounded-oracle %.3e + %.0e" % (kind, eh, K_ROUNDED, eb, SLACK[kind])
-    _decision_flips(case, got, want, FULL[case][3], rnd=rnd)
+    dpb = _decision_flips(case, got, want, FULL[case][3], rnd=rnd)
+    if dpb is not None:          # AVA: the actor probability that gates PostProcessAVA moves by <= 5e-3 (VERDICT r05 item 4)
+        assert dpb <= 5e-3, dpb
     _decision_flips(case + " [bf16 streams]", got_bf, want, FULL[case][3])
 
 
@@ -130,7 +145,10 @@ def _decision_flips(case, got, want, dataset, rnd=None):
         sc_h = lg_h.sigmoid() * ((pb_h > 0.8).float() * pb_h)[..., None]
         sc_r = lg_r.sigmoid() * ((pb_r > 0.8).float() * pb_r)[..., None]
         msg += "; max |d score| of PostProcessAVA %.2e" % float((sc_h - sc_r).abs().max())
+        print(msg)
+        return dpb
     print(msg)
+    return None
 
 
 def _check_bn_buffers(cfg, model, state, clips):

@@ -778,3 +778,32 @@ def test_cooperative_decoder_fails_safe_when_starved(dev):
     for k in KEYS:
         assert torch.equal(out[k], chain2[k]), k
     torch.cuda.synchronize()
+
+
+def test_stream_flag_edge_orders_two_streams_and_gives_up_when_its_signal_never_comes(dev):
+    """csrc/stream_flag.hip: the software edge the gradient exchange uses at its first issue point.  (1) a consumer stream that waits for
+    counter value k reads what the producer stream wrote before its k-th signal -- 50 rounds, the producer's kernel is a long one, the
+    consumer would read the stale value if it ran early; (2) a wait whose signal never comes ends after ~2 s with the error word set."""
+    import time
+    from tubelet_transformer_amd import lib
+    flags = torch.zeros(16, dtype=torch.int32, device=dev)
+    prod, cons = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(32 << 20, device=dev)
+    seen = torch.zeros(50, device=dev)
+    torch.cuda.synchronize()
+    for k in range(1, 51):
+        with torch.cuda.stream(prod):
+            big.add_(1.0)                                                    # ~0.1 ms of work the signal must wait for
+            lib.call("tuber_flag_signal", flags.data_ptr())
+        with torch.cuda.stream(cons):
+            lib.call("tuber_flag_wait", flags.data_ptr(), k, flags.data_ptr() + 4 * 15)
+            seen[k - 1:k].copy_(big[-1:])                                    # must see k
+    torch.cuda.synchronize()
+    assert seen.tolist() == [float(k) for k in range(1, 51)], seen.tolist()
+    assert int(flags[0]) == 50 and int(flags[15]) == 0
+    t0 = time.time()
+    with torch.cuda.stream(cons):
+        lib.call("tuber_flag_wait", flags.data_ptr() + 4, 1, flags.data_ptr() + 4 * 15)      # counter 1 is never bumped
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    assert int(flags[15]) == 1 and 1.5 < dt < 4.0, (flags.tolist(), dt)

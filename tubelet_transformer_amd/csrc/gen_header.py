@@ -55,8 +55,11 @@ DOC = {
                                "stream kept in fp32 between the bottlenecks -- reads the previous block's fp32 output, writes the bf16 GEMM operand AND the fp32 stream.",
     "tuber_layernorm_fwd_f32": "tuber_layernorm_fwd for the eval precision mode: LayerNorm(x + res) (models/transformer/transformer.py:160-167,229-247, post-norm) with the "
                                "residual stream in fp32 from LayerNorm to LayerNorm; writes the bf16 GEMM operand and (optionally) the fp32 stream.",
-    "tuber_gemm_tn_glds_set": "measurement / test hook: 1 = the 128 x 128 weight-gradient tiles of tuber_gemm_tn / tuber_gemm_tn_group (Conv3d / Linear weight gradients, "
-                              "ir_CSN_152.py:41-64, transformer.py:153-168) park their operands by LDS-DMA (global_load_lds_dwordx4) instead of through VGPRs; returns the previous setting.",
+    "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
+                        "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
+                        "MLP models/criterion.py:485-497) under model.eval().",
+    "tuber_attention_f32": "fp32 multi-head attention core (head dimension 32) of the eval precision mode: the decoder's self- and cross-attention "
+                           "(nn.MultiheadAttention, transformer.py:218-240) with fp32 scores, softmax and values.",
     "tuber_flag_signal": "software ordering edge between two HIP streams, producer side: *flag += 1 (release, agent scope) once everything enqueued on the stream "
                          "before it has completed; capturable as the last node of a graph part. With tuber_flag_wait it replaces the hipEventRecord / "
                          "hipStreamWaitEvent pair between the backward stream and the gradient exchange's stream (DistributedDataParallel's reducer, "

@@ -252,8 +252,8 @@ def linear(tp, x, wname, bname=None, rows=None, relu=False, out_f32=False, drop=
             return False
         wt = st.tshadow.data_ptr() + 2 * (toff + r0)
         r = tp.g.pop(id(tx), None)
-        if r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous() or tp.pending.get(id(r)) is rec):
-            tp.g[id(tx)] = r
+        if isinstance(r, _Pair) or (r is not None and (r.dtype != BF or tuple(r.shape) != (M, K) or not r.is_contiguous() or tp.pending.get(id(r)) is rec)):
+            tp.g[id(tx)] = r                             # (an unsummed pair, Tape.put on a pair_ok tensor: left to the stand-alone GEMM, which forces it)
             return False
         tp.force(r)
         dx = torch.empty(M, K, dtype=BF, device=dev)
@@ -464,8 +464,6 @@ def in_proj(tp, x, addend, wname, bname, rows, add_cols):
                 tp.put(tx, dx)
                 tp.put(addend, da)
                 return
-            if r is not None:
-                tp.g[id(tx)] = r
         if xreq:
             tx = tp.target(x)
             dx = torch.empty(M, K, dtype=BF, device=dev)

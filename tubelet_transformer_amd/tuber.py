@@ -223,6 +223,59 @@ class DETR(nn.Module):
         h = T.linear(tp, x, prefix + ".linear1.weight", prefix + ".linear1.bias", relu=True, drop=p)
         return T.linear(tp, h, prefix + ".linear2.weight", prefix + ".linear2.bias")
 
+    def _decoder_f32(self, tp, st, memory, pos, kpm, hs, B, Q, Lm, lay_n, E, H):
+        """Eval precision mode: TransformerDecoder.forward (models/transformer/transformer.py:99-128,218-249) in fp32 on the master
+        parameters -- packed in-projections with the positional embeddings folded in, fp32 attention cores, post-norm LayerNorms on the
+        fp32 residual stream, FFN -- through tuber_linear_f32 / tuber_attention_f32 / tuber_layernorm_fwd_f32.  The encoder memory enters
+        as its fp32 LayerNorm twin (tape.f32).  Writes hs (bf16 rows (layer, b, q): the class branch's query operand) and returns the
+        fp32 decoder output the box / actor heads read."""
+        dev, F32 = st.device, torch.float32
+        fp = lambda name: st.flat.data_ptr() + 4 * st.offsets[name]
+        R, FF = B * Q, self.transformer.decoder.layers[0].linear1.out_features
+        scale = float(E // H) ** -0.5
+        tw = tp.f32.get(id(memory))
+        if tw is not None:
+            mem32 = tw[1]
+        else:
+            mem32 = torch.empty(memory.shape, dtype=F32, device=dev)
+            lib.call("tuber_cast_bf16_f32_scale", memory, mem32, memory.numel(), 1.0)
+        pos32 = torch.empty(pos.shape, dtype=F32, device=dev)
+        lib.call("tuber_cast_bf16_f32_scale", pos, pos32, pos.numel(), 1.0)
+        o = st.offsets["query_embed.weight"]
+        qpos32 = st.flat[o:o + Q * E].view(Q, E).repeat(B, 1)                       # rows (b, q): the fp32 query embeddings themselves
+        tgt = torch.zeros(R, E, dtype=F32, device=dev)
+        hs32 = torch.empty(lay_n * R, E, dtype=F32, device=dev)
+        scratch = torch.empty(R, E, dtype=torch.bfloat16, device=dev)               # the bf16 twin of a LayerNorm output nobody reads here
+        lin = lambda x, ldx, add, addc, w, b, y, ldy, M, N, K, act=0: lib.call("tuber_linear_f32", x, ldx, add, E if add is not None else 0, addc, w, K, b, y, ldy, M, N, K, act)
+
+        def norm(x32, res32, prefix, y=None, y32=None):
+            out32 = torch.empty(R, E, dtype=F32, device=dev) if y32 is None else y32
+            lib.call("tuber_layernorm_fwd_f32", None, x32, None, res32, fp(prefix + ".weight"), fp(prefix + ".bias"), scratch if y is None else y, E, out32, R, E, 1e-5)
+            return out32
+        for i in range(lay_n):
+            L = "transformer.decoder.layers.%d" % i
+            S, P = L + ".self_attn", L + ".multihead_attn"
+            qkv = torch.empty(R, 3 * E, dtype=F32, device=dev)
+            lin(tgt, E, qpos32, 2 * E, fp(S + ".in_proj_weight"), fp(S + ".in_proj_bias"), qkv, 3 * E, R, 3 * E, E)        # q | k see tgt + query_pos, v sees tgt
+            a = torch.empty(R, E, dtype=F32, device=dev)
+            lib.call("tuber_attention_f32", qkv, 3 * E, qkv.data_ptr() + 4 * E, 3 * E, qkv.data_ptr() + 8 * E, 3 * E, a, E, None, B, H, Q, Q, scale)
+            ao = torch.empty(R, E, dtype=F32, device=dev)
+            lin(a, E, None, 0, fp(S + ".out_proj.weight"), fp(S + ".out_proj.bias"), ao, E, R, E, E)
+            tgt = norm(ao, tgt, L + ".norm1")
+            q = torch.empty(R, E, dtype=F32, device=dev)
+            lin(tgt, E, qpos32, E, fp(P + ".in_proj_weight"), fp(P + ".in_proj_bias"), q, E, R, E, E)                      # (tgt + query_pos) W_q
+            kv = torch.empty(B * Lm, 2 * E, dtype=F32, device=dev)
+            lin(mem32, E, pos32, E, fp(P + ".in_proj_weight") + 4 * E * E, fp(P + ".in_proj_bias") + 4 * E, kv, 2 * E, B * Lm, 2 * E, E)      # [(memory + pos) W_k | memory W_v]
+            lib.call("tuber_attention_f32", q, E, kv, 2 * E, kv.data_ptr() + 4 * E, 2 * E, a, E, kpm, B, H, Q, Lm, scale)
+            lin(a, E, None, 0, fp(P + ".out_proj.weight"), fp(P + ".out_proj.bias"), ao, E, R, E, E)
+            tgt = norm(ao, tgt, L + ".norm2")
+            h = torch.empty(R, FF, dtype=F32, device=dev)
+            lin(tgt, E, None, 0, fp(L + ".linear1.weight"), fp(L + ".linear1.bias"), h, FF, R, FF, E, 1)
+            lin(h, FF, None, 0, fp(L + ".linear2.weight"), fp(L + ".linear2.bias"), ao, E, R, E, FF)
+            tgt = norm(ao, tgt, L + ".norm3")
+            norm(tgt, None, "transformer.decoder.norm", y=hs.data_ptr() + 2 * i * R * E, y32=hs32.data_ptr() + 4 * i * R * E)
+        return hs32
+
     def _decoder_coop_launch(self, st, log, kvs, qpos, hs, kpm, B, Q, Lm, lay_n, pdrop, pattn):
         """tuber_decoder_coop_fwd over what the dry run of the decoder's op sequence logged (12 ops per layer: in-proj, attention, out-proj,
         norm1, q-proj, attention, out-proj, norm2, linear1, linear2, norm3, decoder.norm)."""
@@ -337,6 +390,14 @@ class DETR(nn.Module):
         # (the eval precision mode keeps the decoder's residual stream fp32 from LayerNorm to LayerNorm: the launch chain, whose LayerNorm
         #  kernel has that form; the cooperative launch holds its state as bf16 LDS images)
         coop = (not ab.on("no_decoder_coop") and not st.coop_off and (self.training or not ab.eval_fp32_stream()) and lib.query("tuber_decoder_coop_supported", E, H, self.transformer.decoder.layers[0].linear1.out_features, B, Q, lay_n) == 1)
+        # eval precision mode: the decoder stack and the box / actor heads in fp32 (csrc/eval_f32.hip) -- a few MFLOP per layer on <= 640 rows
+        f32dec = not self.training and ab.eval_fp32_stream() and E // H == 32 and not ab.on("eval_bf16_decoder")
+        hs32 = None
+        if f32dec:
+            hs32 = self._decoder_f32(tp, st, memory, pos, kpm, hs, B, Q, Lm, lay_n, E, H)
+            lay_run = 0
+        else:
+            lay_run = lay_n
         if coop:
             # the decoder stack as ONE cooperative launch (csrc/decoder_coop.hip): the memory-side projections first (they do not depend on
             # the decoder state), then a DRY run of the same op sequence -- it allocates every saved tensor, draws the dropout salts and
@@ -347,7 +408,7 @@ class DETR(nn.Module):
                 kvs.append(T.in_proj(tp, memory, pos, P + ".in_proj_weight", P + ".in_proj_bias", (E, 3 * E), E))
             tp.dry, tp.dry_log = True, []
         try:
-            for i in range(lay_n):
+            for i in range(lay_run):
                 L = "transformer.decoder.layers.%d" % i
                 a = self._mha_self(tp, tgt, qpos, L + ".self_attn", B, Q, None, pattn)
                 tgt = T.layer_norm(tp, a, tgt, L + ".norm1", drop=pdrop)
@@ -365,7 +426,13 @@ class DETR(nn.Module):
             self._decoder_coop_launch(st, log, kvs, qpos, hs, kpm, B, Q, Lm, lay_n, pdrop, pattn)
 
         # ---- heads (tuber_ava.py:121-125,142) ----
-        if self.dataset_mode == "ava":
+        F32 = torch.float32
+        fp = lambda name: st.flat.data_ptr() + 4 * st.offsets[name]      # fp32 master parameter
+        if self.dataset_mode == "ava" and f32dec:
+            logits_b = torch.empty(lay_n * B * Q, 3, dtype=F32, device=dev)
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("class_embed_b.weight"), E, fp("class_embed_b.bias"), logits_b, 3, lay_n * B * Q, 3, E, 0)
+            lb_shape = (lay_n, B, Q, 3)
+        elif self.dataset_mode == "ava":
             logits_b = T.linear(tp, hs, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
             lb_shape = (lay_n, B, Q, 3)
         else:
@@ -373,9 +440,16 @@ class DETR(nn.Module):
                                   (B, 1, Tp * hw, 1, 1, 0, 0, 0, 1.0 / (Tp * hw)))
             logits_b = T.linear(tp, pooled, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
             lb_shape = (B, logits_b.shape[1])
-        x = T.linear(tp, hs, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
-        x = T.linear(tp, x, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
-        boxes = T.sigmoid(tp, T.linear(tp, x, "bbox_embed.layers.2.weight", "bbox_embed.layers.2.bias", out_f32=True))
+        if f32dec:
+            Rh = lay_n * B * Q
+            x1, x2, boxes = (torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, 4, dtype=F32, device=dev))
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("bbox_embed.layers.0.weight"), E, fp("bbox_embed.layers.0.bias"), x1, E, Rh, E, E, 1)
+            lib.call("tuber_linear_f32", x1, E, None, 0, 0, fp("bbox_embed.layers.1.weight"), E, fp("bbox_embed.layers.1.bias"), x2, E, Rh, E, E, 1)
+            lib.call("tuber_linear_f32", x2, E, None, 0, 0, fp("bbox_embed.layers.2.weight"), E, fp("bbox_embed.layers.2.bias"), boxes, 4, Rh, 4, E, 2)
+        else:
+            x = T.linear(tp, hs, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
+            x = T.linear(tp, x, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
+            boxes = T.sigmoid(tp, T.linear(tp, x, "bbox_embed.layers.2.weight", "bbox_embed.layers.2.bias", out_f32=True))
 
         # ---- class branch (tuber_ava.py:127-141; transformer_layers.py:71-97) ----
         src_c = T.linear(tp, feat, "class_proj.weight", "class_proj.bias")         # rows (b, t, hw)
