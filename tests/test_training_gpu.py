@@ -550,6 +550,7 @@ _AB_FORWARD = {"dw_register_tiled", "no_blockout_conv1", "no_entry_conv", "no_de
 # backward-only switches that change the fp32 SUMMATION ORDER of a data-gradient GEMM (other split of the reduction over waves): the bf16
 # rounding of that gradient flips on a few elements and everything below it moves by a bf16 ulp -- linear, no chaos: median <= 1e-2
 _AB_SUMORDER = {"no_in_proj_dx2"}
+_AB_EVAL = {"eval_bf16_stream", "eval_bf16_decoder"}
 
 
 @pytest.mark.parametrize("name", _ab_names())
@@ -564,7 +565,8 @@ def test_every_ab_switch_reproduces_the_default_path(dev, name):
     fwd = name in _AB_FORWARD
     for k in e0:
         err = float((e1[k] - e0[k]).abs().max())
-        assert err <= (2e-2 if fwd else 1e-6), (k, err)
+        # (the eval_* switches select the eval forward's PRECISION, round 6: the eval outputs move by the bf16 path's own error, the training step not at all)
+        assert err <= (4e-2 if name in _AB_EVAL else 2e-2 if fwd else 1e-6), (k, err)
     assert math.isfinite(l1) and abs(l1 - l0) <= (6e-2 if fwd else 1e-4) * max(abs(l0), 1.0), (l0, l1)
     assert set(g0) == set(g1)
     rels = []
