@@ -763,8 +763,10 @@ def test_cooperative_decoder_fails_safe_when_starved(dev):
         store.flat.copy_(flat0)
     model.eval()                                               # (the training steps moved the BatchNorm buffers: fresh chain reference below)
     store.coop_off = False
-    with torch.no_grad():
-        with ab.override("no_decoder_coop"):
+    # (the default eval forward -- the eval precision mode -- runs its decoder in fp32 and never takes the cooperative launch; the form that does is
+    #  TUBER_AB=eval_bf16_stream, the training path's rounding points)
+    with torch.no_grad(), ab.override("eval_bf16_stream"):
+        with ab.override("no_decoder_coop", "eval_bf16_stream"):
             chain2 = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}
         starve()
         bad = {k: v.detach().float().clone() for k, v in model(clips).items() if k in KEYS}

@@ -332,6 +332,9 @@ class CSNRunner:
             # once and not read back.  The next block may be layer2's first one (its conv1 is dense; the stride sits on the depthwise conv).
             nxt = self.blocks[bi + 1] if bi + 1 < hi else None
             if precise:
+                # (all four stages.  Leaving layer1's three blocks -- 356 MB tensors, most of the mode's cost: 5.8 instead of 6.3 ms per 2-clip eval batch -- on
+                #  the bf16 stream and their fused kernels was built and measured: the oracle puts that at +6 % on the actor logits, the MI355X at 1.15e-2 ->
+                #  1.96e-2 on config 3, 0.04e-2 under the tolerance; the mode is there for the margin, so it keeps all of them)
                 y32n = torch.empty(Mout, 4 * P, dtype=torch.float32, device=dev)
                 if d["ds"]:
                     lib.call("tuber_block_out_fwd_f32", c4, b4.scale, b4.shift, cd, rs, rh, None, y, y32n, Mout, 4 * P)

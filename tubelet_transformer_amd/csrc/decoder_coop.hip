@@ -105,11 +105,15 @@ __device__ __forceinline__ void coop_barrier(Ctx& c) {
         }
     }
     __syncthreads();
-    // acquire side of the XCD-local path: the exchanged tensors are written once and first read after the barrier that
-    // follows their producer, so this CU's vector L1 should not hold any line of them -- but four workgroups' 32-byte slices share a
-    // 128-byte line and neighbouring buffers share lines at their ends, so the L1 is invalidated instead of relying on that (one
-    // buffer_inv per wave and barrier; the data comes from the shared L2 either way)
-    if (c.same_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+    // (acquire side of the XCD-local path, ADVICE r05: an L1 invalidate -- buffer_inv sc1 -- per wave behind every barrier was built and
+    //  measured in round 6: the launch went from 300 to 443 us, +0.14 ms per step, because the weight and LayerNorm-parameter lines the
+    //  next stage re-reads went with it; removed.  What the path relies on instead, and why it holds: (1) every exchanged tensor is
+    //  written exactly once per launch and FIRST read after the barrier that follows its producer, so a CU's vector L1 -- cold at kernel
+    //  start -- cannot hold a line of it from before that barrier; four workgroups' 32-byte slices sharing one 128-byte line does not
+    //  change this: the line is not in any reader's L1 until its first read, which is behind the barrier, when all four slices are in
+    //  the shared L2 (stores drained by s_waitcnt vmcnt(0) in front of the arrival); (2) no two exchanged tensors share a cache line:
+    //  each is its own allocation of the caching allocator (512-byte granularity); (3) the placement is not assumed: if the census
+    //  finds two XCC ids the fenced path below runs.)
     ++c.phase;
 }
 

@@ -246,7 +246,11 @@ class DETR(nn.Module):
         tgt = torch.zeros(R, E, dtype=F32, device=dev)
         hs32 = torch.empty(lay_n * R, E, dtype=F32, device=dev)
         scratch = torch.empty(R, E, dtype=torch.bfloat16, device=dev)               # the bf16 twin of a LayerNorm output nobody reads here
-        lin = lambda x, ldx, add, addc, w, b, y, ldy, M, N, K, act=0: lib.call("tuber_linear_f32", x, ldx, add, E if add is not None else 0, addc, w, K, b, y, ldy, M, N, K, act)
+        wsp = torch.empty(8 * R * max(E, 64), dtype=F32, device=dev)               # split-k partial tiles of the few-row linears (tuber_linear_f32_slabs <= 8)
+
+        def lin(x, ldx, add, addc, w, b, y, ldy, M, N, K, act=0):
+            S = lib.query("tuber_linear_f32_slabs", M, N, K)
+            lib.call("tuber_linear_f32", x, ldx, add, E if add is not None else 0, addc, w, K, b, y, ldy, M, N, K, act, wsp if S > 1 and S * M * N <= wsp.numel() else None)
 
         def norm(x32, res32, prefix, y=None, y32=None):
             out32 = torch.empty(R, E, dtype=F32, device=dev) if y32 is None else y32
@@ -430,7 +434,7 @@ class DETR(nn.Module):
         fp = lambda name: st.flat.data_ptr() + 4 * st.offsets[name]      # fp32 master parameter
         if self.dataset_mode == "ava" and f32dec:
             logits_b = torch.empty(lay_n * B * Q, 3, dtype=F32, device=dev)
-            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("class_embed_b.weight"), E, fp("class_embed_b.bias"), logits_b, 3, lay_n * B * Q, 3, E, 0)
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("class_embed_b.weight"), E, fp("class_embed_b.bias"), logits_b, 3, lay_n * B * Q, 3, E, 0, None)
             lb_shape = (lay_n, B, Q, 3)
         elif self.dataset_mode == "ava":
             logits_b = T.linear(tp, hs, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
@@ -443,9 +447,9 @@ class DETR(nn.Module):
         if f32dec:
             Rh = lay_n * B * Q
             x1, x2, boxes = (torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, 4, dtype=F32, device=dev))
-            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("bbox_embed.layers.0.weight"), E, fp("bbox_embed.layers.0.bias"), x1, E, Rh, E, E, 1)
-            lib.call("tuber_linear_f32", x1, E, None, 0, 0, fp("bbox_embed.layers.1.weight"), E, fp("bbox_embed.layers.1.bias"), x2, E, Rh, E, E, 1)
-            lib.call("tuber_linear_f32", x2, E, None, 0, 0, fp("bbox_embed.layers.2.weight"), E, fp("bbox_embed.layers.2.bias"), boxes, 4, Rh, 4, E, 2)
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("bbox_embed.layers.0.weight"), E, fp("bbox_embed.layers.0.bias"), x1, E, Rh, E, E, 1, None)
+            lib.call("tuber_linear_f32", x1, E, None, 0, 0, fp("bbox_embed.layers.1.weight"), E, fp("bbox_embed.layers.1.bias"), x2, E, Rh, E, E, 1, None)
+            lib.call("tuber_linear_f32", x2, E, None, 0, 0, fp("bbox_embed.layers.2.weight"), E, fp("bbox_embed.layers.2.bias"), boxes, 4, Rh, 4, E, 2, None)
         else:
             x = T.linear(tp, hs, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
             x = T.linear(tp, x, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
