@@ -37,7 +37,10 @@ def timed(fn, n=20):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
-for label, sw in (("eval precision mode (default)", ()), ("fp32 streams only (eval_bf16_decoder)", ("eval_bf16_decoder",)), ("bf16 streams (eval_bf16_stream)", ("eval_bf16_stream",))):
+MODES = (("eval precision mode (default)", ()), ("fp32 streams only (eval_bf16_decoder)", ("eval_bf16_decoder",)), ("bf16 streams (eval_bf16_stream)", ("eval_bf16_stream",)))
+if os.environ.get("EVAL_MODES"):                                    # e.g. EVAL_MODES=0 under rocprofv3: the default mode only
+    MODES = tuple(MODES[int(i)] for i in os.environ["EVAL_MODES"].split(","))
+for label, sw in MODES:
     with ab.override(*sw), torch.no_grad():
         eager = timed(lambda: model(clips))
         g = torch.cuda.CUDAGraph()

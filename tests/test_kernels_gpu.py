@@ -1465,3 +1465,59 @@ def test_conv1_bwd_fused(dev, M, join, with_r, with_dw):
     if with_dw:
         close("conv1 bwd fused dW1", slab.sum(0), dc1.float().t() @ X.float(), rel=2e-3)
         assert bool(torch.isfinite(slab).all())
+
+
+# ---- fp32 kernels of the eval precision mode (csrc/eval_f32.hip): fp32 matrix-pipe linears and the fp32 attention core against fp64 torch math;
+# tolerance 2e-5 of the output scale (fp32 accumulation order over K <= 2048) ----
+@pytest.mark.parametrize("M,N,K,add_cols,act", [(30, 768, 256, 512, 0), (30, 256, 256, 0, 0), (30, 256, 256, 256, 0), (30, 2048, 256, 0, 1), (30, 256, 2048, 0, 0),
+                                                (180, 3, 256, 0, 0), (180, 256, 256, 0, 1), (180, 4, 256, 0, 2), (704, 512, 256, 256, 0), (640, 768, 256, 512, 0),
+                                                (257, 100, 32, 0, 1), (1, 16, 64, 0, 0), (17, 33, 96, 0, 2)])
+def test_linear_f32(dev, M, N, K, add_cols, act):
+    x, add = rnd(M, K + 8, dev=dev, seed=1)[:, :K], rnd(M, K, dev=dev, seed=2)             # x with a leading dimension
+    W, b = rnd(N, K, dev=dev, seed=3, scale=K ** -0.5), rnd(N, dev=dev, seed=4)
+    y = torch.full((M, N + 4), 7.0, device=dev)                                            # y with a leading dimension: the pad must stay untouched
+    lib.call("tuber_linear_f32", x, K + 8, add if add_cols else None, K, add_cols, W, K, b, y, N + 4, M, N, K, act)
+    ref = x.double() @ W.double().t() + b.double()
+    if add_cols:
+        ref[:, :add_cols] += add.double() @ W[:add_cols].double().t()
+    ref = ref.relu() if act == 1 else ref.sigmoid() if act == 2 else ref
+    close("linear_f32 %dx%dx%d add %d act %d" % (M, N, K, add_cols, act), y[:, :N], ref.float(), rel=2e-5)
+    assert bool((y[:, N:] == 7.0).all())
+
+
+def test_linear_f32_batched_equals_single_launches(dev):
+    M, N, K, nb = 704, 512, 256, 6
+    x, add = rnd(M, K, dev=dev, seed=1), rnd(M, K, dev=dev, seed=2)
+    Wall, ball = rnd(nb, 3 * N // 2 + 4, K, dev=dev, seed=3, scale=K ** -0.5), rnd(nb, N + 12, dev=dev, seed=4)   # weight sets at a constant stride, like the flat parameter buffer
+    y = torch.empty(nb, M, N, device=dev)
+    lib.call("tuber_linear_f32_batched", x, K, add, K, 256, Wall, K, ball, y, N, M, N, K, 0, nb, Wall.stride(0), ball.stride(0), M * N)
+    for z in range(nb):
+        y1 = torch.empty(M, N, device=dev)
+        lib.call("tuber_linear_f32", x, K, add, K, 256, Wall[z], K, ball[z], y1, N, M, N, K, 0)
+        assert torch.equal(y[z], y1), z
+    ref = torch.cat([(x + add).double() @ Wall[0, :256].double().t(), x.double() @ Wall[0, 256:N].double().t()], 1) + ball[0, :N].double()
+    close("linear_f32_batched set 0", y[0], ref.float(), rel=2e-5)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,masked", [(2, 8, 15, 15, False), (2, 8, 15, 352, True), (2, 8, 15, 352, False), (1, 8, 320, 320, False), (2, 8, 40, 2160, True),
+                                              (3, 4, 1, 7, True), (1, 2, 33, 1300, False)])
+def test_attention_f32(dev, B, H, Lq, Lk, masked):
+    E = 32 * H
+    q, kv = rnd(B * Lq, E, dev=dev, seed=1), rnd(B * Lk, 2 * E, dev=dev, seed=2)
+    kpm = None
+    if masked:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        kpm = (torch.rand(B, Lk, generator=g) < 0.3)
+        kpm[:, 0] = False                                                                   # never a fully masked row (NaN in the reference too)
+        kpm = kpm.to(dev).to(torch.uint8)
+    o = torch.empty(B * Lq, E, device=dev)
+    scale = 32 ** -0.5
+    lib.call("tuber_attention_f32", q, E, kv, 2 * E, kv.data_ptr() + 4 * E, 2 * E, o, E, kpm, B, H, Lq, Lk, scale)
+    qd = q.double().view(B, Lq, H, 32).transpose(1, 2)
+    kd = kv[:, :E].double().view(B, Lk, H, 32).transpose(1, 2)
+    vd = kv[:, E:].double().view(B, Lk, H, 32).transpose(1, 2)
+    s = qd @ kd.transpose(-1, -2) * scale
+    if masked:
+        s = s.masked_fill(kpm.bool().view(B, 1, 1, Lk), float("-inf"))
+    ref = (s.softmax(-1) @ vd).transpose(1, 2).reshape(B * Lq, E)
+    close("attention_f32 B%d H%d Lq%d Lk%d" % (B, H, Lq, Lk), o, ref.float(), rel=2e-5)

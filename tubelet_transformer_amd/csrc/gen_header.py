@@ -58,7 +58,8 @@ DOC = {
     "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
                         "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
                         "MLP models/criterion.py:485-497) under model.eval().",
-    "tuber_linear_f32_slabs": "k slabs tuber_linear_f32 splits a few-row, long-K layer into (its workspace holds slabs * M * N floats); 1 = no split.",
+    "tuber_linear_f32_batched": "tuber_linear_f32 for nbatch weight sets over ONE input in one launch (set z: W + z * w_stride, bias + z * bias_stride, y + z * y_stride, strides in elements): "
+                                "the memory-side K / V projections of all decoder layers (models/transformer/transformer.py:232-237), which do not depend on the decoder state.",
     "tuber_attention_f32": "fp32 multi-head attention core (head dimension 32) of the eval precision mode: the decoder's self- and cross-attention "
                            "(nn.MultiheadAttention, transformer.py:218-240) with fp32 scores, softmax and values.",
     "tuber_flag_signal": "software ordering edge between two HIP streams, producer side: *flag += 1 (release, agent scope) once everything enqueued on the stream "

@@ -246,11 +246,25 @@ class DETR(nn.Module):
         tgt = torch.zeros(R, E, dtype=F32, device=dev)
         hs32 = torch.empty(lay_n * R, E, dtype=F32, device=dev)
         scratch = torch.empty(R, E, dtype=torch.bfloat16, device=dev)               # the bf16 twin of a LayerNorm output nobody reads here
-        wsp = torch.empty(8 * R * max(E, 64), dtype=F32, device=dev)               # split-k partial tiles of the few-row linears (tuber_linear_f32_slabs <= 8)
 
         def lin(x, ldx, add, addc, w, b, y, ldy, M, N, K, act=0):
-            S = lib.query("tuber_linear_f32_slabs", M, N, K)
-            lib.call("tuber_linear_f32", x, ldx, add, E if add is not None else 0, addc, w, K, b, y, ldy, M, N, K, act, wsp if S > 1 and S * M * N <= wsp.numel() else None)
+            lib.call("tuber_linear_f32", x, ldx, add, E if add is not None else 0, addc, w, K, b, y, ldy, M, N, K, act)
+
+        # the memory-side projections [(memory + pos) W_k | memory W_v] of ALL layers do not depend on the decoder state: one launch over the
+        # layers' weight sets (the parameters of consecutive layers sit at a constant stride in the flat buffer)
+        P0, P1 = "transformer.decoder.layers.0.multihead_attn", "transformer.decoder.layers.%d.multihead_attn" % min(1, lay_n - 1)
+        wz = st.offsets[P1 + ".in_proj_weight"] - st.offsets[P0 + ".in_proj_weight"]
+        bz = st.offsets[P1 + ".in_proj_bias"] - st.offsets[P0 + ".in_proj_bias"]
+        uniform = wz % 4 == 0 and all(st.offsets["transformer.decoder.layers.%d.multihead_attn.in_proj_weight" % i] == st.offsets[P0 + ".in_proj_weight"] + i * wz and
+                      st.offsets["transformer.decoder.layers.%d.multihead_attn.in_proj_bias" % i] == st.offsets[P0 + ".in_proj_bias"] + i * bz for i in range(lay_n))
+        kvs = torch.empty(lay_n, B * Lm, 2 * E, dtype=F32, device=dev)
+        if uniform:
+            lib.call("tuber_linear_f32_batched", mem32, E, pos32, E, E, fp(P0 + ".in_proj_weight") + 4 * E * E, E, fp(P0 + ".in_proj_bias") + 4 * E, kvs, 2 * E,
+                     B * Lm, 2 * E, E, 0, lay_n, wz, bz, B * Lm * 2 * E)
+        else:
+            for i in range(lay_n):
+                P = "transformer.decoder.layers.%d.multihead_attn" % i
+                lin(mem32, E, pos32, E, fp(P + ".in_proj_weight") + 4 * E * E, fp(P + ".in_proj_bias") + 4 * E, kvs[i], 2 * E, B * Lm, 2 * E, E)
 
         def norm(x32, res32, prefix, y=None, y32=None):
             out32 = torch.empty(R, E, dtype=F32, device=dev) if y32 is None else y32
@@ -268,8 +282,7 @@ class DETR(nn.Module):
             tgt = norm(ao, tgt, L + ".norm1")
             q = torch.empty(R, E, dtype=F32, device=dev)
             lin(tgt, E, qpos32, E, fp(P + ".in_proj_weight"), fp(P + ".in_proj_bias"), q, E, R, E, E)                      # (tgt + query_pos) W_q
-            kv = torch.empty(B * Lm, 2 * E, dtype=F32, device=dev)
-            lin(mem32, E, pos32, E, fp(P + ".in_proj_weight") + 4 * E * E, fp(P + ".in_proj_bias") + 4 * E, kv, 2 * E, B * Lm, 2 * E, E)      # [(memory + pos) W_k | memory W_v]
+            kv = kvs[i]
             lib.call("tuber_attention_f32", q, E, kv, 2 * E, kv.data_ptr() + 4 * E, 2 * E, a, E, kpm, B, H, Q, Lm, scale)
             lin(a, E, None, 0, fp(P + ".out_proj.weight"), fp(P + ".out_proj.bias"), ao, E, R, E, E)
             tgt = norm(ao, tgt, L + ".norm2")
@@ -434,7 +447,7 @@ class DETR(nn.Module):
         fp = lambda name: st.flat.data_ptr() + 4 * st.offsets[name]      # fp32 master parameter
         if self.dataset_mode == "ava" and f32dec:
             logits_b = torch.empty(lay_n * B * Q, 3, dtype=F32, device=dev)
-            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("class_embed_b.weight"), E, fp("class_embed_b.bias"), logits_b, 3, lay_n * B * Q, 3, E, 0, None)
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("class_embed_b.weight"), E, fp("class_embed_b.bias"), logits_b, 3, lay_n * B * Q, 3, E, 0)
             lb_shape = (lay_n, B, Q, 3)
         elif self.dataset_mode == "ava":
             logits_b = T.linear(tp, hs, "class_embed_b.weight", "class_embed_b.bias", out_f32=True)
@@ -447,9 +460,9 @@ class DETR(nn.Module):
         if f32dec:
             Rh = lay_n * B * Q
             x1, x2, boxes = (torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, E, dtype=F32, device=dev), torch.empty(Rh, 4, dtype=F32, device=dev))
-            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("bbox_embed.layers.0.weight"), E, fp("bbox_embed.layers.0.bias"), x1, E, Rh, E, E, 1, None)
-            lib.call("tuber_linear_f32", x1, E, None, 0, 0, fp("bbox_embed.layers.1.weight"), E, fp("bbox_embed.layers.1.bias"), x2, E, Rh, E, E, 1, None)
-            lib.call("tuber_linear_f32", x2, E, None, 0, 0, fp("bbox_embed.layers.2.weight"), E, fp("bbox_embed.layers.2.bias"), boxes, 4, Rh, 4, E, 2, None)
+            lib.call("tuber_linear_f32", hs32, E, None, 0, 0, fp("bbox_embed.layers.0.weight"), E, fp("bbox_embed.layers.0.bias"), x1, E, Rh, E, E, 1)
+            lib.call("tuber_linear_f32", x1, E, None, 0, 0, fp("bbox_embed.layers.1.weight"), E, fp("bbox_embed.layers.1.bias"), x2, E, Rh, E, E, 1)
+            lib.call("tuber_linear_f32", x2, E, None, 0, 0, fp("bbox_embed.layers.2.weight"), E, fp("bbox_embed.layers.2.bias"), boxes, 4, Rh, 4, E, 2)
         else:
             x = T.linear(tp, hs, "bbox_embed.layers.0.weight", "bbox_embed.layers.0.bias", relu=True)
             x = T.linear(tp, x, "bbox_embed.layers.1.weight", "bbox_embed.layers.1.bias", relu=True)
