@@ -118,6 +118,7 @@ class CSNRunner:
         bns = [m for m in body.modules() if isinstance(m, nn.BatchNorm3d)]
         self.scratch = torch.zeros(len(bns), 7, CMAX, dtype=torch.float32, device=dev)
         self._bn_index = {}
+        self._bn_rows = []
         self.blocks = []
         sp = self.scratch.data_ptr()
 
@@ -133,6 +134,7 @@ class CSNRunner:
             b.rmean, b.rvar, b.nbt = mod.running_mean.data_ptr(), mod.running_var.data_ptr(), mod.num_batches_tracked.data_ptr()
             base = sp + 4 * i * 7 * CMAX
             b.scale, b.shift, b.mean, b.invstd, b.cA, b.cB, b.cC = (base + 4 * k * CMAX for k in range(7))
+            self._bn_rows.append((i, b))
             return b
 
         def wptr(name):
@@ -167,6 +169,11 @@ class CSNRunner:
                     d["wdt"], d["lddt"] = tptr(p + "down_sample.0.weight")
                     d["bnd"] = mk_bn(p + "down_sample.1", blk.down_sample[1])
                 self.blocks.append(d)
+        # eval mode: the affine form of EVERY BatchNorm in one launch at the start of the forward (tuber_bn_eval_affine_multi)
+        rows = sorted(self._bn_rows, key=lambda r: r[0])
+        self._bn_table = torch.tensor([[b.gamma, b.beta, b.rmean, b.rvar, b.scale, b.shift, b.C, 0] for _, b in rows], dtype=torch.int64, device=dev)
+        self._bn_cmax = max(b.C for _, b in rows)
+        self._affine_ready = False
         self._ws = {}
         self._fa_max = lib.query("tuber_bn_bwd_fa_max_rows")
         # flat offset where the parameters after the CSN body begin (gradient all-reduce slicing, ddp.py)
@@ -197,7 +204,8 @@ class CSNRunner:
                  bn.scale, bn.shift, bn.mean, bn.invstd)
 
     def _bn_eval(self, bn):
-        lib.call("tuber_bn_eval_affine", bn.gamma, bn.beta, bn.rmean, bn.rvar, BN_EPS, bn.scale, bn.shift, bn.C)
+        if not self._affine_ready:          # a block range run on its own (tests); forward() has every layer's affine form from one launch
+            lib.call("tuber_bn_eval_affine", bn.gamma, bn.beta, bn.rmean, bn.rvar, BN_EPS, bn.scale, bn.shift, bn.C)
 
     def _gemm_stats(self, A, lda, Wb, ldb, C, M, N, K, amode, sc, sh, gather, bn, train, defer=False):
         """conv as GEMM; in training mode also the following BatchNorm's statistics (``defer``: return the statistics rows (st0, st1, R)
@@ -225,6 +233,9 @@ class CSNRunner:
         M0 = B * T * Ho * Wo
         # stem conv: implicit GEMM straight from the fp32 clip (no patch matrix in HBM), BN statistics fused
         lib.call("tuber_stem_pack_weight", self.stem_w32, self.stem_wpad)
+        if not train:
+            lib.call("tuber_bn_eval_affine_multi", self._bn_table, self._bn_table.shape[0], self._bn_cmax, BN_EPS)
+        self._affine_ready = not train
         c0 = torch.empty(M0, 64, dtype=BF, device=dev)
         bn0 = self.stem_bn
         if train:
@@ -240,7 +251,10 @@ class CSNRunner:
         arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
         lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
         saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": [], "lo": 0}
-        x, (Ti, Hi, Wi) = self._forward_blocks(x, B, (T, Hp, Wp), 0, len(self.blocks), train, saved["blocks"])
+        try:
+            x, (Ti, Hi, Wi) = self._forward_blocks(x, B, (T, Hp, Wp), 0, len(self.blocks), train, saved["blocks"])
+        finally:
+            self._affine_ready = False
         feat = x.view(B, Ti, Hi, Wi, 2048)
         return feat, saved
 

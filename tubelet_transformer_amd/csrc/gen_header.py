@@ -55,6 +55,9 @@ DOC = {
                                "stream kept in fp32 between the bottlenecks -- reads the previous block's fp32 output, writes the bf16 GEMM operand AND the fp32 stream.",
     "tuber_layernorm_fwd_f32": "tuber_layernorm_fwd for the eval precision mode: LayerNorm(x + res) (models/transformer/transformer.py:160-167,229-247, post-norm) with the "
                                "residual stream in fp32 from LayerNorm to LayerNorm; writes the bf16 GEMM operand and (optionally) the fp32 stream.",
+    "tuber_bn_eval_affine_multi": "tuber_bn_eval_affine (eval-mode nn.BatchNorm3d: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; "
+                                  "models/backbones/ir_CSN_152.py:46,56,64,154 under model.eval()) for every BatchNorm of the body in ONE launch over a device table of "
+                                  "{gamma, beta, running_mean, running_var, scale, shift, C, unused} rows.",
     "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
                         "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
                         "MLP models/criterion.py:485-497) under model.eval().",

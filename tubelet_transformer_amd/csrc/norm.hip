@@ -120,6 +120,18 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
+// the same for EVERY BatchNorm of a network in one launch (eval forward: 155 launches of the kernel above were 0.6 ms of a 5.5 ms forward):
+// blockIdx.y walks a device table of 8-word rows {gamma, beta, running_mean, running_var, scale, shift, C, unused}.
+struct BnAffineRow { const float* gamma; const float* beta; const float* rmean; const float* rvar; float* scale; float* shift; long C; long pad; };
+__global__ void bn_eval_affine_multi_kernel(const BnAffineRow* __restrict__ table, float eps) {
+    const BnAffineRow r = table[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= r.C) return;
+    const float sc = r.gamma[c] / sqrtf(r.rvar[c] + eps);
+    r.scale[c] = sc;
+    r.shift[c] = r.beta[c] - r.rmean[c] * sc;
+}
+
 // dL/dx = A*dz + B*x + C per channel;  dgamma = sum dz*xhat, dbeta = sum dz
 template <int NTH>
 __global__ __launch_bounds__(NTH) void bn_bwd_finalize_kernel(
@@ -799,6 +811,14 @@ int tuber_bn_eval_affine(const float* gamma, const float* beta, const float* run
                          float* scale, float* shift, int C, hipStream_t stream) {
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, gamma, beta, running_mean, running_var,
                        eps, scale, shift, C);
+    TUBER_RETURN_LAUNCH();
+}
+
+// tuber_bn_eval_affine for n BatchNorm layers in ONE launch.  table: n rows of 8 64-bit words in DEVICE memory -- the pointers gamma, beta,
+// running_mean, running_var, scale, shift, then the channel count and one unused word; cmax >= every row's channel count.
+int tuber_bn_eval_affine_multi(const void* table, int n, int cmax, float eps, hipStream_t stream) {
+    if (!table || n <= 0 || n > 65535 || cmax <= 0) return TUBER_EINVAL;
+    hipLaunchKernelGGL(bn_eval_affine_multi_kernel, dim3(ceil_div(cmax, 256), n), dim3(256), 0, stream, (const BnAffineRow*)table, eps);
     TUBER_RETURN_LAUNCH();
 }
 

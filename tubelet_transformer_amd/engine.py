@@ -313,9 +313,11 @@ class ParamStore:
         self.seed.fill_(int(seed))
 
     # -- per-step refresh --------------------------------------------------------------------
-    def refresh(self):
+    def refresh(self, backward=True):
+        """bf16 shadow of the fp32 masters; ``backward``: also the transposed copies the data-gradient GEMMs read (not needed by a forward nobody
+        differentiates)."""
         lib.call("tuber_cast_f32_bf16", self.flat, self.shadow, self.total)
-        if self.nmat:
+        if self.nmat and backward:
             lib.call("tuber_multi_transpose_bf16", self.shadow, self.tshadow, self.ttable, self.nmat, self.ttiles)
 
     # -- accessors ---------------------------------------------------------------------------

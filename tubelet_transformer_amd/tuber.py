@@ -354,7 +354,7 @@ class DETR(nn.Module):
         """the whole network on the tape (tape.py); returns (tape, (logits2d, logits_b2d, boxes2d), output shapes)."""
         st, runner = self.engine()
         dev = st.device
-        st.refresh()
+        st.refresh(backward=record)
         st.begin_step(self.training)
         tp = T.Tape(st, record)
         E, H = self.hidden_dim, 8
