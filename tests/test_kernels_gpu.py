@@ -1521,3 +1521,27 @@ def test_attention_f32(dev, B, H, Lq, Lk, masked):
         s = s.masked_fill(kpm.bool().view(B, 1, 1, Lk), float("-inf"))
     ref = (s.softmax(-1) @ vd).transpose(1, 2).reshape(B * Lq, E)
     close("attention_f32 B%d H%d Lq%d Lk%d" % (B, H, Lq, Lk), o, ref.float(), rel=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(5632, 1024, 256), (44032, 512, 128), (704, 2048, 512), (1000, 256, 64)])
+def test_gemm_nt_bn_out_eval_tail(dev, M, N, K):
+    """conv4 + eval-mode bn4 + residual join + ReLU in one GEMM (tuber_gemm_nt_bn_out) against fp32 math on the operands the kernel sees, and
+    against the two launches it replaces (tuber_gemm_nt amode 1 -> bf16 c4 -> tuber_block_out_fwd_f32)."""
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    W = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    sc, sh = rnd(K, dev=dev, seed=3).abs() + 0.5, rnd(K, dev=dev, seed=4) * 0.3
+    s4, h4 = rnd(N, dev=dev, seed=5).abs() + 0.5, rnd(N, dev=dev, seed=6) * 0.3
+    R32 = rnd(M, N, dev=dev, seed=7).abs()
+    y, y32 = torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, N, device=dev)
+    lib.call("tuber_gemm_nt_bn_out", A, K, sc, sh, W, K, s4, h4, R32, N, y, N, y32, N, M, N, K)
+    a = bfr((A.float() * sc + sh).relu())
+    ref = (bfr(a @ W.float().t()) * s4 + h4 + R32).relu()            # c4 passes through bf16 (in registers) like in the two-launch path
+    close("gemm_nt_bn_out y32 %dx%dx%d" % (M, N, K), y32, ref)
+    close("gemm_nt_bn_out y   %dx%dx%d" % (M, N, K), y, ref)
+    assert torch.equal(y, y32.to(BF))
+    # the two-launch path it replaces: bit-identical
+    c4, _, _ = gemm_nt(A, W, M, N, K, amode=1, sc=sc, sh=sh)
+    z, z32 = torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, N, device=dev)
+    x_bf = torch.zeros(M, N, device=dev, dtype=BF)
+    lib.call("tuber_block_out_fwd_f32", c4, s4, h4, x_bf, None, None, R32, z, z32, M, N)
+    assert torch.equal(y32, z32) and torch.equal(y, z)

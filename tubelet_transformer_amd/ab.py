@@ -32,6 +32,8 @@ KNOWN = {
     "eager_step": "train_tuber_detection without the captured hipGraph step",
     "eval_bf16_stream": "eval forward with the residual streams (block outputs, LayerNorm outputs) stored in bf16 like the training path, instead of the fp32 "
                         "streams of the eval precision mode (round 6; also TUBER_EVAL_PRECISION=bf16_stream)",
+    "no_eval_conv4_join": "eval precision mode with conv4 and the residual join of an identity block as two launches (tuber_gemm_nt + tuber_block_out_fwd_f32) "
+                          "instead of the join in the GEMM epilogue (tuber_gemm_nt_bn_out; bit-identical outputs)",
     "eval_bf16_decoder": "eval precision mode without the fp32 decoder / heads (csrc/eval_f32.hip): the decoder on the bf16 launch chain with fp32 LayerNorm streams only",
 }
 

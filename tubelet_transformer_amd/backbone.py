@@ -332,9 +332,19 @@ class CSNRunner:
                 self._bn_train(b3, st0, st1, R, Mout)
             else:
                 self._bn_eval(b3)
+            y = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
+            if precise and not d["ds"] and y32 is not None and not ab.on("no_eval_conv4_join"):
+                # eval precision mode, identity block: an eval-mode bn4 is a constant affine map, so conv4 + bn4 + the residual join + ReLU are ONE
+                # GEMM (tuber_gemm_nt_bn_out): c4 never reaches HBM, y leaves as the bf16 operand of the next block and as the fp32 stream
+                self._bn_eval(b4)
+                y32n = torch.empty(Mout, 4 * P, dtype=torch.float32, device=dev)
+                lib.call("tuber_gemm_nt_bn_out", c3, P, b3.scale, b3.shift, d["w4"], P, b4.scale, b4.shift, y32, 4 * P, y, 4 * P, y32n, 4 * P, Mout, 4 * P, P)
+                y32 = y32n
+                x = y
+                Ti, Hi, Wi = To, Hq, Wq
+                continue
             c4 = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
             self._gemm_stats(c3, P, d["w4"], P, c4, Mout, 4 * P, P, 1, b3.scale, b3.shift, None, b4, train)
-            y = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
             if d["ds"] and cd is None:
                 cd = torch.empty(Mout, 4 * P, dtype=BF, device=dev)
                 strided = st != 1 or ss != 1

@@ -57,13 +57,15 @@ __device__ __forceinline__ float dot32(const float (&a)[32], const float (&b)[32
 // attention above SMALL_L)
 
 // ---- tiny sequences (Lq, Lk <= 8: the class branch's attention over the 4 temporal slots, batch = layers x clips x h*w) ----
-// one thread per (batch, head, row); every row is a handful of 64-byte loads that the 4 sibling threads share in L1.
+// one thread per (batch, head, row); every row is a handful of 64-byte loads.  Thread order (round 6): head fastest, then the row, then the batch
+// entry -- eight neighbouring lanes read the eight heads of ONE token row (512 contiguous bytes) and the sibling rows of a (batch, head) unit
+// sit in the same wave (their K / V rows hit in L1); with the row fastest every lane's 64 bytes came from a different token row, h*w rows apart.
 #define SMALL_L 8
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)a.B * a.H * a.Lq) return;
-    const int qi = (int)(t % a.Lq); const long bh = t / a.Lq;
-    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    const int h = (int)(t % a.H), qi = (int)((t / a.H) % a.Lq), b = (int)(t / ((long)a.H * a.Lq));
+    const long li = ((long)b * a.H + h) * a.Lq + qi;      // position in the [B][H][Lq] statistics / dropout index space
     float q[32], o[32], s[SMALL_L];
     load_row32(a.Q + tok_row(a.mq, qi, b) * a.mq.ld + h * 32, q);
     float mx = -INFINITY;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a) {
             const float p = __expf(s[k] - mx);
             l += p;
             float pv = p;
-            if (a.pdrop > 0.f) pv = dropout_keep(seed, (uint64_t)t * a.Lk + k, a.thresh) ? p * inv_keep : 0.f;
+            if (a.pdrop > 0.f) pv = dropout_keep(seed, (uint64_t)li * a.Lk + k, a.thresh) ? p * inv_keep : 0.f;
             float vv[32];
             load_row32(a.V + tok_row(a.mv, k, b) * a.mv.ld + h * 32, vv);
 #pragma unroll
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 32; ++d) o[d] *= inv;
     store_row32(a.O + tok_row(a.mo, qi, b) * a.mo.ld + h * 32, o);
-    if (a.lse) a.lse[t] = mx + __logf(l);
+    if (a.lse) a.lse[li] = mx + __logf(l);
 }
 
 // thread i of a (batch, head): dQ of query i (i < Lq) and dK, dV of key i (i < Lk); delta recomputed locally
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a) {
     const int Lm = max(a.Lq, a.Lk);
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)a.B * a.H * Lm) return;
-    const int i = (int)(t % Lm); const long bh = t / Lm;
-    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    const int h = (int)(t % a.H), i = (int)((t / a.H) % Lm), b = (int)(t / ((long)a.H * Lm));      // head fastest (see attn_small_fwd_kernel)
+    const long bh = (long)b * a.H + h;
     const float inv_keep = dropout_inv_keep(a.pdrop);
     const uint64_t seed = a.pdrop > 0.f ? eff_seed(a.seed_ptr, a.salt) : 0ull;
     if (i < a.Lq) {

@@ -28,7 +28,11 @@ enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5, EPI_EVAL = 6 };
+// EPI_EVAL (round 6, eval forward only): conv4 + the EVAL-mode bn4 + the residual join + ReLU in the GEMM epilogue --
+// y = relu(acc * m_scale[n] + m_shift[n] + R32[m][n]) written as the bf16 GEMM operand of the next block AND as the fp32 residual stream (C32);
+// an eval-mode BatchNorm is a constant affine map, so unlike in training nothing has to wait for the conv output's statistics: c4 never reaches HBM (it is still rounded to bf16 in
+// registers, so y / C32 are bit-identical to tuber_gemm_nt + tuber_block_out_fwd_f32: the eval precision mode's validated rounding points stay as they are).
 #define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS)
 // EPI_JOIN_DS: EPI_JOIN below a stage's FIRST block: a second statistics operand Dm (the raw output of its projection shortcut) and a third
 // row sum dz*Dm (stat2) for the shortcut BatchNorm's backward -- what tuber_block_out_bwd writes for such a block
@@ -54,6 +58,7 @@ struct GemmNT {
     const bf16* Dm; long lddm; float* stat2;      // EPI_JOIN_DS
                                                   // EPI_JOIN_SR: R holds one row per STRIDED sample (n, t/st, h/ss, w/ss) of the M = n*Ti*Hi*Wi output
                                                   // rows (To..ss above): the data gradient of a stage's strided projection shortcut, added where it belongs
+    const float* R32; long ldr32; float* C32; long ldc32;   // EPI_EVAL: fp32 residual stream in / out (m_scale / m_shift: the BatchNorm affine of the output columns)
     float alpha;                                  // accumulators are scaled by alpha before the epilogue
     uint32_t drop_thresh; float drop_inv_keep; const uint64_t* seed_ptr; uint64_t salt;   // EPI_PLAIN: Dropout after bias/residual/ReLU
 };
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; if (EPI == EPI_JOIN_DS) s2[EPI == EPI_JOIN_DS ? c : 0] = 0.f; }
     }
     float msc[NC], msh[NC];
-    if (EPI == EPI_BWD) {
+    if (EPI == EPI_BWD || EPI == EPI_EVAL) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool ok = FULL || nb + c < p.N;
@@ -449,6 +454,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                 dropout_keep_run<NC>(seed, (uint64_t)m * p.N + nb, p.drop_thresh, keep);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) v[c] = keep[c] ? v[c] * p.drop_inv_keep : 0.f;
+            }
+        } else if (EPI == EPI_EVAL) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = fmaf(bf2f(f2bf(v[c])), msc[c], msh[c]);      // c4 passes through bf16 as in the two-launch path: bit-identical outputs
+            if (mok) {
+                const float* r32 = p.R32 + (long)m * p.ldr32 + nb;
+                float* o32 = p.C32 + (long)m * p.ldc32 + nb;
+#pragma unroll
+                for (int c4 = 0; c4 < NC / 4; ++c4) {
+                    const float4 r = *(const float4*)(r32 + c4 * 4);
+                    float4 o;
+                    o.x = v[c4 * 4] = fmaxf(v[c4 * 4] + r.x, 0.f);
+                    o.y = v[c4 * 4 + 1] = fmaxf(v[c4 * 4 + 1] + r.y, 0.f);
+                    o.z = v[c4 * 4 + 2] = fmaxf(v[c4 * 4 + 2] + r.z, 0.f);
+                    o.w = v[c4 * 4 + 3] = fmaxf(v[c4 * 4 + 3] + r.w, 0.f);
+                    *(float4*)(o32 + c4 * 4) = o;
+                }
             }
         } else if (EPI == EPI_STATS) {
             if (mok) {                                   // rows beyond M hold a copy of row M-1
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
     }
-    if (EPI != EPI_PLAIN && p.stat0) {
+    if (EPI != EPI_PLAIN && EPI != EPI_EVAL && p.stat0) {
         // one partial row per workgroup tile: reduce the 16 lanes sharing g, then the WM waves via LDS
         constexpr int NS = EPI == EPI_JOIN_DS ? 3 : 2;
         __syncthreads();
@@ -589,6 +611,7 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, AM, EP, OCC>), grid, block, lds, s, p);                \
     } while (0)
     if (amode == A_PLAIN) {
+        if (epi == EPI_EVAL) return TUBER_EINVAL;        // the eval output epilogue comes with the BatchNorm + ReLU operand prologue only (conv4)
         if (epi == EPI_PLAIN) LNT(A_PLAIN, EPI_PLAIN);
         else if (epi == EPI_STATS) LNT(A_PLAIN, EPI_STATS);
         else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
@@ -600,6 +623,10 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
             if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
             else if (IS_JOIN(epi)) return TUBER_EINVAL;
+            else if (epi == EPI_EVAL) {
+                if (!full) return TUBER_EINVAL;
+                hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_BN_RELU, EPI_EVAL, OCC, 0, true>), grid, block, lds, s, p);
+            }
             else LNT(A_BN_RELU, EPI_BWD);
         } else if (amode == A_ADD) {
             if (epi != EPI_PLAIN) return TUBER_EINVAL;
@@ -736,7 +763,29 @@ int tuber_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, lon
     p.bias = bias; p.R = (const bf16*)R; p.ldr = ldr; p.relu = relu; p.out_f32 = out_f32;
     p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.m_scale = m_scale; p.m_shift = m_shift;
     p.Ym = nullptr; p.ldym = 0; p.add_ncols = 0;
+    p.Dm = nullptr; p.lddm = 0; p.stat2 = nullptr; p.R32 = nullptr; p.ldr32 = 0; p.C32 = nullptr; p.ldc32 = 0;
     return nt_dispatch(p, amode, epi, stream);
+}
+
+// EVAL forward of a bottleneck's tail in ONE launch: conv4 on relu(bn3(c3)) + bn4 + the residual join + ReLU
+//   y[M,N] = relu((relu(A * a_scale + a_shift) . B^T) * out_scale[n] + out_shift[n] + R32[m][n])
+// written twice: as bf16 (y: the GEMM operand of the next bottleneck) and as fp32 (y32: the residual stream of the eval precision mode).
+// Under model.eval() a BatchNorm is a constant affine map (tuber_bn_eval_affine), so -- unlike in training, where bn4 needs the statistics
+// of the whole conv output first -- the join can ride in the GEMM epilogue and c4 never exists in HBM; bit-identical to tuber_gemm_nt(amode 1) +
+// tuber_block_out_fwd_f32 of an identity block (ir_CSN_152.py:62-64,84-90).  N % 128 == 0 (64 for few rows), 16-byte addressable rows.
+int tuber_gemm_nt_bn_out(const void* A, long lda, const float* a_scale, const float* a_shift, const void* B, long ldb,
+                         const float* out_scale, const float* out_shift, const float* R32, long ldr32, void* y, long ldy, float* y32, long ldy32,
+                         int M, int N, int K, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || (ldy & 7) || (ldr32 & 3) || (ldy32 & 3) || (N & 63) ||
+        !a_scale || !a_shift || !out_scale || !out_shift || !R32 || !y || !y32)
+        return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = y; p.ldc = ldy;
+    p.M = M; p.N = N; p.K = K; p.a_scale = a_scale; p.a_shift = a_shift;
+    p.m_scale = out_scale; p.m_shift = out_shift; p.R32 = R32; p.ldr32 = ldr32; p.C32 = y32; p.ldc32 = ldy32;
+    return nt_dispatch(p, A_BN_RELU, EPI_EVAL, stream);
 }
 
 // Packed attention in-projection with the positional embedding folded in (nn.MultiheadAttention's in_proj on with_pos_embed(x, pos),

@@ -58,6 +58,10 @@ DOC = {
     "tuber_bn_eval_affine_multi": "tuber_bn_eval_affine (eval-mode nn.BatchNorm3d: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; "
                                   "models/backbones/ir_CSN_152.py:46,56,64,154 under model.eval()) for every BatchNorm of the body in ONE launch over a device table of "
                                   "{gamma, beta, running_mean, running_var, scale, shift, C, unused} rows.",
+    "tuber_gemm_nt_bn_out": "EVAL forward of a bottleneck's tail in ONE launch: conv4 on relu(bn3(c3)) + the eval-mode bn4 + the residual join + ReLU in the GEMM epilogue "
+                            "(models/backbones/ir_CSN_152.py:62-64,84-90 under model.eval(): a BatchNorm is a constant affine map there, so the join does not wait for "
+                            "statistics). Writes y as bf16 (next block's GEMM operand) and as fp32 (the residual stream of the eval precision mode); c4 never reaches HBM. "
+                            "Replaces tuber_gemm_nt(amode 1) + tuber_block_out_fwd_f32 for identity blocks.",
     "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
                         "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
                         "MLP models/criterion.py:485-497) under model.eval().",
