@@ -590,7 +590,7 @@ def main():
         "config": {"workload": "%s train step, %d clips/GPU of 3x32x%dx%d, dropout on, random-init name-hashed weights%s"
                                % (args.config.replace(".yaml", ""), args.batch, hw[0], hw[1],
                                   ", stem+layer1+layer2 frozen (pretrained recipe)" if args.pretrained_freeze else ""),
-                   "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce on an own communicator + stream, under the layer2/1/stem backward)" % world if world > 1 else "dp1", "launch_mode": mode,
+                   "global_batch": args.batch * world, "parallelism": "dp%d (flat-gradient RCCL all-reduce on an own communicator + stream; three issue points: behind layer4's, layer3's and the stem's backward)" % world if world > 1 else "dp1", "launch_mode": mode,
                    "lib_md5": lib_md5()},
         "final_loss": round(float(loss.detach()), 4) if loss is not None else None,
         "alg_gflop_per_clip_fwd_bwd": alg_gflop,
