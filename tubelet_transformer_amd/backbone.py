@@ -236,25 +236,25 @@ class CSNRunner:
         if not train:
             lib.call("tuber_bn_eval_affine_multi", self._bn_table, self._bn_table.shape[0], self._bn_cmax, BN_EPS)
         self._affine_ready = not train
-        c0 = torch.empty(M0, 64, dtype=BF, device=dev)
-        bn0 = self.stem_bn
-        if train:
-            R = lib.query("tuber_stem_conv_blocks", B, T, H, W)
-            st0, st1 = self.ws("st0", R * 64), self.ws("st1", R * 64)
-            lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, st0, st1, B, T, H, W)
-            self._bn_train(bn0, st0, st1, R, M0)
-        else:
-            lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, None, None, B, T, H, W)
-            self._bn_eval(bn0)
-        Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
-        x = torch.empty(B * T * Hp * Wp, 64, dtype=BF, device=dev)
-        arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
-        lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
-        saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": [], "lo": 0}
         try:
+            c0 = torch.empty(M0, 64, dtype=BF, device=dev)
+            bn0 = self.stem_bn
+            if train:
+                R = lib.query("tuber_stem_conv_blocks", B, T, H, W)
+                st0, st1 = self.ws("st0", R * 64), self.ws("st1", R * 64)
+                lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, st0, st1, B, T, H, W)
+                self._bn_train(bn0, st0, st1, R, M0)
+            else:
+                lib.call("tuber_stem_conv_fwd", clips, self.stem_wpad, c0, None, None, B, T, H, W)
+                self._bn_eval(bn0)
+            Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+            x = torch.empty(B * T * Hp * Wp, 64, dtype=BF, device=dev)
+            arg = torch.empty(B * T * Hp * Wp, 64, dtype=torch.uint8, device=dev) if train else None
+            lib.call("tuber_stem_pool_fwd", c0, self.stem_bn.scale, self.stem_bn.shift, x, arg, B * T, Ho, Wo, Hp, Wp)
+            saved = {"stem": (clips if train else None, None, c0, arg, (B, T, Ho, Wo, Hp, Wp)), "blocks": [], "lo": 0}
             x, (Ti, Hi, Wi) = self._forward_blocks(x, B, (T, Hp, Wp), 0, len(self.blocks), train, saved["blocks"])
         finally:
-            self._affine_ready = False
+            self._affine_ready = False          # a block range run on its own afterwards (run_blocks) derives its own
         feat = x.view(B, Ti, Hi, Wi, 2048)
         return feat, saved
 
