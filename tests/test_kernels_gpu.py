@@ -1545,3 +1545,45 @@ def test_gemm_nt_bn_out_eval_tail(dev, M, N, K):
     x_bf = torch.zeros(M, N, device=dev, dtype=BF)
     lib.call("tuber_block_out_fwd_f32", c4, s4, h4, x_bf, None, None, R32, z, z32, M, N)
     assert torch.equal(y32, z32) and torch.equal(y, z)
+
+
+@pytest.mark.parametrize("M,N,K", [(44032, 128, 512), (16896, 256, 2048), (16896, 2048, 256), (8200, 64, 128), (348160, 64, 256)])
+def test_gemm_nt_96_row_tiles(dev, M, N, K):
+    """round 6: plain-A GEMMs with >= 8 192 rows run on 96 x 64 tiles of the regular pipeline (gemm.hip: nt_use_96).  Against the round-5 tile choice
+    (hook tuber_gemm_nt_96_set(0)): outputs BIT-identical (same k order) for the plain (+bias, residual, ReLU), statistics and masked-backward
+    epilogues; the statistics rows are per 96 output rows with the unused rows of the [ceil(M / 64)][N] buffer written as zero, so their column sums
+    agree to fp32 summation order; and against fp32 math."""
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3)
+    R = rnd(M, N, dev=dev, seed=4).to(BF)
+    Cm = rnd(M, N, dev=dev, seed=7).to(BF)
+    msc, msh = rnd(N, dev=dev, seed=8).abs() + 0.5, rnd(N, dev=dev, seed=9)
+    rows = lib.query("tuber_gemm_nt_stat_rows", M, N)
+
+    def run_all():
+        out = {"plain": gemm_nt(A, B, M, N, K, bias=bias, R=R, relu=1)[0]}
+        for name, kw in (("stats", dict(epi=1)), ("bwd", dict(epi=2, Cm=Cm, msc=msc, msh=msh))):
+            C = torch.empty(M, N, device=dev, dtype=BF)
+            st0, st1 = torch.full((rows, N), 7.0, device=dev), torch.full((rows, N), 7.0, device=dev)      # poisoned: every row must be written
+            lib.call("tuber_gemm_nt", A, K, B, K, C, N, M, N, K, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, kw["epi"], None, None, N, 0, 0, st0, st1,
+                     kw.get("Cm"), N, kw.get("msc"), kw.get("msh"), 1.0, 0.0, None, 0, None, 0, None)
+            out[name] = (C, st0, st1)
+        return out
+    got = run_all()
+    lib.query("tuber_gemm_nt_96_set", 0)
+    try:
+        base = run_all()
+    finally:
+        lib.query("tuber_gemm_nt_96_set", 1)
+    ref = A.float() @ B.float().t()
+    close("96-row plain vs fp32", got["plain"], (ref + bias + R.float()).relu())
+    assert torch.equal(got["plain"], base["plain"])
+    for name in ("stats", "bwd"):
+        assert torch.equal(got[name][0], base[name][0]), name
+        for k in (1, 2):
+            g, b = got[name][k].double().sum(0), base[name][k].double().sum(0)
+            close("96-row %s rows, column sums %d" % (name, k), g.float(), b.float(), rel=2e-4)
+        tiles96 = (M + 95) // 96
+        assert bool((got[name][1][tiles96:] == 0).all()) and bool((got[name][2][tiles96:] == 0).all()), "rows beyond ceil(M / 96) are zero"
+    close("96-row stats sum vs fp32", got["stats"][1].sum(0), ref.sum(0), abs_=2e-3 * float(ref.abs().sum(0).max()))

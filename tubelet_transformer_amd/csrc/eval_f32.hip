@@ -275,8 +275,11 @@ int tuber_attention_f32(const float* q, long ldq, const float* k, long ldk, cons
     const int QCAP = Lq > 16 && lds_bytes(32) <= 160 * 1024 ? 32 : 16;
     const size_t lds = lds_bytes(QCAP);
     if (lds > 160 * 1024) return TUBER_EINVAL;                      // Lk > ~2 250 keys: not a shape of this model
-    const void* fn = QCAP == 32 ? (const void*)attention_f32_kernel<32> : (const void*)attention_f32_kernel<16>;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TUBER_EINVAL;
+    if (lds > 48 * 1024) {                                          // one-time opt-in per kernel and device (the library's pattern: common.h)
+        static LdsOptIn opt[2];
+        if (QCAP == 32) TUBER_LDS_OPT_IN(opt[1], attention_f32_kernel<32>, 160 * 1024);
+        else TUBER_LDS_OPT_IN(opt[0], attention_f32_kernel<16>, 160 * 1024);
+    }
     const dim3 grid(B * H * ceil_div(Lq, QCAP));
     if (QCAP == 32)
         hipLaunchKernelGGL(attention_f32_kernel<32>, grid, dim3(256), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, (const uint8_t*)kpm, H, Lq, Lk, scale);

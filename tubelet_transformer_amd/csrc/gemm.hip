@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             p.stat0[(long)tile_m * p.N + n0 + tid] = a;
             p.stat1[(long)tile_m * p.N + n0 + tid] = b;
             if constexpr (EPI == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
-            if constexpr (WSK && BM == 96) {
+            if constexpr (BM == 96) {
                 // the consumers read tuber_gemm_nt_stat_rows(M, N) = ceil(M / 64) rows: the rows this tiling does not produce are zero
                 const int tiles_m = (p.M + BM - 1) / BM, rows64 = (p.M + 63) / 64;
                 for (int r = tiles_m + tile_m; r < rows64; r += tiles_m) { p.stat0[(long)r * p.N + n0 + tid] = 0.f; p.stat1[(long)r * p.N + n0 + tid] = 0.f; }
@@ -681,6 +681,27 @@ static int launch_nt_wsk(const GemmNT& p, int epi, hipStream_t s) {
 #undef LWSK
     TUBER_RETURN_LAUNCH();
 }
+// 96-row tiles on the REGULAR pipeline (round 6): every plain-A shape with many rows.  `scripts/gemm_bench.py nt 0,7,13,23` on the model's shapes with
+// M >= 16 896 (profiles/r06_gemm_nt_96_row_tiles.txt): 96 x 64 is at or ahead of the 64 x 64 / 64 x 128 / 128 x 128 choice on every one -- the class branch's
+// 16 896-row GEMMs by 5 - 18 % (2048 x 512: 60.2 -> 57.4 us against 128 x 128, 256 x 2048: 35.8 -> 29.2 against 64 x 64, 2048 x 256: 35.7 -> 31.7 against 64 x 128),
+// layer2's conv1 forward / conv4 data gradient (44 032 x 128 x 512: 1 376 tiles of 64 rows = a full round of the chip at four per CU and a third of one; 918 at 96 rows)
+// by 1 - 5 %.  40 KB of LDS per workgroup: four per CU fill the 160 KB exactly; 115 - 128 VGPRs, no scratch.  Outputs bit-identical (same k order), statistics rows per
+// 96 rows (the unused rows of the 64-row layout are written as zero, as the wave-split-K form does).  The layer3 / layer4 long-K shapes (M = 5 632 / 2 816) stay on the
+// wave-split-K 96-row form: the regular 96 x 64 kernel wins their isolated microbenchmark (9.1 vs 10.2 us) and LOSES in the step (13.80 vs 13.62 ms, three pairs).
+static int g_nt_96 = 1;           // EXPERIMENT hook: 0 = the round-5 tile choice (tuber_gemm_nt_96_set)
+static bool nt_use_96(const GemmNT& p, int amode, int epi) {
+    return g_nt_96 && amode == A_PLAIN && !p.gather && p.M >= 8192 && nt_full(p, 64) && (epi == EPI_PLAIN || epi == EPI_STATS || epi == EPI_BWD);
+}
+static int launch_nt_96(const GemmNT& p, int epi, hipStream_t s) {
+    dim3 grid(ceil_div(p.M, 96) * ceil_div(p.N, 64)), block(256);
+    constexpr size_t lds = 2 * (96 + 64) * 128;
+#define L96(EP) hipLaunchKernelGGL((gemm_nt_kernel<96, 64, 2, 2, 2, A_PLAIN, EP, 4, 0, true>), grid, block, lds, s, p)
+    if (epi == EPI_PLAIN) L96(EPI_PLAIN);
+    else if (epi == EPI_STATS) L96(EPI_STATS);
+    else L96(EPI_BWD);
+#undef L96
+    TUBER_RETURN_LAUNCH();
+}
 // shapes that take it: plain A, no row gather, at least `min_kt` k-tiles, and few enough 64x64 tiles that they are all resident at once
 static bool nt_use_wsk(const GemmNT& p, int amode) {
     constexpr int min_kt = 16;
@@ -721,6 +742,7 @@ extern "C" {
 int tuber_gemm_nt_cfg(int M, int N, int K) { return nt_pick_cfg(M, N, K); }
 
 int tuber_gemm_nt_wsk96_set(int on) { g_nt_wsk96 = on; return 0; }
+int tuber_gemm_nt_96_set(int on) { g_nt_96 = on; return 0; }
 // rows per tile of the wave-split-K form tuber_gemm_nt takes for a plain-A (M, N, K) with a 16-byte addressable output: 0 = not taken, 64 or 96
 int tuber_gemm_nt_wsk_tile_rows(int M, int N, int K) {
     GemmNT p{};
@@ -865,6 +887,8 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
     const int M = p.M, N = p.N, K = p.K;
     int cfg = nt_pick_cfg(M, N, K);
     if (nt_force_cfg() < 0 && cfg == 13 && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
+    if ((nt_force_cfg() < 0 && nt_use_96(p, amode, epi)) || (nt_force_cfg() == 23 && amode == A_PLAIN && nt_full(p, 64) && (epi == EPI_PLAIN || epi == EPI_STATS || epi == EPI_BWD))) return launch_nt_96(p, epi, stream);
+    if (nt_force_cfg() == 23) cfg = 13;
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
     if (epi == EPI_JOIN_DS && cfg == 7 && nt_force_cfg() < 0) cfg = 13;   // three side operands spill the 64x128 tile (21 registers at 3 workgroups / CU)
     switch (cfg) {
@@ -887,9 +911,9 @@ static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) 
 // 1 when tuber_gemm_nt_set_cfg(cfg) names a tile configuration this library was built with
 int tuber_gemm_nt_has_cfg(int cfg) {
 #ifdef TUBER_AB_VARIANTS
-    return cfg == 0 || cfg == 7 || cfg == 13 || cfg == 12 || cfg == 17 || cfg == 2 || cfg == 21 || cfg == 22;
+    return cfg == 23 || cfg == 0 || cfg == 7 || cfg == 13 || cfg == 12 || cfg == 17 || cfg == 2 || cfg == 21 || cfg == 22;
 #else
-    return cfg == 0 || cfg == 7 || cfg == 13;
+    return cfg == 0 || cfg == 7 || cfg == 13 || cfg == 23;
 #endif
 }
 

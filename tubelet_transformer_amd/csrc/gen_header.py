@@ -95,6 +95,7 @@ DOC = {
                            "Transpose-read kernel shapes only (N, K, ld multiples of 8, 64x64 tiles); several slabs need accumulate = 2 (the caller reduces them).",
     "tuber_gemm_nt_wsk_tile_rows": "rows per tile of the wave-split-K form tuber_gemm_nt takes for a plain-A (M, N, K): 0 (not taken), 64, or 96 (shapes whose "
                                    "64-row tiling has more workgroups than the chip has CUs while the 96-row one does not: the layer3 / layer4 long-K convs).",
+    "tuber_gemm_nt_96_set": "EXPERIMENT hook (round 6): 0 switches the 96-row tiles of the regular tuber_gemm_nt pipeline off (64-row tiles for layer2's conv1 forward / conv4 data gradient).",
     "tuber_gemm_nt_wsk96_set": "EXPERIMENT hook: 0 switches the 96-row wave-split-K tiles of tuber_gemm_nt off (64-row tiles everywhere).",
     "tuber_gemm_tn_args_bytes": "sizeof(struct TuberGemmTNArgs) as compiled (host-side layout check).",
     "tuber_gemm_tn_group_max": "largest n tuber_gemm_tn_group accepts (the argument blocks travel by value in the kernel argument segment).",

@@ -61,6 +61,8 @@ def load():
     _lib, _sigs = lib, sigs
     if os.environ.get("TUBER_NT_WSK96"):             # measurement hook (DESIGN.md "Switches"): "0" = 64-row wave-split-K tiles everywhere
         lib.tuber_gemm_nt_wsk96_set(int(os.environ["TUBER_NT_WSK96"]))
+    if os.environ.get("TUBER_NT_96"):                # measurement hook (round 6): "0" = 64-row tiles for the shapes that take 96-row tiles on the regular pipeline
+        lib.tuber_gemm_nt_96_set(int(os.environ["TUBER_NT_96"]))
     return lib
 
 
