@@ -1,3 +1,5 @@
+"""round 6: tuber_gemm_nt on 96 x 64 tiles (plain-A shapes with >= 8 192 rows; gemm.hip: nt_use_96) against the round-5 tile choice (hook tuber_gemm_nt_96_set(0)):
+outputs must be bit-identical, statistics column sums equal to fp32 summation order.  usage: python scripts/nt96_check.py"""
 import torch, sys
 sys.path.insert(0, ".")
 from tubelet_transformer_amd import lib
