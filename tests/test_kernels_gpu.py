@@ -1599,3 +1599,39 @@ def test_gemm_nt_96_row_tiles(dev, M, N, K):
         tiles96 = (M + 95) // 96
         assert bool((got[name][1][tiles96:] == 0).all()) and bool((got[name][2][tiles96:] == 0).all()), "rows beyond ceil(M / 96) are zero"
     close("96-row stats sum vs fp32", got["stats"][1].sum(0), ref.sum(0), abs_=2e-3 * float(ref.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(5632, 1024, 256), (44032, 512, 128), (2816, 2048, 512), (1000, 256, 64)])
+def test_join_backward_reads_the_relu_mask_as_a_bit_field(dev, M, N, K):
+    """round 6: tuber_block_out_fwd_mask writes y AND the bit field [y > 0] ([M][N / 8] bytes); tuber_gemm_nt_join_mask reads the bits where
+    tuber_gemm_nt_join reads y.  Both pairs must be bit-identical: y, dz and both statistics rows."""
+    c4 = rnd(M, N, dev=dev, seed=1).to(BF)
+    res = rnd(M, N, dev=dev, seed=2).to(BF)
+    s4, h4 = rnd(N, dev=dev, seed=3).abs() + 0.5, rnd(N, dev=dev, seed=4) * 0.3
+    y0, y1 = torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, N, device=dev, dtype=BF)
+    ymask = torch.full((M, N // 8), 0xAA, device=dev, dtype=torch.uint8)
+    lib.call("tuber_block_out_fwd", c4, s4, h4, res, None, None, y0, M, N)
+    lib.call("tuber_block_out_fwd_mask", c4, s4, h4, res, None, None, y1, ymask, M, N)
+    assert torch.equal(y0, y1)
+    bits = ((ymask.view(M, N // 8, 1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).view(M, N).bool()
+    assert torch.equal(bits, y0.float() > 0)
+    frac = float(bits.float().mean())
+    assert 0.2 < frac < 0.8, frac                                       # a mask that masks
+    # the join backward on top: dz = (A . B^T + R) * [y > 0], statistics rows sum dz, sum dz * c4
+    A = rnd(M, K, dev=dev, seed=5).to(BF)
+    W = rnd(N, K, dev=dev, seed=6, scale=K ** -0.5).to(BF)
+    R = rnd(M, N, dev=dev, seed=7).to(BF)
+    rows = lib.query("tuber_gemm_nt_stat_rows", M, N)
+    outs = []
+    for masked in (False, True):
+        dz = torch.empty(M, N, device=dev, dtype=BF)
+        b0, b1 = torch.full((rows, N), 7.0, device=dev), torch.full((rows, N), 7.0, device=dev)
+        if masked:
+            lib.call("tuber_gemm_nt_join_mask", A, K, W, K, dz, N, M, N, K, R, N, ymask, c4, N, b0, b1)
+        else:
+            lib.call("tuber_gemm_nt_join", A, K, W, K, dz, N, M, N, K, R, N, y0, N, c4, N, b0, b1)
+        outs.append((dz, b0, b1))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    ref = (A.float() @ W.float().t() + R.float()) * (y0.float() > 0)
+    close("join with bit mask vs fp32", outs[1][0], ref)

@@ -283,7 +283,7 @@ class CSNRunner:
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             To, Hq, Wq = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
-            cd = None
+            cd = ymask = None
             if pre_c1 is not None:
                 c1, pre_c1 = pre_c1, None
             elif (not ab.on("no_entry_conv") and d["ds"] and st == 1 and ss == 1 and lib.query("tuber_entry_conv_supported", cin, P, 4 * P) == 1):
@@ -379,10 +379,16 @@ class CSNRunner:
                     pend = bn1_stats(nxt, n0, n1, Rn, Mout)
                 else:
                     self._bn_eval(nxt["bn1"])
+            elif train and not d["ds"] and not ab.on("no_join_mask"):
+                # identity block in training: the ReLU mask of y also leaves as a bit field -- what this block's join backward (inside the conv1
+                # data-gradient GEMM of the block above, tuber_gemm_nt_join_mask) reads instead of y: 1 / 16 of the bytes of a side operand of a
+                # launch that runs at the bandwidth of its side operands
+                ymask = torch.empty(Mout, P // 2, dtype=torch.uint8, device=dev)
+                lib.call("tuber_block_out_fwd_mask", c4, b4.scale, b4.shift, res, rs, rh, y, ymask, Mout, 4 * P)
             else:
                 lib.call("tuber_block_out_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, Mout, 4 * P)
             if train:
-                out_saved.append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq)))
+                out_saved.append((x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq), ymask))
             x = y
             Ti, Hi, Wi = To, Hq, Wq
         return x, (Ti, Hi, Wi)
@@ -499,7 +505,7 @@ class CSNRunner:
         wq = self.store.wq
         for bi in range(top - 1, lowest - 1, -1):
             d, sv, f = self.blocks[bi], sblocks[bi - base], plans[bi]
-            x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq) = sv
+            x, c1, c3, c4, cd, y, (Ti, Hi, Wi, To, Hq, Wq), _ymask = sv
             cin, P, st, ss = d["cin"], d["p"], d["st"], d["ss"]
             C4 = 4 * P
             Min, Mout = B * Ti * Hi * Wi, B * To * Hq * Wq
@@ -689,7 +695,11 @@ class CSNRunner:
                     Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
-                    lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
+                    ym = sblocks[bi - 1 - base][7]                 # the lower block's ReLU mask as a bit field (tuber_block_out_fwd_mask), or None
+                    if ym is not None:
+                        lib.call("tuber_gemm_nt_join_mask", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, ym, c4l, cin, ja, jb)
+                    else:
+                        lib.call("tuber_gemm_nt_join", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, c4l, cin, ja, jb)
                     pre = (dzl, ja, jb, None, Rj)
                     dy = None
                 elif fuse_ds:

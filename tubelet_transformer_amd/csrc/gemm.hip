@@ -28,12 +28,15 @@ enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5, EPI_EVAL = 6 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5, EPI_EVAL = 6, EPI_JOIN_M = 7 };
+// EPI_JOIN_M (round 6): EPI_JOIN whose ReLU mask [Ym > 0] comes as a BIT FIELD (Ymask [M][N / 8] bytes, written by tuber_block_out_fwd_mask) instead of the
+// bf16 tensor y itself: a lane's 8 output columns of a row are one byte.  The join GEMMs run at the bandwidth of their side operands (layer3: 49 MB per launch in
+// 17 us); a timing-only build without the y loads returned 0.135 ms per step, the bit field keeps 15 / 16 of that.
 // EPI_EVAL (round 6, eval forward only): conv4 + the EVAL-mode bn4 + the residual join + ReLU in the GEMM epilogue --
 // y = relu(acc * m_scale[n] + m_shift[n] + R32[m][n]) written as the bf16 GEMM operand of the next block AND as the fp32 residual stream (C32);
 // an eval-mode BatchNorm is a constant affine map, so unlike in training nothing has to wait for the conv output's statistics: c4 never reaches HBM (it is still rounded to bf16 in
 // registers, so y / C32 are bit-identical to tuber_gemm_nt + tuber_block_out_fwd_f32: the eval precision mode's validated rounding points stay as they are).
-#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS)
+#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS || (E) == EPI_JOIN_M)
 // EPI_JOIN_DS: EPI_JOIN below a stage's FIRST block: a second statistics operand Dm (the raw output of its projection shortcut) and a third
 // row sum dz*Dm (stat2) for the shortcut BatchNorm's backward -- what tuber_block_out_bwd writes for such a block
 // EPI_JOIN_SR: EPI_JOIN whose residual R is the gradient of a STRIDED projection shortcut (rows = the sampled positions only; its own
@@ -55,6 +58,7 @@ struct GemmNT {
     float* stat0; float* stat1;                   // EPI_STATS / EPI_BWD partials [tiles_m*WM][N]
     const bf16* Cm; long ldcm; const float* m_scale; const float* m_shift;  // EPI_BWD mask source
     const bf16* Ym; long ldym;                    // EPI_JOIN: mask source (dz = v * [Ym > 0]); Cm is the statistics operand
+    const uint8_t* Ymask;                         // EPI_JOIN_M: the same mask as a bit field [M][N / 8]
     const bf16* Dm; long lddm; float* stat2;      // EPI_JOIN_DS
                                                   // EPI_JOIN_SR: R holds one row per STRIDED sample (n, t/st, h/ss, w/ss) of the M = n*Ti*Hi*Wi output
                                                   // rows (To..ss above): the data gradient of a stage's strided projection shortcut, added where it belongs
@@ -257,7 +261,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     }
     constexpr bool SIDE = EPI == EPI_BWD || IS_JOIN(EPI);
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
-    uint4 sidey[IS_JOIN(EPI) ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
+    constexpr bool YM = EPI == EPI_JOIN_M;
+    uint4 sidey[IS_JOIN(EPI) && !YM ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
+    uint32_t ybits[YM ? MT : 1][NC / 8];              // EPI_JOIN_M: its bit field, one byte per 8 columns
     uint4 sided[EPI == EPI_JOIN_DS ? MT : 1][NC / 8];  // EPI_JOIN_DS: the projection shortcut's raw output
     const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(EPI) || (p.ldym & 7) == 0) && (EPI != EPI_JOIN_DS || (p.lddm & 7) == 0)));
     if (SIDE && side_vec) {
@@ -267,8 +273,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
             for (int c8 = 0; c8 < NC / 8; ++c8) {
                 side[SIDE ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
-                if (IS_JOIN(EPI))
-                    sidey[IS_JOIN(EPI) ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (IS_JOIN(EPI) && !YM)
+                    sidey[IS_JOIN(EPI) && !YM ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (YM) ybits[YM ? i : 0][c8] = m < p.M ? p.Ymask[(long)m * (p.N >> 3) + ((nb + c8 * 8) >> 3)] : 0u;
                 if (EPI == EPI_JOIN_DS)
                     sided[EPI == EPI_JOIN_DS ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Dm + (long)m * p.lddm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
             }
@@ -505,9 +512,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                 for (int c = 0; c < NC; ++c) {
                     if (FULL || nb + c < p.N) {
                         const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
-                        const float yv = side_vec ? bf2f(as_bf16x8(sidey[IS_JOIN(EPI) ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c]);
+                        bool pos;
+                        if constexpr (YM) pos = (ybits[YM ? i : 0][c >> 3] >> (c & 7)) & 1u;
+                        else pos = (side_vec ? bf2f(as_bf16x8(sidey[IS_JOIN(EPI) && !YM ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c])) > 0.f;
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
-                        v[c] = yv > 0.f ? bf2f(f2bf(v[c])) : 0.f;
+                        v[c] = pos ? bf2f(f2bf(v[c])) : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
                         if constexpr (EPI == EPI_JOIN_DS) {
                             const float dv = side_vec ? bf2f(as_bf16x8(sided[i][c >> 3])[c & 7]) : bf2f(p.Dm[(long)m * p.lddm + nb + c]);
@@ -617,6 +626,10 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
         else if (epi == EPI_JOIN_SR) LNT(A_PLAIN, EPI_JOIN_SR);
         else if (epi == EPI_JOIN_DS) LNT(A_PLAIN, EPI_JOIN_DS);
+        else if (epi == EPI_JOIN_M) {
+            if (!full) return TUBER_EINVAL;
+            hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_PLAIN, EPI_JOIN_M, OCC, 0, true>), grid, block, lds, s, p);
+        }
         else LNT(A_PLAIN, EPI_BWD);
     } else {
         if (amode == A_BN_RELU) {
@@ -845,6 +858,24 @@ int tuber_gemm_nt_join(const void* A, long lda, const void* B, long ldb, void* d
     return nt_dispatch(p, A_PLAIN, EPI_JOIN, stream);
 }
 
+// tuber_gemm_nt_join with the ReLU mask of the lower block's output as the bit field tuber_block_out_fwd_mask wrote ([M][N / 8] bytes) instead of y:
+// dz = (A . B^T + R) * [bit], statistics as above.  Identical results (the bit IS y > 0); the launch reads M*N/8 bytes instead of 2*M*N.
+// N % 128 == 0 (64 for few rows), 16-byte addressable rows.
+int tuber_gemm_nt_join_mask(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                            const void* R, long ldr, const void* Ymask, const void* Cm, long ldcm, float* stat0, float* stat1,
+                            hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || (N & 63) || !Ymask || !Cm || !stat0 || !stat1) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm;
+    p.Ymask = (const uint8_t*)Ymask;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN_M, stream);
+}
+
 // tuber_gemm_nt_join below a stage's FIRST block (layer2 / layer3 / layer4; layer1's runs inside tuber_conv1_bwd_fused): Cd = the raw output of that
 // block's projection shortcut, stat2 receives the rows sum dz*cd of the shortcut BatchNorm's backward (tuber_block_out_bwd's third buffer).
 int tuber_gemm_nt_join_ds(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
@@ -886,7 +917,7 @@ int tuber_gemm_nt_join_strided(const void* A, long lda, const void* B, long ldb,
 static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) {
     const int M = p.M, N = p.N, K = p.K;
     int cfg = nt_pick_cfg(M, N, K);
-    if (nt_force_cfg() < 0 && cfg == 13 && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
+    if (nt_force_cfg() < 0 && cfg == 13 && epi != EPI_JOIN_M && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
     if ((nt_force_cfg() < 0 && nt_use_96(p, amode, epi)) || (nt_force_cfg() == 23 && amode == A_PLAIN && nt_full(p, 64) && (epi == EPI_PLAIN || epi == EPI_STATS || epi == EPI_BWD))) return launch_nt_96(p, epi, stream);
     if (nt_force_cfg() == 23) cfg = 13;
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)

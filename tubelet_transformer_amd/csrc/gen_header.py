@@ -62,6 +62,10 @@ DOC = {
                             "(models/backbones/ir_CSN_152.py:62-64,84-90 under model.eval(): a BatchNorm is a constant affine map there, so the join does not wait for "
                             "statistics). Writes y as bf16 (next block's GEMM operand) and as fp32 (the residual stream of the eval precision mode); c4 never reaches HBM. "
                             "Replaces tuber_gemm_nt(amode 1) + tuber_block_out_fwd_f32 for identity blocks.",
+    "tuber_block_out_fwd_mask": "tuber_block_out_fwd (y = relu(bn4(c4) + shortcut), models/backbones/ir_CSN_152.py:84-90) that also writes the ReLU mask of y as a bit field "
+                                "([M][C / 8] bytes, bit e of byte (m, c / 8) = y[m][c + e] > 0) for the join backward (tuber_gemm_nt_join_mask).",
+    "tuber_gemm_nt_join_mask": "tuber_gemm_nt_join (conv1 data gradient of bottleneck i+1 + the join backward of bottleneck i: autograd of ir_CSN_152.py:72,86-89) with the ReLU mask "
+                               "[y > 0] read from the bit field of tuber_block_out_fwd_mask instead of y itself: identical results, M*N/8 bytes instead of 2*M*N.",
     "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
                         "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
                         "MLP models/criterion.py:485-497) under model.eval().",

@@ -173,7 +173,7 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
 __global__ __launch_bounds__(256) void block_out_fwd_kernel(
     const bf16* __restrict__ c4, const float* __restrict__ s4, const float* __restrict__ h4,
     const bf16* __restrict__ res, const float* __restrict__ rs, const float* __restrict__ rh,
-    bf16* __restrict__ y, long M, int C) {
+    bf16* __restrict__ y, uint8_t* __restrict__ ymask, long M, int C) {
     const int tpr = C >> 3;
     const int cg = threadIdx.x % tpr;
     const long rpp = 256 / tpr;
@@ -185,13 +185,18 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(
         const bf16x8 c = as_bf16x8(*(const uint4*)(c4 + off));
         const bf16x8 r = as_bf16x8(*(const uint4*)(res + off));
         bf16x8 o;
+        unsigned bits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float rv = bf2f(r[e]);
             if (rs) rv = fmaf(rv, ar[e], br[e]);
             o[e] = f2bf(fmaxf(fmaf(bf2f(c[e]), a4[e], b4[e]) + rv, 0.f));
+            bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
         }
         *(uint4*)(y + off) = as_uint4(o);
+        // ReLU mask of the block output, one bit per element ([M][C / 8] bytes, bit e of byte (m, c / 8) = y[m][c + e] > 0): what the join
+        // backward of this block reads instead of the 16 x larger y (tuber_gemm_nt_join_mask, round 6)
+        if (ymask) ymask[row * tpr + cg] = (uint8_t)bits;
     }
 }
 
@@ -841,7 +846,17 @@ int tuber_block_out_fwd(const void* c4, const float* s4, const float* h4, const 
                         void* y, long M, int C, hipStream_t stream) {
     if (!chan_ok(C)) return TUBER_EINVAL;
     hipLaunchKernelGGL(block_out_fwd_kernel, dim3(ew_grid(M, C)), dim3(256), 0, stream, (const bf16*)c4, s4, h4, (const bf16*)res,
-                       rs, rh, (bf16*)y, M, C);
+                       rs, rh, (bf16*)y, (uint8_t*)nullptr, M, C);
+    TUBER_RETURN_LAUNCH();
+}
+
+// tuber_block_out_fwd that ALSO writes the ReLU mask of its output as a bit field: ymask [M][C / 8] bytes, bit e of byte (m, c / 8) =
+// y[m][c + e] > 0.  The join backward of this block (tuber_gemm_nt_join_mask) reads it instead of y: 1 / 16 of the bytes.
+int tuber_block_out_fwd_mask(const void* c4, const float* s4, const float* h4, const void* res, const float* rs, const float* rh,
+                             void* y, void* ymask, long M, int C, hipStream_t stream) {
+    if (!chan_ok(C) || !ymask) return TUBER_EINVAL;
+    hipLaunchKernelGGL(block_out_fwd_kernel, dim3(ew_grid(M, C)), dim3(256), 0, stream, (const bf16*)c4, s4, h4, (const bf16*)res,
+                       rs, rh, (bf16*)y, (uint8_t*)ymask, M, C);
     TUBER_RETURN_LAUNCH();
 }
 
