@@ -1635,3 +1635,68 @@ def test_join_backward_reads_the_relu_mask_as_a_bit_field(dev, M, N, K):
         assert torch.equal(a, b)
     ref = (A.float() @ W.float().t() + R.float()) * (y0.float() > 0)
     close("join with bit mask vs fp32", outs[1][0], ref)
+
+
+def _bits_of(y):
+    """the [M][N / 8] bit field of y > 0 (the layout tuber_block_out_fwd_mask writes)"""
+    M, N = y.shape
+    b = (y.float() > 0).view(M, N // 8, 8).to(torch.int32)
+    w = (b << torch.arange(8, device=y.device, dtype=torch.int32)).sum(-1)
+    return w.to(torch.uint8).contiguous()
+
+
+def test_strided_and_first_block_joins_with_the_bit_field_mask(dev):
+    """tuber_gemm_nt_join_strided_mask / tuber_gemm_nt_join_ds_mask == their y-reading forms, bit for bit (dz and every statistics row);
+    tuber_blockout_conv1_fwd_mask == tuber_blockout_conv1_fwd + the bit field of its y."""
+    # strided form: a stage boundary (n, Ti, Hi, Wi) = (2, 4, 16, 22), spatial stride 2
+    n, Ti, Hi, Wi, st, ss, N, K = 2, 4, 16, 22, 1, 2, 512, 256
+    To, Ho, Wo = (Ti - 1) // st + 1, (Hi - 1) // ss + 1, (Wi - 1) // ss + 1
+    M, Mo = n * Ti * Hi * Wi, n * To * Ho * Wo
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    B = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).to(BF)
+    Rs = rnd(Mo, N, dev=dev, seed=3).to(BF)
+    Y = rnd(M, N, dev=dev, seed=4).to(BF).relu()
+    C4, Cd, Rr = rnd(M, N, dev=dev, seed=5).to(BF), rnd(M, N, dev=dev, seed=6).to(BF), rnd(M, N, dev=dev, seed=7).to(BF)
+    ym = _bits_of(Y)
+    R1 = lib.query("tuber_gemm_nt_stat_rows", M, N)
+    res = []
+    for masked in (False, True):
+        dz = torch.empty(M, N, device=dev, dtype=BF)
+        b0, b1 = torch.full((R1, N), 7.0, device=dev), torch.full((R1, N), 7.0, device=dev)
+        if masked:
+            lib.call("tuber_gemm_nt_join_strided_mask", A, K, B, K, dz, N, M, N, K, Rs, N, To, Ho, Wo, Ti, Hi, Wi, st, ss, ym, C4, N, b0, b1)
+        else:
+            lib.call("tuber_gemm_nt_join_strided", A, K, B, K, dz, N, M, N, K, Rs, N, To, Ho, Wo, Ti, Hi, Wi, st, ss, Y, N, C4, N, b0, b1)
+        res.append((dz, b0, b1))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    res = []
+    for masked in (False, True):
+        dz = torch.empty(M, N, device=dev, dtype=BF)
+        d0, d1, d2 = (torch.full((R1, N), 7.0, device=dev) for _ in range(3))
+        if masked:
+            lib.call("tuber_gemm_nt_join_ds_mask", A, K, B, K, dz, N, M, N, K, Rr, N, ym, C4, N, Cd, N, d0, d1, d2)
+        else:
+            lib.call("tuber_gemm_nt_join_ds", A, K, B, K, dz, N, M, N, K, Rr, N, Y, N, C4, N, Cd, N, d0, d1, d2)
+        res.append((dz, d0, d1, d2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # the layer1 join + next conv1 kernel with the mask output
+    Mb, C, PN = 20000, 256, 128
+    c4, rs_in = rnd(Mb, C, dev=dev, seed=11).to(BF), rnd(Mb, C, dev=dev, seed=12).to(BF)
+    s4, h4 = rnd(C, dev=dev, seed=13).abs() + 0.5, rnd(C, dev=dev, seed=14) * 0.3
+    W = rnd(PN, C, dev=dev, seed=15, scale=C ** -0.5).to(BF)
+    rows = lib.query("tuber_gemm_nt_stat_rows", Mb, PN)
+    outs = []
+    for masked in (False, True):
+        y, c1 = torch.empty(Mb, C, device=dev, dtype=BF), torch.empty(Mb, PN, device=dev, dtype=BF)
+        t0, t1 = torch.zeros(rows, PN, device=dev), torch.zeros(rows, PN, device=dev)
+        mk = torch.zeros(Mb, C // 8, device=dev, dtype=torch.uint8)
+        if masked:
+            lib.call("tuber_blockout_conv1_fwd_mask", c4, s4, h4, rs_in, None, None, y, mk, W, C, c1, t0, t1, Mb, PN)
+        else:
+            lib.call("tuber_blockout_conv1_fwd", c4, s4, h4, rs_in, None, None, y, W, C, c1, t0, t1, Mb, PN)
+        outs.append((y, c1, t0, t1, mk))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][4], _bits_of(outs[1][0]))

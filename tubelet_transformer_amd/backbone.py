@@ -374,13 +374,18 @@ class CSNRunner:
                     n0, n1 = self.ws("st0", Rn * PN), self.ws("st1", Rn * PN)
                 else:
                     n0 = n1 = None
-                lib.call("tuber_blockout_conv1_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, nxt["w1"], nxt["cin"], pre_c1, n0, n1, Mout, PN)
+                if train and nxt["stage"] != d["stage"] and not ab.on("no_join_mask"):
+                    # the last block of layer1: its join backward runs in layer2's first conv1 data-gradient GEMM (strided form) and reads the mask as a bit field
+                    ymask = torch.empty(Mout, P // 2, dtype=torch.uint8, device=dev)
+                    lib.call("tuber_blockout_conv1_fwd_mask", c4, b4.scale, b4.shift, res, rs, rh, y, ymask, nxt["w1"], nxt["cin"], pre_c1, n0, n1, Mout, PN)
+                else:
+                    lib.call("tuber_blockout_conv1_fwd", c4, b4.scale, b4.shift, res, rs, rh, y, nxt["w1"], nxt["cin"], pre_c1, n0, n1, Mout, PN)
                 if train:
                     pend = bn1_stats(nxt, n0, n1, Rn, Mout)
                 else:
                     self._bn_eval(nxt["bn1"])
-            elif train and not d["ds"] and not ab.on("no_join_mask"):
-                # identity block in training: the ReLU mask of y also leaves as a bit field -- what this block's join backward (inside the conv1
+            elif train and not ab.on("no_join_mask"):
+                # training: the ReLU mask of y also leaves as a bit field -- what this block's join backward (inside the conv1
                 # data-gradient GEMM of the block above, tuber_gemm_nt_join_mask) reads instead of y: 1 / 16 of the bytes of a side operand of a
                 # launch that runs at the bandwidth of its side operands
                 ymask = torch.empty(Mout, P // 2, dtype=torch.uint8, device=dev)
@@ -709,7 +714,10 @@ class CSNRunner:
                     Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                     ja, jb, jc = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin), self.ws("stj2", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
-                    lib.call("tuber_gemm_nt_join_ds", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, sv_l[3], cin, sv_l[4], cin, ja, jb, jc)
+                    if sv_l[7] is not None:
+                        lib.call("tuber_gemm_nt_join_ds_mask", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, sv_l[7], sv_l[3], cin, sv_l[4], cin, ja, jb, jc)
+                    else:
+                        lib.call("tuber_gemm_nt_join_ds", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, res, cin, x, cin, sv_l[3], cin, sv_l[4], cin, ja, jb, jc)
                     pre = (dzl, ja, jb, jc, Rj)
                     dy = None
                 elif fuse_sr:
@@ -720,8 +728,13 @@ class CSNRunner:
                     Rj = lib.query("tuber_gemm_nt_stat_rows", Min, cin)
                     ja, jb = self.ws("stj0", Rj * cin), self.ws("stj1", Rj * cin)
                     dzl = torch.empty(Min, cin, dtype=BF, device=dev)
-                    lib.call("tuber_gemm_nt_join_strided", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, dxd, cin, To, Hq, Wq, Ti, Hi, Wi, st, ss,
-                             x, cin, c4l, cin, ja, jb)
+                    ym = sblocks[bi - 1 - base][7]
+                    if ym is not None:
+                        lib.call("tuber_gemm_nt_join_strided_mask", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, dxd, cin, To, Hq, Wq, Ti, Hi, Wi, st, ss,
+                                 ym, c4l, cin, ja, jb)
+                    else:
+                        lib.call("tuber_gemm_nt_join_strided", dc1, P, d["w1t"], d["ld1t"], dzl, cin, Min, cin, P, dxd, cin, To, Hq, Wq, Ti, Hi, Wi, st, ss,
+                                 x, cin, c4l, cin, ja, jb)
                     pre = (dzl, ja, jb, None, Rj)
                     dy = None
                 else:

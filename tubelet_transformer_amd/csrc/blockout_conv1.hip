@@ -25,6 +25,7 @@ struct BoC1Args {
     const bf16* c4; const float* s4; const float* h4;      // bn4(c4) = c4*s4 + h4
     const bf16* res; const float* rs; const float* rh;     // shortcut: res (identity) or res*rs + rh (projection + its BatchNorm)
     bf16* y;                                               // [M, 256] out
+    uint8_t* ymask;                                        // optional: the ReLU mask of y as a bit field [M][32] (tuber_gemm_nt_join_strided_mask reads it)
     const bf16* w; long ldw;                               // next conv1 weight [PN][ldw] bf16 (row = output channel)
     bf16* c1;                                              // [M, PN] out
     float* st0; float* st1;                                // [tiles][PN] out (NULL in eval mode)
@@ -73,14 +74,19 @@ __global__ __launch_bounds__(256, PN == 64 ? 2 : 1) void blockout_conv1_kernel(B
             const int row = gr + 8 * h;
             const bf16x8 c = as_bf16x8(rcv[h]), r = as_bf16x8(rrv[h]);
             bf16x8 o;
+            unsigned bits = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float rv = bf2f(r[e]);
                 if (proj) rv = fmaf(rv, ar[e], br[e]);
                 o[e] = f2bf(fmaxf(fmaf(bf2f(c[e]), a4[e], b4[e]) + rv, 0.f));
+                bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
             }
             const uint4 ov = as_uint4(o);
-            if (m0 + row < a.M) *(uint4*)(a.y + (m0 + row) * C + gch * 8) = ov;
+            if (m0 + row < a.M) {
+                *(uint4*)(a.y + (m0 + row) * C + gch * 8) = ov;
+                if (a.ymask) a.ymask[(m0 + row) * (C / 8) + gch] = (uint8_t)bits;
+            }
             *(uint4*)(yimg + goff(row, gch * 8)) = ov;
         }
         load_tile(min(t + (long)gridDim.x, ntiles - 1));
@@ -162,6 +168,20 @@ int tuber_blockout_conv1_fwd(const void* c4, const float* s4, const float* h4, c
     if (!c4 || !s4 || !h4 || !res || !y || !w || !c1 || M <= 0 || ldw < C || (ldw & 7) || (rs && !rh) || (st0 && !st1)) return TUBER_EINVAL;
     BoC1Args a;
     a.c4 = (const bf16*)c4; a.s4 = s4; a.h4 = h4; a.res = (const bf16*)res; a.rs = rs; a.rh = rh; a.y = (bf16*)y;
+    a.ymask = nullptr;
+    a.w = (const bf16*)w; a.ldw = ldw; a.c1 = (bf16*)c1; a.st0 = st0; a.st1 = st1; a.M = M;
+    if (pn == 64) return launch<64>(a, stream);
+    if (pn == 128) return launch<128>(a, stream);
+    return TUBER_EINVAL;
+}
+
+// the same launch, also writing the ReLU mask of y as a bit field ([M][32] bytes, bit e of byte (m, c / 8) = y[m][c + e] > 0) for the join backward across the
+// stage boundary (tuber_gemm_nt_join_strided_mask)
+int tuber_blockout_conv1_fwd_mask(const void* c4, const float* s4, const float* h4, const void* res, const float* rs, const float* rh,
+                                  void* y, void* ymask, const void* w, long ldw, void* c1, float* st0, float* st1, long M, int pn, hipStream_t stream) {
+    if (!c4 || !s4 || !h4 || !res || !y || !ymask || !w || !c1 || M <= 0 || ldw < C || (ldw & 7) || (rs && !rh) || (st0 && !st1)) return TUBER_EINVAL;
+    BoC1Args a;
+    a.c4 = (const bf16*)c4; a.s4 = s4; a.h4 = h4; a.res = (const bf16*)res; a.rs = rs; a.rh = rh; a.y = (bf16*)y; a.ymask = (uint8_t*)ymask;
     a.w = (const bf16*)w; a.ldw = ldw; a.c1 = (bf16*)c1; a.st0 = st0; a.st1 = st1; a.M = M;
     if (pn == 64) return launch<64>(a, stream);
     if (pn == 128) return launch<128>(a, stream);

@@ -28,7 +28,7 @@ enum { A_PLAIN = 0, A_BN_RELU = 1, A_BN_BWD = 2, A_ADD = 3 };
 // A_BN_BWD: a = cA[k]*A + cB[k]*A2 + cC[k] (BatchNorm backward apply; measured slower than the apply kernel, not instantiated)
 // A_ADD:    a = A + A2 for the output-column tiles below add_ncols, a = A for the rest: a packed attention in-projection whose
 //           q / k rows see x + pos (with_pos_embed) and whose v rows see x -- one GEMM instead of an add kernel and two GEMMs
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5, EPI_EVAL = 6, EPI_JOIN_M = 7 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4, EPI_JOIN_DS = 5, EPI_EVAL = 6, EPI_JOIN_M = 7, EPI_JOIN_SR_M = 8, EPI_JOIN_DS_M = 9 };
 // EPI_JOIN_M (round 6): EPI_JOIN whose ReLU mask [Ym > 0] comes as a BIT FIELD (Ymask [M][N / 8] bytes, written by tuber_block_out_fwd_mask) instead of the
 // bf16 tensor y itself: a lane's 8 output columns of a row are one byte.  The join GEMMs run at the bandwidth of their side operands (layer3: 49 MB per launch in
 // 17 us); a timing-only build without the y loads returned 0.135 ms per step, the bit field keeps 15 / 16 of that.
@@ -36,7 +36,8 @@ enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWD = 2, EPI_JOIN = 3, EPI_JOIN_SR = 4,
 // y = relu(acc * m_scale[n] + m_shift[n] + R32[m][n]) written as the bf16 GEMM operand of the next block AND as the fp32 residual stream (C32);
 // an eval-mode BatchNorm is a constant affine map, so unlike in training nothing has to wait for the conv output's statistics: c4 never reaches HBM (it is still rounded to bf16 in
 // registers, so y / C32 are bit-identical to tuber_gemm_nt + tuber_block_out_fwd_f32: the eval precision mode's validated rounding points stay as they are).
-#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS || (E) == EPI_JOIN_M)
+#define IS_JOIN(E) ((E) == EPI_JOIN || (E) == EPI_JOIN_SR || (E) == EPI_JOIN_DS)
+#define IS_JOIN_M(E) ((E) == EPI_JOIN_M || (E) == EPI_JOIN_SR_M || (E) == EPI_JOIN_DS_M)      /* the bit-field forms of the three */
 // EPI_JOIN_DS: EPI_JOIN below a stage's FIRST block: a second statistics operand Dm (the raw output of its projection shortcut) and a third
 // row sum dz*Dm (stat2) for the shortcut BatchNorm's backward -- what tuber_block_out_bwd writes for such a block
 // EPI_JOIN_SR: EPI_JOIN whose residual R is the gradient of a STRIDED projection shortcut (rows = the sampled positions only; its own
@@ -88,6 +89,9 @@ __host__ __device__ constexpr int wsk_image_bytes(int bm) { return (bm + 64) * 1
 // epilogue are compiled out.
 template <int BM, int BN, int WM, int WN, int G, int AMODE, int EPI, int OCC, int WSK = 0, bool FULL = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
+    // the *_M epilogues are their base epilogue with the ReLU mask read as a bit field (YM): everything below switches on the base (E0)
+    constexpr int E0 = EPI == EPI_JOIN_M ? EPI_JOIN : EPI == EPI_JOIN_SR_M ? EPI_JOIN_SR : EPI == EPI_JOIN_DS_M ? EPI_JOIN_DS : EPI;
+    constexpr bool YM = IS_JOIN_M(EPI);
     static_assert(!WSK || ((BM == 64 || BM == 96) && BN == 64 && WM == 2 && WN == 2 && AMODE == A_PLAIN), "wave split-K: 64x64 / 96x64 tiles, plain A");
     constexpr int KS = 1, kg = 0;               // (the in-workgroup k-split of round 1 was measured and dropped; the index math keeps its shape)
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
@@ -259,13 +263,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         for (int j = 0; j < G; ++j)
             if (j < nk) load_tile(j, ra[j], rb[j], ra2[TWO ? j : 0]);
     }
-    constexpr bool SIDE = EPI == EPI_BWD || IS_JOIN(EPI);
+    constexpr bool SIDE = E0 == EPI_BWD || IS_JOIN(E0);
     uint4 side[SIDE ? MT : 1][NC / 8];         // EPI_BWD / EPI_JOIN: the statistics operand c, fetched behind the k-loop
-    constexpr bool YM = EPI == EPI_JOIN_M;
-    uint4 sidey[IS_JOIN(EPI) && !YM ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
+    uint4 sidey[IS_JOIN(E0) && !YM ? MT : 1][NC / 8];       // EPI_JOIN: the mask source y
     uint32_t ybits[YM ? MT : 1][NC / 8];              // EPI_JOIN_M: its bit field, one byte per 8 columns
-    uint4 sided[EPI == EPI_JOIN_DS ? MT : 1][NC / 8];  // EPI_JOIN_DS: the projection shortcut's raw output
-    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(EPI) || (p.ldym & 7) == 0) && (EPI != EPI_JOIN_DS || (p.lddm & 7) == 0)));
+    uint4 sided[E0 == EPI_JOIN_DS ? MT : 1][NC / 8];  // EPI_JOIN_DS: the projection shortcut's raw output
+    const bool side_vec = SIDE && (FULL || (vec_ok && ((p.ldcm & 7) == 0) && (!IS_JOIN(E0) || (p.ldym & 7) == 0) && (E0 != EPI_JOIN_DS || (p.lddm & 7) == 0)));
     if (SIDE && side_vec) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -273,11 +276,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
             for (int c8 = 0; c8 < NC / 8; ++c8) {
                 side[SIDE ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Cm + (long)m * p.ldcm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
-                if (IS_JOIN(EPI) && !YM)
-                    sidey[IS_JOIN(EPI) && !YM ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (IS_JOIN(E0) && !YM)
+                    sidey[IS_JOIN(E0) && !YM ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Ym + (long)m * p.ldym + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
                 if (YM) ybits[YM ? i : 0][c8] = m < p.M ? p.Ymask[(long)m * (p.N >> 3) + ((nb + c8 * 8) >> 3)] : 0u;
-                if (EPI == EPI_JOIN_DS)
-                    sided[EPI == EPI_JOIN_DS ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Dm + (long)m * p.lddm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
+                if (E0 == EPI_JOIN_DS)
+                    sided[E0 == EPI_JOIN_DS ? i : 0][c8] = m < p.M ? *(const uint4*)(p.Dm + (long)m * p.lddm + nb + c8 * 8) : make_uint4(0, 0, 0, 0);
             }
         }
     }
@@ -410,13 +413,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
     const bool epi_on = true;
 
     // ---- epilogue: lane holds, for each mt, columns nb .. nb+4*NT-1 of row m ----
-    float s0[NC], s1[NC], s2[EPI == EPI_JOIN_DS ? NC : 1];
-    if (EPI != EPI_PLAIN) {
+    float s0[NC], s1[NC], s2[E0 == EPI_JOIN_DS ? NC : 1];
+    if (E0 != EPI_PLAIN) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; if (EPI == EPI_JOIN_DS) s2[EPI == EPI_JOIN_DS ? c : 0] = 0.f; }
+        for (int c = 0; c < NC; ++c) { s0[c] = 0.f; s1[c] = 0.f; if (E0 == EPI_JOIN_DS) s2[E0 == EPI_JOIN_DS ? c : 0] = 0.f; }
     }
     float msc[NC], msh[NC];
-    if (EPI == EPI_BWD || EPI == EPI_EVAL) {
+    if (E0 == EPI_BWD || E0 == EPI_EVAL) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool ok = FULL || nb + c < p.N;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha;
-        if (EPI == EPI_PLAIN) {
+        if (E0 == EPI_PLAIN) {
             if (p.bias) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) v[c] += p.bias[nb + c];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) v[c] = keep[c] ? v[c] * p.drop_inv_keep : 0.f;
             }
-        } else if (EPI == EPI_EVAL) {
+        } else if (E0 == EPI_EVAL) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) v[c] = fmaf(bf2f(f2bf(v[c])), msc[c], msh[c]);      // c4 passes through bf16 as in the two-launch path: bit-identical outputs
             if (mok) {
@@ -479,16 +482,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                     *(float4*)(o32 + c4 * 4) = o;
                 }
             }
-        } else if (EPI == EPI_STATS) {
+        } else if (E0 == EPI_STATS) {
             if (mok) {                                   // rows beyond M hold a copy of row M-1
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { s0[c] += v[c]; s1[c] += v[c] * v[c]; }
             }
-        } else if (IS_JOIN(EPI)) {
+        } else if (IS_JOIN(E0)) {
             if (mok) {
                 long rrow = m;
                 bool rok = p.R != nullptr;
-                if constexpr (EPI == EPI_JOIN_SR) {      // the strided projection shortcut's gradient lives at the sampled positions only
+                if constexpr (E0 == EPI_JOIN_SR) {      // the strided projection shortcut's gradient lives at the sampled positions only
                     const int w = m % p.Wi; int q = m / p.Wi;
                     const int h = q % p.Hi; q /= p.Hi;
                     const int t = q % p.Ti; const int n = q / p.Ti;
@@ -514,11 +517,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
                         const float cv = side_vec ? bf2f(as_bf16x8(side[SIDE ? i : 0][c >> 3])[c & 7]) : bf2f(p.Cm[(long)m * p.ldcm + nb + c]);
                         bool pos;
                         if constexpr (YM) pos = (ybits[YM ? i : 0][c >> 3] >> (c & 7)) & 1u;
-                        else pos = (side_vec ? bf2f(as_bf16x8(sidey[IS_JOIN(EPI) && !YM ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c])) > 0.f;
+                        else pos = (side_vec ? bf2f(as_bf16x8(sidey[IS_JOIN(E0) && !YM ? i : 0][c >> 3])[c & 7]) : bf2f(p.Ym[(long)m * p.ldym + nb + c])) > 0.f;
                         // the stored dz is bf16: the statistics are taken of the ROUNDED value, like the stand-alone join kernel does
                         v[c] = pos ? bf2f(f2bf(v[c])) : 0.f;
                         s0[c] += v[c]; s1[c] += v[c] * cv;
-                        if constexpr (EPI == EPI_JOIN_DS) {
+                        if constexpr (E0 == EPI_JOIN_DS) {
                             const float dv = side_vec ? bf2f(as_bf16x8(sided[i][c >> 3])[c & 7]) : bf2f(p.Dm[(long)m * p.lddm + nb + c]);
                             s2[c] += v[c] * dv;
                         }
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
         if (mok) {
-            if (EPI == EPI_PLAIN && p.out_f32) {
+            if (E0 == EPI_PLAIN && p.out_f32) {
                 float* o = (float*)p.C + (long)m * p.ldc + nb;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) if (FULL || nb + c < p.N) o[c] = v[c];
@@ -560,9 +563,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             }
         }
     }
-    if (EPI != EPI_PLAIN && EPI != EPI_EVAL && p.stat0) {
+    if (E0 != EPI_PLAIN && E0 != EPI_EVAL && p.stat0) {
         // one partial row per workgroup tile: reduce the 16 lanes sharing g, then the WM waves via LDS
-        constexpr int NS = EPI == EPI_JOIN_DS ? 3 : 2;
+        constexpr int NS = E0 == EPI_JOIN_DS ? 3 : 2;
         __syncthreads();
         float* red = (float*)smem;                       // [WM][BN][NS]
 #pragma unroll
@@ -570,12 +573,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
             const float a = quad16_sum(s0[c]);
             const float b = quad16_sum(s1[c]);
             float d = 0.f;
-            if constexpr (EPI == EPI_JOIN_DS) d = quad16_sum(s2[c]);
+            if constexpr (E0 == EPI_JOIN_DS) d = quad16_sum(s2[c]);
             if (li == 0 && epi_on) {
                 const int col = wn * TN + g * NC + c;
                 red[(wm * BN + col) * NS + 0] = a;
                 red[(wm * BN + col) * NS + 1] = b;
-                if constexpr (EPI == EPI_JOIN_DS) red[(wm * BN + col) * NS + 2] = d;
+                if constexpr (E0 == EPI_JOIN_DS) red[(wm * BN + col) * NS + 2] = d;
             }
         }
         __syncthreads();
@@ -584,11 +587,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
             for (int w = 0; w < WM; ++w) {
                 a += red[(w * BN + tid) * NS]; b += red[(w * BN + tid) * NS + 1];
-                if constexpr (EPI == EPI_JOIN_DS) d += red[(w * BN + tid) * NS + 2];
+                if constexpr (E0 == EPI_JOIN_DS) d += red[(w * BN + tid) * NS + 2];
             }
             p.stat0[(long)tile_m * p.N + n0 + tid] = a;
             p.stat1[(long)tile_m * p.N + n0 + tid] = b;
-            if constexpr (EPI == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
+            if constexpr (E0 == EPI_JOIN_DS) p.stat2[(long)tile_m * p.N + n0 + tid] = d;
             if constexpr (BM == 96) {
                 // the consumers read tuber_gemm_nt_stat_rows(M, N) = ceil(M / 64) rows: the rows this tiling does not produce are zero
                 const int tiles_m = (p.M + BM - 1) / BM, rows64 = (p.M + 63) / 64;
@@ -626,16 +629,18 @@ static int launch_nt_cfg(const GemmNT& p, int amode, int epi, hipStream_t s) {
         else if (epi == EPI_JOIN) LNT(A_PLAIN, EPI_JOIN);
         else if (epi == EPI_JOIN_SR) LNT(A_PLAIN, EPI_JOIN_SR);
         else if (epi == EPI_JOIN_DS) LNT(A_PLAIN, EPI_JOIN_DS);
-        else if (epi == EPI_JOIN_M) {
+        else if (IS_JOIN_M(epi)) {                      // the bit-field forms: full tiles only
             if (!full) return TUBER_EINVAL;
-            hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_PLAIN, EPI_JOIN_M, OCC, 0, true>), grid, block, lds, s, p);
+            if (epi == EPI_JOIN_M) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_PLAIN, EPI_JOIN_M, OCC, 0, true>), grid, block, lds, s, p);
+            else if (epi == EPI_JOIN_SR_M) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_PLAIN, EPI_JOIN_SR_M, OCC, 0, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_PLAIN, EPI_JOIN_DS_M, OCC, 0, true>), grid, block, lds, s, p);
         }
         else LNT(A_PLAIN, EPI_BWD);
     } else {
         if (amode == A_BN_RELU) {
             if (epi == EPI_PLAIN) LNT(A_BN_RELU, EPI_PLAIN);
             else if (epi == EPI_STATS) LNT(A_BN_RELU, EPI_STATS);
-            else if (IS_JOIN(epi)) return TUBER_EINVAL;
+            else if (IS_JOIN(epi) || IS_JOIN_M(epi)) return TUBER_EINVAL;
             else if (epi == EPI_EVAL) {
                 if (!full) return TUBER_EINVAL;
                 hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, G, A_BN_RELU, EPI_EVAL, OCC, 0, true>), grid, block, lds, s, p);
@@ -914,14 +919,47 @@ int tuber_gemm_nt_join_strided(const void* A, long lda, const void* B, long ldb,
     return nt_dispatch(p, A_PLAIN, EPI_JOIN_SR, stream);
 }
 
+// tuber_gemm_nt_join_ds / tuber_gemm_nt_join_strided with the ReLU mask [y > 0] of the lower block's output read from the bit field of
+// tuber_block_out_fwd_mask / tuber_blockout_conv1_fwd ([M][N / 8] bytes) instead of y: identical results.  Full tiles only (N % 128 == 0; 64 for the ds form).
+int tuber_gemm_nt_join_ds_mask(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                               const void* R, long ldr, const void* Ymask, const void* Cm, long ldcm, const void* Cd, long ldcd,
+                               float* stat0, float* stat1, float* stat2, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || (N & 63) || !Ymask || !Cm || !Cd || !stat0 || !stat1 || !stat2) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.stat0 = stat0; p.stat1 = stat1; p.stat2 = stat2; p.Cm = (const bf16*)Cm; p.ldcm = ldcm; p.Dm = (const bf16*)Cd; p.lddm = ldcd;
+    p.Ymask = (const uint8_t*)Ymask;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN_DS_M, stream);
+}
+int tuber_gemm_nt_join_strided_mask(const void* A, long lda, const void* B, long ldb, void* dz, long ldc, int M, int N, int K,
+                                    const void* R, long ldr, int To, int Ho, int Wo, int Ti, int Hi, int Wi, int st, int ss,
+                                    const void* Ymask, const void* Cm, long ldcm, float* stat0, float* stat1, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || (lda & 7) || (ldb & 7) || (N & 63) || !Ymask || !Cm || !stat0 || !stat1 || !R || st < 1 || ss < 1
+        || To != (Ti - 1) / st + 1 || Ho != (Hi - 1) / ss + 1 || Wo != (Wi - 1) / ss + 1 || M % (Ti * Hi * Wi)) return TUBER_EINVAL;
+    GemmNT p;
+    memset(&p, 0, sizeof p);
+    p.alpha = 1.f; p.drop_inv_keep = 1.f;
+    p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.C = dz; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.R = (const bf16*)R; p.ldr = ldr;
+    p.To = To; p.Ho = Ho; p.Wo = Wo; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.st = st; p.ss = ss;
+    p.stat0 = stat0; p.stat1 = stat1; p.Cm = (const bf16*)Cm; p.ldcm = ldcm;
+    p.Ymask = (const uint8_t*)Ymask;
+    return nt_dispatch(p, A_PLAIN, EPI_JOIN_SR_M, stream);
+}
+
 static int nt_dispatch(const GemmNT& p, int amode, int epi, hipStream_t stream) {
     const int M = p.M, N = p.N, K = p.K;
     int cfg = nt_pick_cfg(M, N, K);
-    if (nt_force_cfg() < 0 && cfg == 13 && epi != EPI_JOIN_M && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
+    if (nt_force_cfg() < 0 && cfg == 13 && !IS_JOIN_M(epi) && nt_use_wsk(p, amode)) return launch_nt_wsk(p, epi, stream);
     if ((nt_force_cfg() < 0 && nt_use_96(p, amode, epi)) || (nt_force_cfg() == 23 && amode == A_PLAIN && nt_full(p, 64) && (epi == EPI_PLAIN || epi == EPI_STATS || epi == EPI_BWD))) return launch_nt_96(p, epi, stream);
     if (nt_force_cfg() == 23) cfg = 13;
     if (cfg == 0 && epi != EPI_PLAIN && nt_force_cfg() < 0) cfg = 7;     // statistics rows are per 64 output rows (tuber_gemm_nt_stat_rows)
-    if (epi == EPI_JOIN_DS && cfg == 7 && nt_force_cfg() < 0) cfg = 13;   // three side operands spill the 64x128 tile (21 registers at 3 workgroups / CU)
+    if ((epi == EPI_JOIN_DS || epi == EPI_JOIN_DS_M) && cfg == 7 && nt_force_cfg() < 0) cfg = 13;   // three side operands spill the 64x128 tile (21 registers at 3 workgroups / CU)
     switch (cfg) {
         case 0: return launch_nt_cfg<128, 128, 2, 2, 2, 2>(p, amode, epi, stream);    // class-branch FFN (plain epilogue)
         case 7: return launch_nt_cfg<64, 128, 1, 4, 2, 3>(p, amode, epi, stream);

@@ -66,6 +66,9 @@ DOC = {
                                 "([M][C / 8] bytes, bit e of byte (m, c / 8) = y[m][c + e] > 0) for the join backward (tuber_gemm_nt_join_mask).",
     "tuber_gemm_nt_join_mask": "tuber_gemm_nt_join (conv1 data gradient of bottleneck i+1 + the join backward of bottleneck i: autograd of ir_CSN_152.py:72,86-89) with the ReLU mask "
                                "[y > 0] read from the bit field of tuber_block_out_fwd_mask instead of y itself: identical results, M*N/8 bytes instead of 2*M*N.",
+    "tuber_gemm_nt_join_ds_mask": "tuber_gemm_nt_join_ds with the ReLU mask read from the bit field of tuber_block_out_fwd_mask instead of y (identical results).",
+    "tuber_gemm_nt_join_strided_mask": "tuber_gemm_nt_join_strided with the ReLU mask read from the bit field of tuber_block_out_fwd_mask / tuber_blockout_conv1_fwd_mask instead of y (identical results).",
+    "tuber_blockout_conv1_fwd_mask": "tuber_blockout_conv1_fwd that also writes the ReLU mask of y as a bit field ([M][32] bytes) for the join backward across the stage boundary.",
     "tuber_linear_f32": "fp32 linear layer of the eval precision mode: y = act((x [+ add]) . W^T + bias) on the fp32 master weights -- the decoder's nn.Linear / packed "
                         "in-projections (models/transformer/transformer.py:218-249, with_pos_embed as the add operand) and the box / actor heads (models/tuber_ava.py:121-125,142; "
                         "MLP models/criterion.py:485-497) under model.eval().",
