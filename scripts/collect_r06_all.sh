@@ -17,7 +17,7 @@ TUBER_FORCE_DDP=1 TUBER_DDP_CUTS=3 TUBER_DDP_EDGE=event $B --no-roofline > $O/be
 TUBER_FORCE_DDP=1 TUBER_NO_SPLIT_GRAPH=1 $B --no-roofline > $O/bench_force_ddp_one_rank_single_graph.json 2>/dev/null
 TUBER_FORCE_DDP=1 TUBER_NO_OWN_RCCL=1 $B --no-roofline > $O/bench_force_ddp_structure_only_no_edges.json 2>/dev/null
 TUBER_SHARE_GPU=1 TUBER_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $O/bench_two_ranks_one_gpu_gloo_self_spawned.json 2>/dev/null
-for sw in no_join_mask no_ln_bwd_fusion no_in_proj_dx2 no_decoder_coop no_bn3_in_dw no_dw_bwd_one_launch no_conv4_bwd_fused no_blockout_conv1 no_conv1_bwd_fused no_join_fusion no_wgrad_groups no_bn_bwd_fa no_bn1_in_dw_fwd no_strided_join_fusion,no_ds_join_fusion; do
+for sw in no_fresh_reduce no_join_mask no_ln_bwd_fusion no_in_proj_dx2 no_decoder_coop no_bn3_in_dw no_dw_bwd_one_launch no_conv4_bwd_fused no_blockout_conv1 no_conv1_bwd_fused no_join_fusion no_wgrad_groups no_bn_bwd_fa no_bn1_in_dw_fwd no_strided_join_fusion,no_ds_join_fusion; do
   TUBER_AB=$sw $B --no-roofline > $O/bench_ab_${sw//,/+}.json 2>/dev/null
 done
 TUBER_AB=no_entry_conv,no_proj_bwd_fused,no_stem_bn_in_wgrad $B --no-roofline > $O/bench_ab_no_first_block_and_stem_fusions.json 2>/dev/null

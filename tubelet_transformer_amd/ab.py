@@ -12,6 +12,7 @@ KNOWN = {
     "no_wgrad_groups": "one tuber_gemm_tn launch per weight-gradient GEMM instead of the grouped launches (engine.WgradQueue)",
     "immediate_reduce": "second-stage reductions of the weight-gradient partials per call instead of the deferred tuber_multi_reduce",
     "no_join_fusion": "stand-alone block_out_bwd instead of the join backward in the conv1 data-gradient GEMM's epilogue",
+    "no_fresh_reduce": "tuber_multi_reduce always reads the gradient window it reduces into (out += sum) instead of overwriting the windows zero_grad has just cleared",
     "no_join_mask": "the join backward reads the lower block's output y for its ReLU mask instead of the bit field tuber_block_out_fwd_mask writes (bit-identical gradients)",
     "no_strided_join_fusion": "gemm + rows_scatter_add + block_out_bwd at the stage boundaries instead of the join GEMM with the strided residual",
     "no_ds_join_fusion": "stand-alone block_out_bwd for the first block of every stage (the join kernels take identity-block joins only)",

@@ -651,10 +651,14 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(const MultiReduceEnt
     __shared__ float red[32][33];
     const int2 be = blk[blockIdx.x];
     MultiReduceEntry e = table[be.x];
+    // mode bit 3 (round 6): the gradient window is known to be zero (zero_grad ran, nothing has written it since), so the head entry does not READ it:
+    // out = sum instead of out += sum -- the same value (0 + a == a), one read of the gradient buffer less per step
+    const bool fresh = (e.mode & 8) != 0;
+    e.mode &= 7;
     if (e.mode == 0) {                       // scalar: 1024 elements per block
         const long i = (long)be.y * 1024 + threadIdx.x;
         if (i >= e.n) return;
-        float o = e.out[i];
+        float o = fresh ? 0.f : e.out[i];
         for (;;) {
             float a = 0.f;
             for (int s = 0; s < e.S; ++s) a += e.P[(long)s * e.stride + i];
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(const MultiReduceEnt
     } else if (e.mode == 2) {                // the same sums, four elements per thread: 4096 elements per block
         const long i = ((long)be.y * 1024 + threadIdx.x) * 4;
         if (i >= e.n) return;
-        float4 o = *(const float4*)(e.out + i);
+        float4 o = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(e.out + i);
         for (;;) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(const MultiReduceEnt
         const long j = (long)be.y * 32 + cl;
         float o = 0.f;
         float* op = nullptr;
-        if (rg == 0 && j < e.n) { op = e.C > 0 ? e.out + (j % e.C) * 27 + j / e.C : e.out + j; o = *op; }
+        if (rg == 0 && j < e.n) { op = e.C > 0 ? e.out + (j % e.C) * 27 + j / e.C : e.out + j; o = fresh ? 0.f : *op; }
         for (;;) {
             float a = 0.f;
             if (j < e.n) for (int s = rg; s < e.S; s += 32) a += e.P[(long)s * e.stride + j];

@@ -11,6 +11,7 @@ Layout in HBM (per model, per GPU):
 Offsets are multiples of 64 elements so every bf16 row is 16-byte aligned.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -89,6 +90,11 @@ class DeferredReduce:
         self.chunks, self.ci, self.off = [], 0, 0
         self.entries, self.outs, self.heads, self.cache = [], {}, [], {}
         self.pre_flush = None
+        # gradient windows that are known to be ZERO: filled by ParamStore.zero_grad (every window), emptied as windows are reduced into.  The first
+        # reduction into such a window does not read it (mode bit 3 of tuber_multi_reduce: out = sum instead of out += sum; round 6)
+        self.fresh = None                # None: unknown (something else may have written the buffer) -> always accumulate; else the set of outs written since zero_grad
+        self.resolve = None              # (address, n) -> the tensor slice behind it, for the debug check
+        self.check_zero = bool(os.environ.get("TUBER_CHECK_DEFER_ZERO"))     # debug: assert that a window taken as zero IS zero (eager steps only)
 
     @property
     def enabled(self):
@@ -125,7 +131,7 @@ class DeferredReduce:
         head = self.outs.get(out)
         if head is not None:             # a further contribution to the same gradient (shared parameter): chain it, order preserved
             h = self.entries[head]
-            if (h[2], h[5], h[6]) != (n, mode, int(C)):
+            if (h[2], h[5] & 7, h[6]) != (n, mode, int(C)):
                 self.flush()
                 head = None
             else:
@@ -136,6 +142,10 @@ class DeferredReduce:
         if head is None:
             self.outs[out] = len(self.entries)
             self.heads.append(len(self.entries))
+            if self.fresh is not None and not ab.on("no_fresh_reduce"):
+                if out not in self.fresh:
+                    ent[5] |= 8          # nothing has been reduced into this window since zero_grad: overwrite
+                self.fresh.add(out)
         self.entries.append(ent)
 
     def flush(self):
@@ -153,7 +163,8 @@ class DeferredReduce:
             tab = np.array(list(key), dtype=self._ENTRY)
             heads = np.array(self.heads, dtype=np.int32)
             ht = tab[heads]
-            per = np.where(ht["mode"] == 0, (ht["n"] + 1023) // 1024, np.where(ht["mode"] == 2, (ht["n"] + 4095) // 4096, (ht["n"] + 31) // 32)).astype(np.int64)
+            hm = ht["mode"] & 7
+            per = np.where(hm == 0, (ht["n"] + 1023) // 1024, np.where(hm == 2, (ht["n"] + 4095) // 4096, (ht["n"] + 31) // 32)).astype(np.int64)
             blk = np.empty((int(per.sum()), 2), np.int32)
             blk[:, 0] = np.repeat(heads, per)
             starts = np.concatenate([[0], np.cumsum(per)[:-1]])
@@ -162,6 +173,12 @@ class DeferredReduce:
                 self.cache.clear()
             hit = (torch.from_numpy(tab.view(np.uint8).copy()).to(self.device), torch.from_numpy(blk).to(self.device), len(blk))
             self.cache[key] = hit
+        if self.check_zero and not torch.cuda.is_current_stream_capturing():
+            for h in self.heads:
+                e = self.entries[h]
+                if e[5] & 8:
+                    buf = self.resolve(e[1], e[2]) if self.resolve is not None else None      # (depthwise layout: the same n elements, permuted)
+                    assert buf is None or not bool(buf.any()), "deferred reduce: window at %#x taken as zero is not" % e[1]
         lib.call("tuber_multi_reduce", hit[0], hit[1], hit[2])
         self.entries, self.outs, self.heads = [], {}, []
 
@@ -226,6 +243,11 @@ class ParamStore:
         self.coop_sync = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.coop_off = False            # set by coop_failed(): a timed-out cooperative launch switches this engine to the launch chain
         self.defer = DeferredReduce(self.device)
+
+        def _window(ptr, n, g=self.gflat):
+            o = (ptr - g.data_ptr()) // 4
+            return g[o:o + n] if 0 <= o and o + n <= g.numel() else None
+        self.defer.resolve = _window
         self.wq = WgradQueue(self)
         self.defer.pre_flush = self.wq.flush
 
@@ -278,6 +300,7 @@ class ParamStore:
     def zero_grad(self):
         self.gflat.zero_()
         self.ensure_grad_views()
+        self.defer.fresh = set()         # every gradient window is zero from here on, until something is reduced into it
 
     def begin_step(self, train):
         """new forward: call-site salts restart at 0; in training the device seed advances (captured in graphs)."""
