@@ -578,3 +578,33 @@ def test_reference_entry_scripts_import_with_this_repo_first_on_the_path(script)
     r = subprocess.run([sys.executable, "-c", _IMPORT_BLOCK_PROBE, ROOT, ref, script], capture_output=True, text=True, timeout=600,
                        cwd="/tmp", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
     assert r.returncode == 0 and "IMPORT-BLOCK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_deferred_reduce_overwrites_only_windows_zero_grad_has_cleared():
+    """engine.DeferredReduce (host logic, round 6): the head entry of a gradient window carries mode bit 3 (tuber_multi_reduce: out = sum, the
+    window is not read) only when zero_grad ran and nothing has been reduced into that window since; every other case keeps out += sum --
+    gradients cleared some other way, a second reduction into the same window (shared parameter in a later flush, gradient accumulation
+    over two backward passes), TUBER_AB=no_fresh_reduce."""
+    from tubelet_transformer_amd import ab
+    from tubelet_transformer_amd.engine import DeferredReduce
+    d = DeferredReduce(torch.device("cpu"))
+    A, B, P = 0x1000, 0x9000, 0x100000
+    d.add(P, A, 4096, 4096, 2, 0)
+    assert d.entries[0][5] & 8 == 0, "nobody called zero_grad: accumulate"
+    d.entries, d.outs, d.heads = [], {}, []
+    d.fresh = set()                                             # what ParamStore.zero_grad does
+    d.add(P, A, 4096, 4096, 2, 0)
+    d.add(P, A, 4096, 4096, 2, 0)                               # a second use of the same parameter in the same flush: chained behind the head
+    d.add(P, B, 128, 128, 4, 1)
+    heads = [d.entries[h] for h in d.heads]
+    assert [e[1] for e in heads] == [A, B] and all(e[5] & 8 for e in heads)
+    assert d.entries[0][7] == 1 and d.entries[1][5] & 8 == 0, "the chained contribution accumulates on the head's sum"
+    assert (heads[0][5] & 7, heads[1][5] & 7) == (2, 1), "the float4 form of mode 0 and the tree form keep their meaning under the flag"
+    d.entries, d.outs, d.heads = [], {}, []                     # (a flush)
+    d.add(P, A, 4096, 4096, 2, 0)                               # the same window again before the next zero_grad: accumulate
+    assert d.entries[0][5] & 8 == 0
+    d.entries, d.outs, d.heads = [], {}, []
+    d.fresh = set()
+    with ab.override("no_fresh_reduce"):
+        d.add(P, A, 4096, 4096, 2, 0)
+    assert d.entries[0][5] & 8 == 0
