@@ -44,13 +44,16 @@ def alg_cost(name, a):
             by += 2 * M * N          # mask source read
         tile, occ = {0: ("128,128,2,2,2", 2), 2: ("64,64,2,2,4", 4), 7: ("64,128,1,4,2", 3), 12: ("64,64,2,2,4", 3), 13: ("64,64,2,2,2", 4),
                      17: ("64,128,1,4,2", 4)}[cfg]
+        if amode == 0 and not a[12] and M >= 8192 and N % 64 == 0 and not out_f32 and epi in (0, 1, 2):
+            tile, occ = "96,64,2,2,2", 4     # round 6: plain-A shapes with >= 8 192 rows run on 96 x 64 tiles (gemm.hip: nt_use_96)
         return "gemm_nt_kernel<%s,%d,%d,%d>" % (tile, amode, epi, occ), by, 2 * M * N * K
-    if name == "tuber_gemm_nt_join":
+    if name in ("tuber_gemm_nt_join", "tuber_gemm_nt_join_mask"):
         M, N, K = a[6], a[7], a[8]
         cfg = lib.query("tuber_gemm_nt_cfg", M, N, K)
         tile, occ = {0: ("64,128,1,4,2", 3), 7: ("64,128,1,4,2", 3), 13: ("64,64,2,2,2", 4)}.get(cfg, ("64,64,2,2,2", 4))
-        by = 2 * (M * K + N * K + M * N) + 2 * M * N * (3 if a[9] is not None else 2)      # + residual, mask source y, statistics operand c4
-        return "gemm_nt_kernel<%s,0,3,%d>" % (tile, occ), by, 2 * M * N * K
+        masked = name.endswith("_mask")      # round 6: the ReLU mask of y as a bit field (1 bit instead of 2 bytes per element), epilogue EPI_JOIN_M = 7
+        by = 2 * (M * K + N * K + M * N) + 2 * M * N * (2 if a[9] is not None else 1) + (M * N // 8 if masked else 2 * M * N)      # + residual, statistics operand c4, mask
+        return "gemm_nt_kernel<%s,0,%d,%d>" % (tile, 7 if masked else 3, occ), by, 2 * M * N * K
     if name == "tuber_gemm_tn":
         M, N, K = a[7], a[8], a[9]
         ldg, lda, gmode = a[1], a[3], a[22] is not None
@@ -132,7 +135,7 @@ def alg_cost(name, a):
 def shape_of(name, a):
     if name == "tuber_gemm_nt":
         return "M%d N%d K%d amode%d epi%d" % (a[6], a[7], a[8], a[9], a[21])
-    if name == "tuber_gemm_nt_join":
+    if name in ("tuber_gemm_nt_join", "tuber_gemm_nt_join_mask"):
         return "M%d N%d K%d join" % (a[6], a[7], a[8])
     if name == "tuber_gemm_tn":
         return "M%d N%d K%d amode%d" % (a[7], a[8], a[9], a[10])

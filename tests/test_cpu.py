@@ -490,7 +490,7 @@ def test_bench_roofline_bookkeeping_matches_trace_names():
     files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_kernel_trace_stats.txt")) if "_cfg" not in f and "_freeze_" not in f)
     assert files, "no committed kernel-trace summary"
     one = lambda k: {k: {"bytes": 1, "ms": 1.0, "launches": 1, "flops": 0}}
-    for key in ("gemm_nt_kernel<64,128,1,4,2,0,3,3>", "bn_bwd_fa_kernel", "gemm_tn3_group_kernel", "conv1_bwd_kernel<1>", "dwconv_tile_bwd_both_kernel"):
+    for key in ("gemm_nt_kernel<64,128,1,4,2,0,7,3>", "gemm_nt_kernel<96,64,2,2,2,0,1,4>", "bn_bwd_fa_kernel", "gemm_tn3_group_kernel", "conv1_bwd_kernel<1>", "dwconv_tile_bwd_both_kernel"):
         assert bench.dominant_from_trace(one(key), True) == key, key
     assert bench.dominant_from_trace(one("no_such_kernel"), True) is None
     assert bench.dominant_from_trace(one("bn_bwd_fa_kernel"), False) is None          # other configs: no committed trace to rank by
